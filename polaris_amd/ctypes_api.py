@@ -1,0 +1,164 @@
+"""ctypes mirrors of include/polaris_types.h and the loader for the C-ABI library.
+
+The numpy dtypes below are byte-for-byte the structs of include/polaris_types.h, which are in
+turn the reference's device layouts (asset/scene/optimized_scene.go:25-190, CL/types.cl:4-187).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libpolaris_hip.so")
+
+MAX_BOUNCES = 32
+
+# ---- numpy structured dtypes (scene arrays) -------------------------------------------------
+BVH_NODE = np.dtype([("min", "<f4", 3), ("ldata", "<i4"), ("max", "<f4", 3), ("rdata", "<i4")])
+MESH_INSTANCE = np.dtype([("mesh_index", "<u4"), ("bvh_root", "<u4"), ("reserved", "<u4", 2),
+                          ("inv_transform", "<f4", 16)])
+MATERIAL_NODE = np.dtype([("type", "<u4"), ("left_child", "<u4"), ("right_child", "<i4"), ("tex", "<i4"),
+                          ("k", "<f4", 4), ("t", "<f4", 4), ("int_ior", "<f4"), ("ext_ior", "<f4"),
+                          ("scale", "<f4"), ("roughness_tex", "<i4")])
+EMISSIVE = np.dtype([("transform", "<f4", 16), ("area", "<f4"), ("tri_index", "<u4"),
+                     ("mat_node_index", "<u4"), ("type", "<u4")])
+TEXTURE_META = np.dtype([("format", "<u4"), ("width", "<u4"), ("height", "<u4"), ("data_offset", "<u4")])
+assert BVH_NODE.itemsize == 32 and MESH_INSTANCE.itemsize == 80 and MATERIAL_NODE.itemsize == 64
+assert EMISSIVE.itemsize == 80 and TEXTURE_META.itemsize == 16
+
+BXDF_INVALID, BXDF_EMISSIVE, BXDF_DIFFUSE, BXDF_CONDUCTOR = 0, 2, 4, 8
+BXDF_ROUGH_CONDUCTOR, BXDF_DIELECTRIC, BXDF_ROUGH_DIELECTRIC = 16, 32, 64
+OP_MIX, OP_MIX_MAP, OP_BUMP_MAP, OP_NORMAL_MAP, OP_DISPERSE = 10001, 10002, 10003, 10004, 10005
+TEX_L8, TEX_L32F, TEX_RGBA8, TEX_RGBA32F = 0, 1, 2, 3
+EMISSIVE_AREA, EMISSIVE_ENVIRONMENT = 0, 1
+
+
+# ---- ctypes structs -------------------------------------------------------------------------
+class SceneView(C.Structure):
+    _fields_ = [
+        ("bvh_nodes", C.c_void_p), ("num_bvh_nodes", C.c_uint32),
+        ("mesh_instances", C.c_void_p), ("num_mesh_instances", C.c_uint32),
+        ("material_nodes", C.c_void_p), ("num_material_nodes", C.c_uint32),
+        ("emissives", C.c_void_p), ("num_emissives", C.c_uint32),
+        ("texture_data", C.c_void_p), ("texture_data_bytes", C.c_uint32),
+        ("texture_meta", C.c_void_p), ("num_textures", C.c_uint32),
+        ("vertices", C.c_void_p), ("normals", C.c_void_p), ("uvs", C.c_void_p),
+        ("material_index", C.c_void_p), ("num_triangles", C.c_uint32),
+        ("scene_diffuse_mat_index", C.c_int32), ("scene_emissive_mat_index", C.c_int32),
+    ]
+
+
+class BlockRequest(C.Structure):
+    """tracer.BlockRequest (tracer/tracer.go:6-34)."""
+    _fields_ = [
+        ("frame_w", C.c_uint32), ("frame_h", C.c_uint32),
+        ("block_x", C.c_uint32), ("block_y", C.c_uint32), ("block_w", C.c_uint32), ("block_h", C.c_uint32),
+        ("samples_per_pixel", C.c_uint32), ("num_bounces", C.c_uint32), ("min_bounces_for_rr", C.c_uint32),
+        ("exposure", C.c_float), ("seed", C.c_uint32), ("accumulated_samples", C.c_uint32),
+    ]
+
+
+class TraceStats(C.Structure):
+    _fields_ = [
+        ("primary_rays", C.c_uint64), ("indirect_rays", C.c_uint64), ("occlusion_rays", C.c_uint64),
+        ("shaded_hits", C.c_uint64), ("shaded_misses", C.c_uint64), ("emitter_hits", C.c_uint64),
+        ("unoccluded", C.c_uint64),
+        ("rays_per_bounce", C.c_uint64 * MAX_BOUNCES), ("occl_per_bounce", C.c_uint64 * MAX_BOUNCES),
+        ("device_ms", C.c_double),
+    ]
+
+    def total_rays(self) -> int:
+        """BASELINE.md section 3 counting rule: primary + indirect + occlusion rays traced."""
+        return int(self.primary_rays + self.indirect_rays + self.occlusion_rays)
+
+    def algorithmic_bytes(self, pixels: int, traces: int = 1, frames: int = 1) -> int:
+        """compulsory stream bytes of the wavefront formulation."""
+        return int(112 * self.primary_rays + 68 * self.shaded_hits + 92 * self.indirect_rays
+                   + 80 * self.occlusion_rays + 44 * self.unoccluded + 60 * self.shaded_misses
+                   + 24 * self.emitter_hits + 48 * pixels * traces + 16 * pixels * frames)
+
+    def as_dict(self) -> dict:
+        d = {k: int(getattr(self, k)) for k in ("primary_rays", "indirect_rays", "occlusion_rays", "shaded_hits",
+                                                  "shaded_misses", "emitter_hits", "unoccluded")}
+        d["rays_per_bounce"] = [int(v) for v in self.rays_per_bounce]
+        d["occl_per_bounce"] = [int(v) for v in self.occl_per_bounce]
+        d["device_ms"] = float(self.device_ms)
+        return d
+
+
+def _ptr(a):
+    return None if a is None or a.size == 0 else a.ctypes.data_as(C.c_void_p)
+
+
+def scene_view(scene) -> SceneView:
+    """Borrow a polaris_amd.scenes.Scene's arrays as a PolarisSceneView (arrays must stay alive)."""
+    v = SceneView()
+    v.bvh_nodes, v.num_bvh_nodes = _ptr(scene.bvh_nodes), len(scene.bvh_nodes)
+    v.mesh_instances, v.num_mesh_instances = _ptr(scene.mesh_instances), len(scene.mesh_instances)
+    v.material_nodes, v.num_material_nodes = _ptr(scene.material_nodes), len(scene.material_nodes)
+    v.emissives, v.num_emissives = _ptr(scene.emissives), len(scene.emissives)
+    v.texture_data, v.texture_data_bytes = _ptr(scene.texture_data), scene.texture_data.size
+    v.texture_meta, v.num_textures = _ptr(scene.texture_meta), len(scene.texture_meta)
+    v.vertices, v.normals, v.uvs = _ptr(scene.vertices), _ptr(scene.normals), _ptr(scene.uvs)
+    v.material_index, v.num_triangles = _ptr(scene.material_index), len(scene.material_index)
+    v.scene_diffuse_mat_index = int(scene.scene_diffuse_mat_index)
+    v.scene_emissive_mat_index = int(scene.scene_emissive_mat_index)
+    return v
+
+
+# Every symbol include/polaris_hip.h declares; tests check the built library exports all of them.
+C_ABI_SYMBOLS = [
+    "polaris_hip_device_count", "polaris_hip_device_info", "polaris_hip_create", "polaris_hip_destroy",
+    "polaris_hip_last_error", "polaris_hip_resize", "polaris_hip_upload_scene", "polaris_hip_set_camera",
+    "polaris_hip_set_option", "polaris_hip_trace", "polaris_hip_merge", "polaris_hip_export_block",
+    "polaris_hip_merge_device", "polaris_hip_sync_framebuffer", "polaris_hip_read_framebuffer",
+    "polaris_hip_read_accumulator", "polaris_hip_tap_primary", "polaris_hip_abi_version",
+    "polaris_hip_kernel_ms",
+]
+
+_lib = None
+
+
+def load_library(path: str | None = None) -> C.CDLL:
+    """Load libpolaris_hip.so (built in-tree by __graft_entry__.build()).  Fails loudly if absent:
+    there is no CPU fallback for the product path."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(f"{p} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; "
+                           f"g.build()'); the tracer has no CPU fallback")
+    lib = C.CDLL(p)
+    vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
+    lib.polaris_hip_abi_version.restype = i32
+    lib.polaris_hip_device_count.restype = i32
+    lib.polaris_hip_device_info.argtypes = [i32, C.c_char_p, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_uint64)]
+    lib.polaris_hip_create.argtypes = [i32, C.POINTER(vp)]
+    lib.polaris_hip_destroy.argtypes = [vp]
+    lib.polaris_hip_destroy.restype = None
+    lib.polaris_hip_last_error.argtypes = [vp]
+    lib.polaris_hip_last_error.restype = C.c_char_p
+    lib.polaris_hip_resize.argtypes = [vp, u32, u32]
+    lib.polaris_hip_upload_scene.argtypes = [vp, C.POINTER(SceneView)]
+    lib.polaris_hip_set_camera.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.polaris_hip_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    lib.polaris_hip_trace.argtypes = [vp, C.POINTER(BlockRequest), C.POINTER(u32), C.c_size_t, C.POINTER(TraceStats)]
+    lib.polaris_hip_merge.argtypes = [vp, vp, C.POINTER(BlockRequest)]
+    lib.polaris_hip_export_block.argtypes = [vp, C.POINTER(BlockRequest), vp]
+    lib.polaris_hip_merge_device.argtypes = [vp, vp, C.POINTER(BlockRequest)]
+    lib.polaris_hip_sync_framebuffer.argtypes = [vp, C.POINTER(BlockRequest)]
+    lib.polaris_hip_read_framebuffer.argtypes = [vp, vp, C.c_size_t]
+    lib.polaris_hip_read_accumulator.argtypes = [vp, i32, vp, C.c_size_t]
+    lib.polaris_hip_tap_primary.argtypes = [vp, C.POINTER(BlockRequest), u32, vp, vp, vp, vp]
+    lib.polaris_hip_kernel_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    for name in C_ABI_SYMBOLS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int and name not in ("polaris_hip_device_count", "polaris_hip_abi_version"):
+            pass
+    if path is None:
+        _lib = lib
+    return lib
