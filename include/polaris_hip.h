@@ -1,0 +1,140 @@
+/*
+ * polaris_hip.h -- C ABI of the MI355X (gfx950) tracer backend for polaris.
+ *
+ * This is the drop-in boundary: exactly what a Go package `tracer/hip` implementing
+ * tracer.Tracer (reference tracer/tracer.go:80-111) binds through cgo, replacing
+ * tracer/opencl (+ tracer/opencl/device).  Plain pointers and sizes only; no C++/torch
+ * types; every function returns 0 on success or a POLARIS_E_* code, never throws/aborts.
+ * INTEGRATION.md shows the Go side.
+ *
+ * Method-by-method correspondence (reference file:line -> entry point):
+ *   device.GetPlatformInfo / SelectDevices, Speed estimate
+ *       tracer/opencl/device/platform.go, device.go:209-222  -> polaris_hip_device_count/_info
+ *   opencl.NewTracer + Tracer.Init   tracer/opencl/tracer.go:58-117      -> polaris_hip_create
+ *   Tracer.Close                     tracer/opencl/tracer.go:120-145     -> polaris_hip_destroy
+ *   Tracer.UpdateState(FrameDimensions)  tracer.go:169-171 -> buffers.go:127-174 Resize
+ *                                                                        -> polaris_hip_resize
+ *   Tracer.UpdateState(SceneData)    tracer.go:172-174 -> buffers.go:180-201 UploadSceneData
+ *                                                                        -> polaris_hip_upload_scene
+ *   Tracer.UpdateState(CameraData)   tracer.go:175-179                   -> polaris_hip_set_camera
+ *   Tracer.Trace                     tracer.go:194-247 + pipeline.go:94-213 -> polaris_hip_trace
+ *   Tracer.MergeOutput               tracer.go:279-286, resources.go:108-124 -> polaris_hip_merge
+ *   Tracer.SyncFramebuffer           tracer.go:250-276, resources.go:344-360 -> polaris_hip_sync_framebuffer
+ *   SaveFrameBuffer's ReadData       pipeline.go:226-232                 -> polaris_hip_read_framebuffer
+ *   errors                           tracer/opencl/errors.go:5-22        -> POLARIS_E_* + polaris_hip_last_error
+ *
+ * Threading: any entry point may be called from any OS thread (goroutines migrate); each
+ * call binds the handle's device.  Calls on ONE handle are serialised by a per-handle mutex;
+ * polaris_hip_merge(dst, src, ..) may be called concurrently from several threads onto one
+ * dst (renderer/default.go:188-191 does exactly that) and with src == dst.
+ * Ownership: the library copies everything it needs before returning; no caller pointer is
+ * retained (cgo rule).
+ */
+#ifndef POLARIS_HIP_H
+#define POLARIS_HIP_H
+
+#include "polaris_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define POLARIS_HIP_ABI_VERSION 1
+
+/* status codes (0 = ok).  The first three mirror tracer/opencl/errors.go sentinels. */
+#define POLARIS_OK                0
+#define POLARIS_E_NO_SCENE_DATA   1  /* ErrNoSceneData: Trace/Sync before a scene upload (tracer.go:203-205,254-256) */
+#define POLARIS_E_BAD_ARGUMENT    2  /* null pointer, block outside frame, too many bounces, short seed list */
+#define POLARIS_E_NO_DEVICE       3  /* device index out of range / no HIP device */
+#define POLARIS_E_DEVICE          4  /* a HIP runtime call failed; text in last_error */
+#define POLARIS_E_BAD_SCENE       5  /* scene arrays inconsistent (index out of range, BVH deeper than the traversal stack) */
+#define POLARIS_E_UNSUPPORTED     6  /* e.g. merge between handles that cannot reach each other */
+
+typedef struct polaris_hip_tracer polaris_hip_tracer; /* opaque */
+
+int polaris_hip_abi_version(void);
+
+/* Device enumeration.  Speed estimate of the reference = compute_units * clock_mhz / 1000
+ * (tracer/opencl/device/device.go:219); the Go side computes it from these two numbers. */
+int polaris_hip_device_count(void);
+int polaris_hip_device_info(int index, char name[256], uint32_t *compute_units, uint32_t *clock_mhz,
+                            uint64_t *global_mem_bytes);
+
+int polaris_hip_create(int device_index, polaris_hip_tracer **out);
+void polaris_hip_destroy(polaris_hip_tracer *h);
+
+/* Text of the last error on this handle (or, with h == NULL, of the calling thread's last
+ * failed create/device call).  Valid until the next call on the same handle/thread. */
+const char *polaris_hip_last_error(polaris_hip_tracer *h);
+
+/* (Re)allocate every frame-sized buffer; clears the frame accumulator. */
+int polaris_hip_resize(polaris_hip_tracer *h, uint32_t frame_w, uint32_t frame_h);
+
+/* Validate, re-lay-out for traversal and upload the scene.  Everything is copied. */
+int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *scene);
+
+/* eye[3]; frustum[16] = corner rays TL, TR, BL, BR as float4 (scene.Camera.Frustrum). */
+int polaris_hip_set_camera(polaris_hip_tracer *h, const float eye[3], const float frustum[16]);
+
+/* Tunables (not part of the reference interface).  Keys:
+ *   "samples_per_batch"  samples traced concurrently as one wavefront batch (default: auto)
+ *   "exact_accumulate"   1 = add every contribution straight into the trace accumulator in
+ *                        the reference's order (forces one sample per batch; bit-exact with
+ *                        the CPU oracle), 0 = per-path radiance + ordered resolve (default)
+ *   "packet_primary"     1 = wave-packet traversal for primary rays (default), 0 = per-ray
+ *   "time_kernels"       1 = bracket every kernel with HIP events (polaris_hip_kernel_ms) */
+int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value);
+
+/*
+ * Tracer.Trace: clears the frame accumulator if req->accumulated_samples == 0, clears the
+ * trace accumulator, then traces req->samples_per_pixel samples over rows
+ * [block_y, block_y+block_h).  The host PRNG draws of the reference (Go math/rand: one per
+ * sample, tracer.go:222, plus one per bounce, pipeline.go:146) are passed in explicitly:
+ *   seeds[s*(1+num_bounces)]       camera seed of sample s
+ *   seeds[s*(1+num_bounces)+1+b]   shade seed of bounce b of sample s
+ * n_seeds >= samples_per_pixel*(1+num_bounces).  Blocks until the device is done (the
+ * reference's Trace is synchronous: every launch ends in clFinish, device/kernel.go:124).
+ * stats may be NULL.
+ */
+int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *req, const uint32_t *seeds,
+                      size_t n_seeds, PolarisTraceStats *stats);
+
+/* Tracer.MergeOutput: dst.frameAccumulator[rows of req] += src.traceAccumulator[rows of req].
+ * Asynchronous on dst's merge stream like the reference (Exec1DNoWait, resources.go:119);
+ * completed by polaris_hip_sync_framebuffer(dst).  src may live on another GPU of the same
+ * process (peer access over xGMI, falling back to a staged peer copy). */
+int polaris_hip_merge(polaris_hip_tracer *dst, polaris_hip_tracer *src, const PolarisBlockRequest *req);
+
+/* One-process-per-GPU variant of the same exchange (bench.py under torch.distributed):
+ * export copies the block's rows of the trace accumulator (block_h*frame_w float4) to a device
+ * buffer the caller owns; merge_device adds such a strip, resident on dst's device, into
+ * dst's frame accumulator. */
+int polaris_hip_export_block(polaris_hip_tracer *h, const PolarisBlockRequest *req, void *device_dst);
+int polaris_hip_merge_device(polaris_hip_tracer *dst, const void *device_rows, const PolarisBlockRequest *req);
+
+/* Tracer.SyncFramebuffer: wait for pending merges, then tonemapSimpleReinhard over rows of
+ * req with weight 1/(accumulated_samples+samples_per_pixel) into the RGBA8 frame buffer. */
+int polaris_hip_sync_framebuffer(polaris_hip_tracer *h, const PolarisBlockRequest *req);
+
+/* frame_w*frame_h*4 bytes RGBA8 (pipeline.go:226-232). */
+int polaris_hip_read_framebuffer(polaris_hip_tracer *h, uint8_t *rgba, size_t n_bytes);
+
+/* Radiance-level read-back for parity tests (no reference counterpart): which = 0 trace
+ * accumulator, 1 frame accumulator; n_floats = frame_w*frame_h*4 (float3 at stride 4). */
+int polaris_hip_read_accumulator(polaris_hip_tracer *h, int which, float *out, size_t n_floats);
+
+/* Test tap: generate + intersect the primary rays of one sample with camera seed `seed` and
+ * return rays [N][8], hit flags [N], (w,u,v,t) [N][4] and (instance, triangle) [N][2];
+ * N = frame_w*block_h.  Any output pointer may be NULL. */
+int polaris_hip_tap_primary(polaris_hip_tracer *h, const PolarisBlockRequest *req, uint32_t seed,
+                            float *rays, int32_t *hit, float *wuvt, int32_t *tri);
+
+/* With option time_kernels=1: accumulated device milliseconds and launch count of the named
+ * kernel ("generate", "intersect", "shade", "occlusion", "scan", "resolve", ...) since the
+ * last call for that name. */
+int polaris_hip_kernel_ms(polaris_hip_tracer *h, const char *kernel, double *ms, uint64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POLARIS_HIP_H */

@@ -1,0 +1,482 @@
+// kernels.h -- the gfx950 kernels of the polaris wavefront path tracer.
+//
+// Formulation (DESIGN.md has the full picture).  K samples of the block are traced as ONE
+// wavefront batch: slot = sample * Npad + index, Npad = N rounded up to the 256-thread
+// workgroup, so a workgroup never straddles two samples.  Every stream is a float4 array
+// (one 16 B access per lane = the coalescing sweet spot of the guide):
+//     ray_o  = origin.xyz | max distance          ray_d = direction.xyz | path word
+//     thr    = path throughput.xyz | -            hit   = u | v | t | triangle (-1 = miss)
+//     occ_o / occ_d / occ_e = shadow ray origin|maxDist, dir|accumulator index, NEE radiance
+//     lsum   = per-path radiance of this batch (resolved into the trace accumulator in
+//              sample order at the end of the batch)
+// path word = path index (24 bit, the reference keeps it as a float in dir.w,
+// util/ray.cl:9-12) | dispersion flags << 24 (util/path.cl:4-6).
+//
+// Compaction is per WORKGROUP, in place and stable: surviving rays of a workgroup's 256 slots
+// are packed to the front of the same 256 slots (ballot + popcount ranks inside a wave, LDS
+// across the 4 waves); cnt[wg] says how many are live and a tiny segmented scan turns the
+// counts into pfx[wg], the position the workgroup's first ray WOULD have in the reference's
+// globally compacted buffer.  pfx + lane is therefore exactly the `globalId` the reference
+// seeds the shading PRNG with (kernels/pt_integrator.cl:81) when its atomic compaction runs
+// in work-item order -- without ever moving a ray out of its pixel neighbourhood, without a
+// grid-wide dependency inside the shading kernel, and without host round trips.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "scene_layout.h"
+#include "shading.h"
+
+namespace pol {
+
+constexpr int WG = 256;            // threads per workgroup (4 wave64)
+constexpr int kExitMarker = (int)0x80000000;
+
+struct PairNode { float4 lo0, hi0, lo1, hi1; };  // .w of lo0/lo1 carry the child refs (int bits)
+struct TriRec { float4 v0, e1, e2; };             // v0.w carries the DFS rank (uint bits)
+struct InstRec { float4 r0, r1, r2; int4 meta; }; // meta.x = root ref, meta.y = rank
+
+struct BvhDev {
+	const PairNode *pairs;
+	const int2 *leaves;
+	const TriRec *tris;
+	const InstRec *insts;
+	int root_ref;
+};
+
+struct Streams {
+	float4 *ray_o, *ray_d, *thr, *hit;
+	float4 *occ_o, *occ_d, *occ_e;
+	float4 *lsum;
+	uint32_t *cnt_ray, *cnt_occ, *pfx;
+	int *hit_inst; // optional (test tap): instance id per slot, may be null
+};
+
+// device-side counters of one Trace call (mirrors PolarisTraceStats, all uint64)
+enum StatSlot { ST_SHADED_HITS = 0, ST_SHADED_MISSES, ST_EMITTER_HITS, ST_UNOCCLUDED, ST_RAYS_BOUNCE, ST_OCCL_BOUNCE = ST_RAYS_BOUNCE + POLARIS_MAX_BOUNCES, ST_COUNT = ST_OCCL_BOUNCE + POLARIS_MAX_BOUNCES };
+
+__device__ __forceinline__ int fbits(float f) { return __float_as_int(f); }
+__device__ __forceinline__ float ibits(int i) { return __int_as_float(i); }
+
+// ------------------------------------------------------------------------------------------
+// generatePrimaryRays, kernels/camera.cl:5-58  (+ the per-workgroup bookkeeping of this design)
+// ------------------------------------------------------------------------------------------
+struct CameraArgs { float4 tl, tr, bl, br; float3 eye; float2 texel; };
+
+__global__ __launch_bounds__(WG) void k_generate(Streams st, CameraArgs cam, const uint32_t *seeds, uint32_t seed_stride,
+                                                  uint32_t first_sample, uint32_t N, uint32_t Npad, uint32_t W, uint32_t blockY,
+                                                  int zero_lsum) {
+	const uint32_t wgs_per_sample = Npad / WG;
+	const uint32_t s = blockIdx.x / wgs_per_sample;
+	const uint32_t idx0 = (blockIdx.x % wgs_per_sample) * WG;
+	const uint32_t idx = idx0 + threadIdx.x;
+	const size_t slot = (size_t)blockIdx.x * WG + threadIdx.x;
+	if (threadIdx.x == 0) {
+		st.cnt_ray[blockIdx.x] = idx0 < N ? min((uint32_t)WG, N - idx0) : 0u;
+		st.pfx[blockIdx.x] = idx0; // rays are dense at bounce 0: reference position == index
+	}
+	if (idx >= N) return;
+	const uint32_t seed = seeds[(size_t)(first_sample + s) * seed_stride];
+	const uint32_t gx = idx % W, gy = idx / W;
+	Rng rng = {gx + seed, gy + seed}; // camera.cl:38
+	f2 s0 = rng_next(rng);
+	float ox = s0.x < 0.5f ? pm_sqrt(2.0f * s0.x) - 0.5f : 1.5f - pm_sqrt(2.0f - 2.0f * s0.x);
+	float oy = s0.y < 0.5f ? pm_sqrt(2.0f * s0.y) - 0.5f : 1.5f - pm_sqrt(2.0f - 2.0f * s0.y);
+	float tx = ((float)gx + ox) * cam.texel.x;
+	float ty = ((float)(gy + blockY) + oy) * cam.texel.y;
+	// mix(mix(TL, BL, ty), mix(TR, BR, ty), tx), then normalize over all four lanes (w = 0)
+	float lx = pm_mix(cam.tl.x, cam.bl.x, ty), ly = pm_mix(cam.tl.y, cam.bl.y, ty), lz = pm_mix(cam.tl.z, cam.bl.z, ty), lw = pm_mix(cam.tl.w, cam.bl.w, ty);
+	float rx = pm_mix(cam.tr.x, cam.br.x, ty), ry = pm_mix(cam.tr.y, cam.br.y, ty), rz = pm_mix(cam.tr.z, cam.br.z, ty), rw = pm_mix(cam.tr.w, cam.br.w, ty);
+	float dx = pm_mix(lx, rx, tx), dy = pm_mix(ly, ry, tx), dz = pm_mix(lz, rz, tx), dw = pm_mix(lw, rw, tx);
+	float inv = 1.0f / pm_sqrt(dx * dx + dy * dy + dz * dz + dw * dw);
+	st.ray_o[slot] = make_float4(cam.eye.x, cam.eye.y, cam.eye.z, kFltMax);
+	st.ray_d[slot] = make_float4(dx * inv, dy * inv, dz * inv, ibits((int)idx));
+	st.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+	if (zero_lsum) st.lsum[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// ------------------------------------------------------------------------------------------
+// BVH traversal.  Results follow kernels/intersect.cl:184-347 (closest hit) and :26-180 (any
+// hit): identical slab test, identical Moeller-Trumbore arithmetic, so the set of candidate
+// hits and every t/u/v are bit-identical; the ORDER of traversal is ours (near child first,
+// subtrees beyond the current best culled with a conservative margin), which cannot change the
+// minimum -- exact ties are resolved by DFS rank = "first tested wins" of the reference.
+// One lane = one ray; the node stack is a per-lane column of an LDS array ([depth][lane], so
+// a wave's accesses are conflict free).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float slab_entry(float4 lo, float4 hi, f3 o, f3 inv, float maxDist) { // intersect.cl:301-309
+	float t0x = (lo.x - o.x) * inv.x, t0y = (lo.y - o.y) * inv.y, t0z = (lo.z - o.z) * inv.z;
+	float t1x = (hi.x - o.x) * inv.x, t1y = (hi.y - o.y) * inv.y, t1z = (hi.z - o.z) * inv.z;
+	float minmax = pm_fmin(pm_fmin(pm_fmax(t0x, t1x), pm_fmax(t0y, t1y)), pm_fmax(t0z, t1z));
+	float maxmin = pm_fmax(pm_fmax(pm_fmin(t0x, t1x), pm_fmin(t0y, t1y)), pm_fmin(t0z, t1z));
+	return (minmax < 0 || maxmin > minmax) ? kFltMax : (maxmin >= maxDist ? kFltMax : maxmin);
+}
+
+struct HitRec { float t, u, v; int tri; int inst; uint32_t irank, trank; };
+
+template <bool ANY_HIT>
+__device__ __forceinline__ bool traverse(const BvhDev &B, f3 O, f3 D, float maxDist, int (*stk)[WG], HitRec &best) {
+	const int lane = threadIdx.x;
+	int sp = 0;
+	int cur = B.root_ref;
+	f3 o = O, d = D;
+	f3 inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)}; // native_recip(ray.dir), intersect.cl:302
+	int inst = 0;
+	uint32_t irank = 0;
+	best.t = maxDist; best.tri = -1; best.inst = 0; best.u = best.v = 0.0f; best.irank = best.trank = 0;
+	for (;;) {
+		if (cur >= 0) { // inner node: test both children
+			const PairNode P = B.pairs[cur];
+			float t0 = slab_entry(P.lo0, P.hi0, o, inv, maxDist);
+			float t1 = slab_entry(P.lo1, P.hi1, o, inv, maxDist);
+			if (!ANY_HIT) { // cull subtrees that start beyond the best hit (margin >> rounding of t)
+				const float lim = best.t * 1.001f;
+				if (t0 > lim) t0 = kFltMax;
+				if (t1 > lim) t1 = kFltMax;
+			}
+			int c0 = fbits(P.lo0.w), c1 = fbits(P.lo1.w);
+			const bool h0 = t0 < kFltMax, h1 = t1 < kFltMax;
+			if (h0 && h1) {
+				if (t1 < t0) { int t = c0; c0 = c1; c1 = t; }
+				stk[sp++][lane] = c1;
+				cur = c0;
+				continue;
+			}
+			if (h0 || h1) { cur = h0 ? c0 : c1; continue; }
+		} else { // leaf (cur = ~node)
+			const int2 li = B.leaves[~cur];
+			if (li.y == 0) { // top-level leaf: enter the mesh instance (intersect.cl:239-252)
+				inst = -li.x;
+				const InstRec I = B.insts[inst];
+				irank = (uint32_t)I.meta.y;
+				stk[sp++][lane] = kExitMarker;
+				// mul4x1 / mul3x1, util/transform.cl:9-26
+				f3 no = {I.r0.x * o.x + I.r0.y * o.y + I.r0.z * o.z + I.r0.w, I.r1.x * o.x + I.r1.y * o.y + I.r1.z * o.z + I.r1.w,
+				         I.r2.x * o.x + I.r2.y * o.y + I.r2.z * o.z + I.r2.w};
+				f3 nd = {I.r0.x * d.x + I.r0.y * d.y + I.r0.z * d.z, I.r1.x * d.x + I.r1.y * d.y + I.r1.z * d.z,
+				         I.r2.x * d.x + I.r2.y * d.y + I.r2.z * d.z};
+				o = no; d = nd;
+				inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)};
+				cur = I.meta.x;
+				continue;
+			}
+			const int first = -li.x;
+			for (int t = first; t < first + li.y; t++) { // Moeller-Trumbore, intersect.cl:255-292
+				const TriRec T = B.tris[t];
+				f3 e1 = xyz(T.e1), e2 = xyz(T.e2);
+				f3 pv = cross(d, e2);
+				float det = dot(e1, pv);
+				if (pm_fabs(det) < kEps) continue;
+				float idet = pm_rcp(det);
+				f3 tv = o - xyz(T.v0);
+				float u = dot(tv, pv) * idet;
+				if (u < 0.0f || u > 1.0f) continue;
+				f3 qv = cross(tv, e1);
+				float v = dot(d, qv) * idet;
+				if (v < 0.0f || u + v > 1.0f) continue;
+				float tt = dot(e2, qv) * idet;
+				if (ANY_HIT) {
+					if (tt > kEps && tt < maxDist) return true;
+				} else if (tt > kEps) {
+					const uint32_t trank = (uint32_t)fbits(T.v0.w);
+					const bool closer = tt < best.t;
+					const bool tie = tt == best.t && best.tri >= 0 && (irank < best.irank || (irank == best.irank && trank < best.trank));
+					if (closer || tie) { best.t = tt; best.u = u; best.v = v; best.tri = t; best.inst = inst; best.irank = irank; best.trank = trank; }
+				}
+			}
+		}
+		// pop
+		for (;;) {
+			if (sp == 0) return best.tri >= 0;
+			cur = stk[--sp][lane];
+			if (cur != kExitMarker) break;
+			o = O; d = D; // leaving the instance: restore the world-space ray (intersect.cl:330-335)
+			inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)};
+		}
+	}
+}
+
+// rayIntersectionQuery: closest hit for the live rays of every workgroup.
+__global__ __launch_bounds__(WG) void k_intersect(Streams st, BvhDev B) {
+	__shared__ int stk[kTraversalStack][WG];
+	if (threadIdx.x >= st.cnt_ray[blockIdx.x]) return;
+	const size_t slot = (size_t)blockIdx.x * WG + threadIdx.x;
+	const float4 o4 = st.ray_o[slot], d4 = st.ray_d[slot];
+	HitRec h;
+	traverse<false>(B, xyz(o4), xyz(d4), o4.w, stk, h);
+	st.hit[slot] = make_float4(h.u, h.v, h.t, ibits(h.tri));
+	if (st.hit_inst) st.hit_inst[slot] = h.inst;
+}
+
+// rayIntersectionTest + accumulateEmissiveSamples (intersect.cl:26-180, pt_integrator.cl:278-296)
+// fused: an unoccluded shadow ray adds its NEE radiance straight to its accumulator cell.
+__global__ __launch_bounds__(WG) void k_occlusion(Streams st, BvhDev B, float4 *acc, unsigned long long *stats) {
+	__shared__ int stk[kTraversalStack][WG];
+	if (threadIdx.x >= st.cnt_occ[blockIdx.x]) return;
+	const size_t slot = (size_t)blockIdx.x * WG + threadIdx.x;
+	const float4 o4 = st.occ_o[slot], d4 = st.occ_d[slot];
+	HitRec h;
+	const bool occluded = traverse<true>(B, xyz(o4), xyz(d4), o4.w, stk, h);
+	if (!occluded) {
+		const float4 e = st.occ_e[slot];
+		float4 *cell = acc + (uint32_t)fbits(d4.w);
+		float4 a = *cell; // one path per cell and launch: plain read-modify-write
+		a.x += e.x; a.y += e.y; a.z += e.z;
+		*cell = a;
+	}
+	const unsigned long long m = __ballot(!occluded);
+	if (m != 0 && (threadIdx.x & 63) == (__ffsll((long long)m) - 1)) atomicAdd(&stats[ST_UNOCCLUDED], (unsigned long long)__popcll(m));
+}
+
+// ------------------------------------------------------------------------------------------
+// shadeHits (+ shadePrimaryRayMisses / shadeIndirectRayMisses), kernels/pt_integrator.cl:17-275
+// ------------------------------------------------------------------------------------------
+struct ShadeArgs {
+	const uint32_t *seeds; uint32_t seed_stride, first_sample; // shade seed of sample s: seeds[(first+s)*stride + 1 + bounce]
+	uint32_t N, Npad, W, blockY;
+	uint32_t bounce, min_rr;
+	int last_bounce;   // no closest-hit query follows (pipeline.go:203): do not emit indirect rays
+	int exact;         // accumulate into acc[pixelIndex] (trace accumulator) instead of lsum[path slot]
+	float4 *acc;       // trace accumulator (exact) or lsum (batched)
+};
+
+__global__ __launch_bounds__(WG) void k_shade(Streams st, SceneDev S, ShadeArgs A, unsigned long long *stats) {
+	__shared__ uint32_t wave_ind[4], wave_occ[4];
+	__shared__ uint32_t blk_stats[3];
+	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const uint32_t cnt = st.cnt_ray[blockIdx.x];
+	if (cnt == 0) { // uniform exit: nothing live in this workgroup
+		if (tid == 0) st.cnt_occ[blockIdx.x] = 0;
+		return;
+	}
+	if (tid < 3) blk_stats[tid] = 0;
+	const uint32_t wgs_per_sample = A.Npad / WG;
+	const uint32_t s = blockIdx.x / wgs_per_sample;
+	const size_t base = (size_t)blockIdx.x * WG;
+	const size_t slot = base + tid;
+	const bool active = tid < cnt;
+
+	bool emit_ind = false, emit_occ = false;
+	float4 n_ro, n_rd, n_thr, n_oo, n_od, n_oe;
+	uint32_t n_hit = 0, n_miss = 0, n_emit = 0;
+
+	if (active) {
+		const float4 d4 = st.ray_d[slot];
+		const float4 t4 = st.thr[slot];
+		const float4 h4 = st.hit[slot];
+		const uint32_t pword = (uint32_t)fbits(d4.w);
+		const uint32_t path_index = pword & 0xFFFFFFu;
+		uint32_t flags = pword >> 24;
+		const uint32_t pixel_index = A.blockY * A.W + path_index; // camera.cl:32-33
+		const uint32_t cell = A.exact ? pixel_index : (uint32_t)(s * A.Npad + path_index);
+		f3 thr = xyz(t4);
+		const int tri = fbits(h4.w);
+		if (tri < 0) {
+			if (S.bg_node >= 0) { // pt_integrator.cl:214-275 (throughput is exactly 1 for primaries)
+				const PolarisMaterialNode *bg = S.nodes + S.bg_node;
+				f2 uv = latlong_uv(xyz(d4));
+				f3 kd = mat_color(uv, bg->k, bg->tex, S);
+				f3 add = A.bounce == 0 ? kd : thr * kd;
+				float4 a = A.acc[cell];
+				a.x += add.x; a.y += add.y; a.z += add.z;
+				A.acc[cell] = a;
+				n_miss = 1;
+			}
+		} else {
+			n_hit = 1;
+			// PRNG: (seed, position in the reference's compacted buffer), pt_integrator.cl:81-84
+			Rng rng = {A.seeds[(size_t)(A.first_sample + s) * A.seed_stride + 1 + A.bounce], st.pfx[blockIdx.x] + tid};
+			const f2 sample0 = rng_next(rng), sample1 = rng_next(rng), sample2 = rng_next(rng);
+			const f3 in_dir = -xyz(d4);
+			// surfaceInit, util/surface.cl:12-33
+			const float bu = h4.x, bv = h4.y, bw = 1.0f - (bu + bv); // intersect.cl:283-286
+			const uint32_t off = (uint32_t)tri * 3;
+			Surf sf;
+			{
+				float4 a = S.vertices[off], b = S.vertices[off + 1], c = S.vertices[off + 2];
+				sf.p = mk3(bw * a.x + bu * b.x + bv * c.x, bw * a.y + bu * b.y + bv * c.y, bw * a.z + bu * b.z + bv * c.z);
+				a = S.normals[off]; b = S.normals[off + 1]; c = S.normals[off + 2];
+				sf.n = normalize(mk3(bw * a.x + bu * b.x + bv * c.x, bw * a.y + bu * b.y + bv * c.y, bw * a.z + bu * b.z + bv * c.z));
+				float2 ua = S.uvs[off], ub = S.uvs[off + 1], uc = S.uvs[off + 2];
+				sf.uv = {bw * ua.x + bu * ub.x + bv * uc.x, bw * ua.y + bu * ub.y + bv * uc.y};
+			}
+			f3 tint = splat(1.0f);
+			const Mat m = select_material(S.mat_index[tri], sf, flags, tint, rng, S);
+			const float in_dot_n = dot(in_dir, sf.n);
+			if (m.type == POLARIS_BXDF_EMISSIVE) { // pt_integrator.cl:101-107 (indexed by pixel: SURVEY 5.8)
+				if (in_dot_n > 0.0f) {
+					f3 add = thr * m.nd->scale * mat_color(sf.uv, m.nd->k, m.nd->tex, S);
+					float4 a = A.acc[cell];
+					a.x += add.x; a.y += add.y; a.z += add.z;
+					A.acc[cell] = a;
+					n_emit = 1;
+				}
+			} else {
+				bool reject = m.type == POLARIS_BXDF_INVALID;
+				if (A.bounce >= A.min_rr) { // Russian roulette, :113-125
+					float p = pm_max(pm_min(0.5f, 0.2126f * thr.x + 0.7152f * thr.y + 0.0722f * thr.z), 0.01f);
+					if (p < sample2.x) reject = true;
+					else thr = thr / p;
+				}
+				if (!reject) {
+					f3 out_dir = splat(0.0f);
+					float bxdf_pdf = 1.0f, bxdf_weight = 1.0f;
+					const f3 bxdf_val = bxdf_sample(sf, m, S, sample0, in_dir, out_dir, bxdf_pdf);
+					const float displace = pm_sign(dot(sf.n, out_dir));
+					const f3 ind_origin = sf.p + (sf.n * displace) * kEps;  // DISPLACE_BY_EPSILON, :134
+					const f3 occ_origin = sf.p + sf.n * kEps;               // :136
+					// light selection + sampling + MIS, :139-155
+					f3 e_dir = splat(0.0f), e_rad = splat(0.0f);
+					float e_pdf = 0.0f, sel_pdf = 0.0f, e_weight = 0.0f, e_dist = 0.0f;
+					const PolarisEmissive *em = nullptr;
+					if (S.num_emissives > 0) {
+						sel_pdf = pm_rcp((float)(int)S.num_emissives); // emissiveSelect, emissive_sampler.cl:226-237
+						const int ei = pm_clampi((int)(sample1.x * (int)S.num_emissives), 0, (int)S.num_emissives - 1);
+						em = S.emissives + ei;
+						const LightSample L = light_sample(sf, em, S, sample1);
+						e_dir = L.dir; e_rad = L.radiance; e_pdf = L.pdf; e_dist = L.dist;
+					}
+					const float n_dot_e = pm_max(0.0f, dot(sf.n, e_dir));
+					const bool want_nee = maxcomp(e_rad) > 0.0f && e_pdf > 0.0f && n_dot_e > 0.0f; // :158
+					if (em) {
+						float bxdf_e_pdf;
+						f3 bxdf_e_val;
+						bxdf_pdf_eval(sf, m, S, in_dir, e_dir, want_nee, bxdf_e_pdf, bxdf_e_val);
+						e_weight = (e_pdf * e_pdf) / (e_pdf * e_pdf + bxdf_e_pdf * bxdf_e_pdf);       // POWER_HEURISTIC, :149
+						const float e_bxdf_pdf = light_pdf(sf, em, S, out_dir);
+						bxdf_weight = (bxdf_pdf * bxdf_pdf) / (bxdf_pdf * bxdf_pdf + e_bxdf_pdf * e_bxdf_pdf); // :154
+						if (want_nee) {
+							e_rad = e_rad * (e_weight * bxdf_e_val * thr * n_dot_e / (e_pdf * sel_pdf)); // :160
+							if (maxcomp(e_rad) > 0.0f) {
+								emit_occ = true;
+								n_oo = make_float4(occ_origin.x, occ_origin.y, occ_origin.z, e_dist - kLightEps); // :203
+								n_od = make_float4(e_dir.x, e_dir.y, e_dir.z, ibits((int)cell));
+								n_oe = make_float4(e_rad.x, e_rad.y, e_rad.z, 0.0f);
+							}
+						}
+					}
+					if ((m.type & (POLARIS_BXDF_CONDUCTOR | POLARIS_BXDF_DIELECTRIC)) != 0) bxdf_weight = 1.0f; // :166-168
+					const f3 tp = bxdf_weight * bxdf_val * tint * pm_fabs(dot(sf.n, out_dir)); // :173
+					if (maxcomp(tp) > 0.0f && bxdf_pdf > 0.0f && !A.last_bounce) {
+						const f3 nt = thr * tp / bxdf_pdf; // :175
+						emit_ind = true;
+						n_ro = make_float4(ind_origin.x, ind_origin.y, ind_origin.z, kFltMax); // :209
+						n_rd = make_float4(out_dir.x, out_dir.y, out_dir.z, ibits((int)(path_index | (flags << 24))));
+						n_thr = make_float4(nt.x, nt.y, nt.z, 0.0f);
+					}
+				}
+			}
+		}
+	}
+
+	// ---- stable in-place compaction of the two output streams -----------------------------
+	const unsigned long long m_ind = __ballot(emit_ind), m_occ = __ballot(emit_occ);
+	const unsigned long long below = (1ull << lane) - 1ull;
+	const uint32_t r_ind = __popcll(m_ind & below), r_occ = __popcll(m_occ & below);
+	if (lane == 0) { wave_ind[wave] = __popcll(m_ind); wave_occ[wave] = __popcll(m_occ); }
+	// block statistics (one atomic per counter per workgroup)
+	const unsigned long long mh = __ballot(n_hit != 0), mm = __ballot(n_miss != 0), me = __ballot(n_emit != 0);
+	__syncthreads(); // also orders every lane's stream loads before any lane's in-place stores
+	if (lane == 0) {
+		if (mh) atomicAdd(&blk_stats[0], (uint32_t)__popcll(mh));
+		if (mm) atomicAdd(&blk_stats[1], (uint32_t)__popcll(mm));
+		if (me) atomicAdd(&blk_stats[2], (uint32_t)__popcll(me));
+	}
+	uint32_t b_ind = 0, b_occ = 0, tot_ind = 0, tot_occ = 0;
+#pragma unroll
+	for (int w = 0; w < 4; w++) {
+		if (w < (int)wave) { b_ind += wave_ind[w]; b_occ += wave_occ[w]; }
+		tot_ind += wave_ind[w]; tot_occ += wave_occ[w];
+	}
+	if (emit_ind) {
+		const size_t d = base + b_ind + r_ind;
+		st.ray_o[d] = n_ro; st.ray_d[d] = n_rd; st.thr[d] = n_thr;
+	}
+	if (emit_occ) {
+		const size_t d = base + b_occ + r_occ;
+		st.occ_o[d] = n_oo; st.occ_d[d] = n_od; st.occ_e[d] = n_oe;
+	}
+	__syncthreads();
+	if (tid == 0) {
+		st.cnt_ray[blockIdx.x] = tot_ind;
+		st.cnt_occ[blockIdx.x] = tot_occ;
+		if (blk_stats[0]) atomicAdd(&stats[ST_SHADED_HITS], (unsigned long long)blk_stats[0]);
+		if (blk_stats[1]) atomicAdd(&stats[ST_SHADED_MISSES], (unsigned long long)blk_stats[1]);
+		if (blk_stats[2]) atomicAdd(&stats[ST_EMITTER_HITS], (unsigned long long)blk_stats[2]);
+	}
+}
+
+// ------------------------------------------------------------------------------------------
+// Segmented exclusive scan of the per-workgroup live-ray counts, one workgroup per sample:
+// pfx[wg] = number of live rays in earlier workgroups of the same sample = position of this
+// workgroup's first ray in the reference's compacted buffer.  Also books the ray counters.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_scan(Streams st, uint32_t wgs_per_sample, uint32_t bounce, int count_next_rays,
+                                               unsigned long long *stats) {
+	__shared__ uint32_t part[1024];
+	__shared__ uint32_t part_occ[1024];
+	const uint32_t tid = threadIdx.x;
+	const uint32_t per = (wgs_per_sample + 1023) / 1024;
+	const uint32_t b0 = blockIdx.x * wgs_per_sample;
+	const uint32_t lo = tid * per, hi = min(lo + per, wgs_per_sample);
+	uint32_t sum = 0, socc = 0;
+	for (uint32_t i = lo; i < hi; i++) { sum += st.cnt_ray[b0 + i]; socc += st.cnt_occ[b0 + i]; }
+	part[tid] = sum;
+	part_occ[tid] = socc;
+	__syncthreads();
+	// Hillis-Steele inclusive scan over the 1024 partials
+	for (uint32_t off = 1; off < 1024; off <<= 1) {
+		uint32_t v = tid >= off ? part[tid - off] : 0, vo = tid >= off ? part_occ[tid - off] : 0;
+		__syncthreads();
+		part[tid] += v;
+		part_occ[tid] += vo;
+		__syncthreads();
+	}
+	uint32_t run = part[tid] - sum;
+	for (uint32_t i = lo; i < hi; i++) { st.pfx[b0 + i] = run; run += st.cnt_ray[b0 + i]; }
+	if (tid == 1023) {
+		if (count_next_rays && part[1023]) atomicAdd(&stats[ST_RAYS_BOUNCE + bounce + 1], (unsigned long long)part[1023]);
+		if (part_occ[1023]) atomicAdd(&stats[ST_OCCL_BOUNCE + bounce], (unsigned long long)part_occ[1023]);
+	}
+}
+
+// Batch epilogue: trace accumulator += per-path radiance, samples added in ascending order.
+__global__ __launch_bounds__(WG) void k_resolve(const float4 *lsum, float4 *acc, uint32_t K, uint32_t N, uint32_t Npad, uint32_t pixel0) {
+	const uint32_t idx = blockIdx.x * WG + threadIdx.x;
+	if (idx >= N) return;
+	float4 a = acc[pixel0 + idx];
+	for (uint32_t s = 0; s < K; s++) {
+		const float4 l = lsum[(size_t)s * Npad + idx];
+		a.x += l.x; a.y += l.y; a.z += l.z;
+	}
+	acc[pixel0 + idx] = a;
+}
+
+// aggregateAccumulator, kernels/accumulator.cl:13-19 (rows of one block)
+__global__ __launch_bounds__(WG) void k_aggregate(const float4 *src, float4 *dst, uint32_t n) {
+	const uint32_t i = blockIdx.x * WG + threadIdx.x;
+	if (i >= n) return;
+	float4 a = dst[i];
+	const float4 b = src[i];
+	a.x += b.x; a.y += b.y; a.z += b.z;
+	dst[i] = a;
+}
+
+// tonemapSimpleReinhard, kernels/hdr.cl:5-28
+__global__ __launch_bounds__(WG) void k_tonemap(const float4 *acc, uchar4 *fb, uint32_t n, float weight, float exposure) {
+	const uint32_t i = blockIdx.x * WG + threadIdx.x;
+	if (i >= n) return;
+	const float4 a = acc[i];
+	const float e = 1.0f / 2.2f;
+	float c[3] = {a.x * weight * exposure, a.y * weight * exposure, a.z * weight * exposure};
+	unsigned char o[3];
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+		float m = c[k] / (c[k] + 1.0f);
+		float v = pm_clamp(pm_pow(m, e), 0.0f, 1.0f) * 255.0f;
+		o[k] = (unsigned char)v; // truncation (hdr.cl:22-27)
+	}
+	fb[i] = make_uchar4(o[0], o[1], o[2], 255);
+}
+
+} // namespace pol

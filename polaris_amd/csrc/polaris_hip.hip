@@ -1,0 +1,650 @@
+// polaris_hip.hip -- host side of the C ABI declared in include/polaris_hip.h.
+//
+// Replaces the reference's Go host layer for the tracer path (tracer/opencl/tracer.go,
+// pipeline.go, resources.go, buffers.go, device/*.go) with one HIP stream per tracer handle
+// and NO host round trips inside a Trace: the reference ends every one of its ~21-26 launches
+// per sample in clFinish and resets two ray counters from the host before every shadeHits
+// (resources.go:230-238, device/kernel.go:124); here a whole batch of samples is enqueued
+// back to back, live-ray counts stay on the device, and the only synchronisation is the
+// one at the end of Trace (which the interface requires: Trace is synchronous).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "polaris_hip.h"
+
+using namespace pol;
+
+namespace {
+
+thread_local std::string g_thread_error;
+
+struct KernelTimer { double ms = 0.0; uint64_t launches = 0; };
+
+struct DevBuf {
+	void *p = nullptr;
+	size_t bytes = 0;
+};
+
+} // namespace
+
+struct polaris_hip_tracer {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	std::mutex mu;
+	std::string error;
+
+	// frame-sized state (buffers.go:127-174)
+	uint32_t W = 0, H = 0;
+	float4 *trace_acc = nullptr, *frame_acc = nullptr;
+	uchar4 *framebuffer = nullptr;
+
+	// scene (buffers.go:180-201), re-laid out by scene_layout.h
+	bool have_scene = false;
+	std::vector<DevBuf> scene_bufs;
+	BvhDev bvh{};
+	SceneDev scene{};
+	int max_stack = 0;
+
+	// camera (tracer.go:175-179)
+	bool have_camera = false;
+	CameraArgs cam{};
+
+	// wavefront batch state
+	size_t slots = 0; // capacity in slots
+	Streams st{};
+	std::vector<DevBuf> stream_bufs;
+	uint32_t *d_seeds = nullptr;
+	size_t seeds_cap = 0;
+	unsigned long long *d_stats = nullptr;
+	void *staging = nullptr; // peer-merge staging strip
+	size_t staging_bytes = 0;
+
+	// options
+	int64_t opt_samples_per_batch = 0; // 0 = auto
+	int opt_exact = 0;
+	int opt_packet_primary = 0;
+	int opt_time_kernels = 0;
+
+	// per-kernel timing (option time_kernels)
+	struct Pending { const char *name; hipEvent_t a, b; };
+	std::vector<Pending> pending;
+	std::vector<hipEvent_t> event_pool;
+	std::map<std::string, KernelTimer> timers;
+	hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+};
+
+namespace {
+
+int fail(polaris_hip_tracer *h, int code, const char *fmt, ...) {
+	char buf[1024];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	if (h) h->error = buf;
+	g_thread_error = buf;
+	return code;
+}
+
+#define HIP_TRY(h, expr)                                                                              \
+	do {                                                                                              \
+		hipError_t e_ = (expr);                                                                       \
+		if (e_ != hipSuccess) return fail(h, POLARIS_E_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+	} while (0)
+
+template <typename T>
+int dev_alloc(polaris_hip_tracer *h, std::vector<DevBuf> &pool, T **out, size_t count) {
+	void *p = nullptr;
+	size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+	HIP_TRY(h, hipMalloc(&p, bytes));
+	pool.push_back({p, bytes});
+	*out = (T *)p;
+	return POLARIS_OK;
+}
+
+template <typename T>
+int dev_upload(polaris_hip_tracer *h, std::vector<DevBuf> &pool, T **out, const void *src, size_t count) {
+	int rc = dev_alloc(h, pool, out, count);
+	if (rc) return rc;
+	if (count) HIP_TRY(h, hipMemcpyAsync(*out, src, count * sizeof(T), hipMemcpyHostToDevice, h->stream));
+	return POLARIS_OK;
+}
+
+void free_pool(std::vector<DevBuf> &pool) {
+	for (auto &b : pool)
+		if (b.p) (void)hipFree(b.p);
+	pool.clear();
+}
+
+// Bracket a launch with events when time_kernels is on.
+struct Timed {
+	polaris_hip_tracer *h;
+	const char *name;
+	hipEvent_t a = nullptr, b = nullptr;
+	Timed(polaris_hip_tracer *h_, const char *n) : h(h_), name(n) {
+		if (!h->opt_time_kernels) return;
+		auto get = [&]() {
+			hipEvent_t e;
+			if (!h->event_pool.empty()) { e = h->event_pool.back(); h->event_pool.pop_back(); }
+			else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+			return e;
+		};
+		a = get(); b = get();
+		if (a) (void)hipEventRecord(a, h->stream);
+	}
+	~Timed() {
+		if (!a || !b) return;
+		(void)hipEventRecord(b, h->stream);
+		h->pending.push_back({name, a, b});
+	}
+};
+
+void collect_timers(polaris_hip_tracer *h) { // stream must be idle
+	for (auto &p : h->pending) {
+		float ms = 0.0f;
+		if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+			auto &t = h->timers[p.name];
+			t.ms += ms;
+			t.launches++;
+		}
+		h->event_pool.push_back(p.a);
+		h->event_pool.push_back(p.b);
+	}
+	h->pending.clear();
+}
+
+int ensure_streams(polaris_hip_tracer *h, size_t slots, bool want_inst) {
+	if (slots <= h->slots && (!want_inst || h->st.hit_inst)) return POLARIS_OK;
+	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	free_pool(h->stream_bufs);
+	h->st = Streams{};
+	h->slots = 0;
+	const size_t wgs = slots / WG;
+	int rc = 0;
+	rc |= dev_alloc(h, h->stream_bufs, &h->st.ray_o, slots);
+	rc |= dev_alloc(h, h->stream_bufs, &h->st.ray_d, slots);
+	rc |= dev_alloc(h, h->stream_bufs, &h->st.thr, slots);
+	rc |= dev_alloc(h, h->stream_bufs, &h->st.hit, slots);
+	rc |= dev_alloc(h, h->stream_bufs, &h->st.occ_o, slots);
+	rc |= dev_alloc(h, h->stream_bufs, &h->st.occ_d, slots);
+	rc |= dev_alloc(h, h->stream_bufs, &h->st.occ_e, slots);
+	rc |= dev_alloc(h, h->stream_bufs, &h->st.lsum, slots);
+	rc |= dev_alloc(h, h->stream_bufs, &h->st.cnt_ray, wgs);
+	rc |= dev_alloc(h, h->stream_bufs, &h->st.cnt_occ, wgs);
+	rc |= dev_alloc(h, h->stream_bufs, &h->st.pfx, wgs);
+	if (want_inst) rc |= dev_alloc(h, h->stream_bufs, &h->st.hit_inst, slots);
+	if (rc) { free_pool(h->stream_bufs); h->st = Streams{}; return rc; }
+	h->slots = slots;
+	return POLARIS_OK;
+}
+
+int check_request(polaris_hip_tracer *h, const PolarisBlockRequest *r) {
+	if (!r) return fail(h, POLARIS_E_BAD_ARGUMENT, "block request is null");
+	if (h->W == 0 || h->H == 0) return fail(h, POLARIS_E_BAD_ARGUMENT, "frame dimensions not set (UpdateState FrameDimensions)");
+	if (r->frame_w != h->W || r->frame_h != h->H)
+		return fail(h, POLARIS_E_BAD_ARGUMENT, "request frame %ux%u does not match the tracer's %ux%u", r->frame_w, r->frame_h, h->W, h->H);
+	if (r->block_h == 0 || (uint64_t)r->block_y + r->block_h > h->H)
+		return fail(h, POLARIS_E_BAD_ARGUMENT, "block rows [%u,%u) outside the frame", r->block_y, r->block_y + r->block_h);
+	if (r->block_x != 0 || (r->block_w != 0 && r->block_w != h->W))
+		return fail(h, POLARIS_E_BAD_ARGUMENT, "only full-width row blocks are supported (BlockW = FrameW, renderer/default.go:110)");
+	return POLARIS_OK;
+}
+
+inline uint32_t grid_for(size_t n) { return (uint32_t)((n + WG - 1) / WG); }
+
+// One wavefront batch: K samples starting at sample s0.
+void launch_batch(polaris_hip_tracer *h, const PolarisBlockRequest *r, uint32_t s0, uint32_t K, uint32_t N, uint32_t Npad,
+                  bool exact) {
+	const uint32_t B = r->num_bounces, stride = 1 + B;
+	const uint32_t wgs_per_sample = Npad / WG, wgs = K * wgs_per_sample;
+	hipStream_t q = h->stream;
+	{
+		Timed t(h, "generate");
+		hipLaunchKernelGGL(k_generate, dim3(wgs), dim3(WG), 0, q, h->st, h->cam, h->d_seeds, stride, s0, N, Npad, h->W, r->block_y,
+		                   exact ? 0 : 1);
+	}
+	ShadeArgs A{};
+	A.seeds = h->d_seeds; A.seed_stride = stride; A.first_sample = s0;
+	A.N = N; A.Npad = Npad; A.W = h->W; A.blockY = r->block_y;
+	A.min_rr = r->min_bounces_for_rr;
+	A.exact = exact ? 1 : 0;
+	A.acc = exact ? h->trace_acc : h->st.lsum;
+	for (uint32_t b = 0; b < B; b++) {
+		{
+			Timed t(h, "intersect");
+			hipLaunchKernelGGL(k_intersect, dim3(wgs), dim3(WG), 0, q, h->st, h->bvh);
+		}
+		A.bounce = b;
+		A.last_bounce = (b + 1 == B) ? 1 : 0;
+		{
+			Timed t(h, "shade");
+			hipLaunchKernelGGL(k_shade, dim3(wgs), dim3(WG), 0, q, h->st, h->scene, A, h->d_stats);
+		}
+		{
+			Timed t(h, "scan");
+			hipLaunchKernelGGL(k_scan, dim3(K), dim3(1024), 0, q, h->st, wgs_per_sample, b, A.last_bounce ? 0 : 1, h->d_stats);
+		}
+		{
+			Timed t(h, "occlusion");
+			hipLaunchKernelGGL(k_occlusion, dim3(wgs), dim3(WG), 0, q, h->st, h->bvh, A.acc, h->d_stats);
+		}
+	}
+	if (!exact) {
+		Timed t(h, "resolve");
+		hipLaunchKernelGGL(k_resolve, dim3(grid_for(N)), dim3(WG), 0, q, h->st.lsum, h->trace_acc, K, N, Npad, r->block_y * h->W);
+	}
+}
+
+} // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+int polaris_hip_abi_version(void) { return POLARIS_HIP_ABI_VERSION; }
+
+int polaris_hip_device_count(void) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+int polaris_hip_device_info(int index, char name[256], uint32_t *compute_units, uint32_t *clock_mhz, uint64_t *global_mem_bytes) {
+	int n = polaris_hip_device_count();
+	if (index < 0 || index >= n) return fail(nullptr, POLARIS_E_NO_DEVICE, "device %d out of range (%d devices)", index, n);
+	hipDeviceProp_t p;
+	HIP_TRY(nullptr, hipGetDeviceProperties(&p, index));
+	if (name) { strncpy(name, p.name, 255); name[255] = 0; }
+	if (compute_units) *compute_units = (uint32_t)p.multiProcessorCount;
+	if (clock_mhz) *clock_mhz = (uint32_t)(p.clockRate / 1000);
+	if (global_mem_bytes) *global_mem_bytes = (uint64_t)p.totalGlobalMem;
+	return POLARIS_OK;
+}
+
+int polaris_hip_create(int device_index, polaris_hip_tracer **out) {
+	if (!out) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "out handle pointer is null");
+	*out = nullptr;
+	int n = polaris_hip_device_count();
+	if (device_index < 0 || device_index >= n)
+		return fail(nullptr, POLARIS_E_NO_DEVICE, "device %d out of range (%d HIP devices visible)", device_index, n);
+	polaris_hip_tracer *h = new polaris_hip_tracer();
+	h->device = device_index;
+	hipError_t e = hipSetDevice(device_index);
+	if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipMalloc((void **)&h->d_stats, ST_COUNT * sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipEventCreate(&h->ev_start);
+	if (e == hipSuccess) e = hipEventCreate(&h->ev_stop);
+	if (e != hipSuccess) {
+		fail(nullptr, POLARIS_E_DEVICE, "creating tracer on device %d: %s", device_index, hipGetErrorString(e));
+		delete h;
+		return POLARIS_E_DEVICE;
+	}
+	*out = h;
+	return POLARIS_OK;
+}
+
+void polaris_hip_destroy(polaris_hip_tracer *h) {
+	if (!h) return;
+	{
+		std::lock_guard<std::mutex> lk(h->mu);
+		(void)hipSetDevice(h->device);
+		if (h->stream) (void)hipStreamSynchronize(h->stream);
+		collect_timers(h);
+		for (auto e : h->event_pool) (void)hipEventDestroy(e);
+		free_pool(h->stream_bufs);
+		free_pool(h->scene_bufs);
+		if (h->trace_acc) (void)hipFree(h->trace_acc);
+		if (h->frame_acc) (void)hipFree(h->frame_acc);
+		if (h->framebuffer) (void)hipFree(h->framebuffer);
+		if (h->d_seeds) (void)hipFree(h->d_seeds);
+		if (h->d_stats) (void)hipFree(h->d_stats);
+		if (h->staging) (void)hipFree(h->staging);
+		if (h->ev_start) (void)hipEventDestroy(h->ev_start);
+		if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
+		if (h->stream) (void)hipStreamDestroy(h->stream);
+	}
+	delete h;
+}
+
+const char *polaris_hip_last_error(polaris_hip_tracer *h) { return h ? h->error.c_str() : g_thread_error.c_str(); }
+
+int polaris_hip_resize(polaris_hip_tracer *h, uint32_t frame_w, uint32_t frame_h) {
+	if (!h) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "handle is null");
+	std::lock_guard<std::mutex> lk(h->mu);
+	if (frame_w == 0 || frame_h == 0 || (uint64_t)frame_w * frame_h > (1ull << 28))
+		return fail(h, POLARIS_E_BAD_ARGUMENT, "bad frame dimensions %ux%u", frame_w, frame_h);
+	HIP_TRY(h, hipSetDevice(h->device));
+	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	if (h->trace_acc) (void)hipFree(h->trace_acc);
+	if (h->frame_acc) (void)hipFree(h->frame_acc);
+	if (h->framebuffer) (void)hipFree(h->framebuffer);
+	h->trace_acc = h->frame_acc = nullptr;
+	h->framebuffer = nullptr;
+	h->W = h->H = 0;
+	const size_t F = (size_t)frame_w * frame_h;
+	HIP_TRY(h, hipMalloc((void **)&h->trace_acc, F * sizeof(float4)));
+	HIP_TRY(h, hipMalloc((void **)&h->frame_acc, F * sizeof(float4)));
+	HIP_TRY(h, hipMalloc((void **)&h->framebuffer, F * sizeof(uchar4)));
+	HIP_TRY(h, hipMemsetAsync(h->trace_acc, 0, F * sizeof(float4), h->stream));
+	HIP_TRY(h, hipMemsetAsync(h->frame_acc, 0, F * sizeof(float4), h->stream));
+	HIP_TRY(h, hipMemsetAsync(h->framebuffer, 0, F * sizeof(uchar4), h->stream));
+	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	h->W = frame_w;
+	h->H = frame_h;
+	return POLARIS_OK;
+}
+
+int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) {
+	if (!h) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "handle is null");
+	std::lock_guard<std::mutex> lk(h->mu);
+	if (!sc) return fail(h, POLARIS_E_BAD_ARGUMENT, "scene view is null");
+	SceneLayout L;
+	const std::string err = build_layout(*sc, L);
+	if (!err.empty()) return fail(h, POLARIS_E_BAD_SCENE, "%s", err.c_str());
+	HIP_TRY(h, hipSetDevice(h->device));
+	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	free_pool(h->scene_bufs);
+	h->have_scene = false;
+	int rc = 0;
+	PairNode *pairs; int2 *leaves; TriRec *tris; InstRec *insts;
+	rc |= dev_upload(h, h->scene_bufs, &pairs, L.pairs.data(), L.pairs.size());
+	rc |= dev_upload(h, h->scene_bufs, &leaves, L.leaves.data(), L.leaves.size());
+	rc |= dev_upload(h, h->scene_bufs, &tris, L.tris.data(), L.tris.size());
+	rc |= dev_upload(h, h->scene_bufs, &insts, L.insts.data(), L.insts.size());
+	float4 *vertices, *normals; float2 *uvs; uint32_t *mat_index;
+	PolarisMaterialNode *nodes; PolarisEmissive *emissives; PolarisTextureMetadata *tex_meta; uint8_t *tex_data;
+	const size_t nv = (size_t)sc->num_triangles * 3;
+	rc |= dev_upload(h, h->scene_bufs, &vertices, sc->vertices, nv);
+	rc |= dev_upload(h, h->scene_bufs, &normals, sc->normals, nv);
+	rc |= dev_upload(h, h->scene_bufs, &uvs, sc->uvs, nv);
+	rc |= dev_upload(h, h->scene_bufs, &mat_index, sc->material_index, sc->num_triangles);
+	rc |= dev_upload(h, h->scene_bufs, &nodes, sc->material_nodes, sc->num_material_nodes);
+	rc |= dev_upload(h, h->scene_bufs, &emissives, sc->emissives, sc->num_emissives);
+	rc |= dev_upload(h, h->scene_bufs, &tex_meta, sc->texture_meta, sc->num_textures);
+	rc |= dev_upload(h, h->scene_bufs, &tex_data, sc->texture_data, sc->texture_data_bytes);
+	if (rc) { free_pool(h->scene_bufs); return rc; }
+	HIP_TRY(h, hipStreamSynchronize(h->stream)); // host vectors in L die at return
+	h->bvh = BvhDev{pairs, leaves, tris, insts, L.root_ref};
+	h->scene = SceneDev{vertices, normals, uvs, mat_index, nodes, emissives, tex_meta, tex_data, sc->num_emissives,
+	                    sc->scene_diffuse_mat_index};
+	h->max_stack = L.max_stack;
+	h->have_scene = true;
+	return POLARIS_OK;
+}
+
+int polaris_hip_set_camera(polaris_hip_tracer *h, const float eye[3], const float fr[16]) {
+	if (!h) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "handle is null");
+	std::lock_guard<std::mutex> lk(h->mu);
+	if (!eye || !fr) return fail(h, POLARIS_E_BAD_ARGUMENT, "camera pointers are null");
+	h->cam.tl = make_float4(fr[0], fr[1], fr[2], fr[3]);
+	h->cam.tr = make_float4(fr[4], fr[5], fr[6], fr[7]);
+	h->cam.bl = make_float4(fr[8], fr[9], fr[10], fr[11]);
+	h->cam.br = make_float4(fr[12], fr[13], fr[14], fr[15]);
+	h->cam.eye = make_float3(eye[0], eye[1], eye[2]);
+	h->have_camera = true;
+	return POLARIS_OK;
+}
+
+int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value) {
+	if (!h) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "handle is null");
+	std::lock_guard<std::mutex> lk(h->mu);
+	if (!key) return fail(h, POLARIS_E_BAD_ARGUMENT, "option key is null");
+	const std::string k(key);
+	if (k == "samples_per_batch") h->opt_samples_per_batch = value < 0 ? 0 : value;
+	else if (k == "exact_accumulate") h->opt_exact = value != 0;
+	else if (k == "packet_primary") h->opt_packet_primary = value != 0;
+	else if (k == "time_kernels") h->opt_time_kernels = value != 0;
+	else return fail(h, POLARIS_E_BAD_ARGUMENT, "unknown option '%s'", key);
+	return POLARIS_OK;
+}
+
+int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const uint32_t *seeds, size_t n_seeds,
+                      PolarisTraceStats *stats) {
+	if (!h) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "handle is null");
+	std::lock_guard<std::mutex> lk(h->mu);
+	if (!h->have_scene) return fail(h, POLARIS_E_NO_SCENE_DATA, "no scene data uploaded"); // ErrNoSceneData, tracer.go:203-205
+	if (int rc = check_request(h, r)) return rc;
+	if (!h->have_camera) return fail(h, POLARIS_E_BAD_ARGUMENT, "camera not set (UpdateState CameraData)");
+	const uint32_t B = r->num_bounces, spp = r->samples_per_pixel;
+	if (B > POLARIS_MAX_BOUNCES) return fail(h, POLARIS_E_BAD_ARGUMENT, "num_bounces %u exceeds %d", B, POLARIS_MAX_BOUNCES);
+	const size_t need_seeds = (size_t)spp * (1 + B);
+	if (need_seeds && (!seeds || n_seeds < need_seeds))
+		return fail(h, POLARIS_E_BAD_ARGUMENT, "seed list has %zu entries, need samples*(1+bounces) = %zu", n_seeds, need_seeds);
+	const uint64_t N64 = (uint64_t)h->W * r->block_h;
+	if (N64 > (1u << 24)) // the reference stores the path index as a float in ray.dir.w (util/ray.cl:9-12)
+		return fail(h, POLARIS_E_BAD_ARGUMENT, "block has %llu pixels; the path index is exact only below 2^24", (unsigned long long)N64);
+	const uint32_t N = (uint32_t)N64, Npad = (N + WG - 1) / WG * WG;
+
+	HIP_TRY(h, hipSetDevice(h->device));
+	const bool exact = h->opt_exact != 0;
+	uint32_t K = 1;
+	if (!exact) {
+		if (h->opt_samples_per_batch > 0) K = (uint32_t)std::min<int64_t>(h->opt_samples_per_batch, 4096);
+		else K = std::max<uint32_t>(1u, (uint32_t)((4u << 20) / Npad)); // ~4 M paths in flight
+		K = std::max<uint32_t>(1u, std::min(K, std::max(spp, 1u)));
+	}
+	if (int rc = ensure_streams(h, (size_t)K * Npad, false)) return rc;
+	if (need_seeds > h->seeds_cap) {
+		if (h->d_seeds) (void)hipFree(h->d_seeds);
+		h->d_seeds = nullptr;
+		h->seeds_cap = 0;
+		HIP_TRY(h, hipMalloc((void **)&h->d_seeds, need_seeds * sizeof(uint32_t)));
+		h->seeds_cap = need_seeds;
+	}
+	h->cam.texel = make_float2(1.0f / (float)h->W, 1.0f / (float)h->H); // resources.go:130-133
+	const size_t F = (size_t)h->W * h->H;
+	hipStream_t q = h->stream;
+	HIP_TRY(h, hipEventRecord(h->ev_start, q));
+	if (r->accumulated_samples == 0) // pipeline Reset stage (tracer.go:208-213)
+		HIP_TRY(h, hipMemsetAsync(h->frame_acc, 0, F * sizeof(float4), q));
+	HIP_TRY(h, hipMemsetAsync(h->trace_acc, 0, F * sizeof(float4), q)); // ClearTraceAccumulator (tracer.go:215)
+	HIP_TRY(h, hipMemsetAsync(h->d_stats, 0, ST_COUNT * sizeof(unsigned long long), q));
+	if (need_seeds) HIP_TRY(h, hipMemcpyAsync(h->d_seeds, seeds, need_seeds * sizeof(uint32_t), hipMemcpyHostToDevice, q));
+	for (uint32_t s0 = 0; s0 < spp; s0 += K) launch_batch(h, r, s0, std::min(K, spp - s0), N, Npad, exact);
+	HIP_TRY(h, hipGetLastError());
+	unsigned long long hs[ST_COUNT];
+	HIP_TRY(h, hipMemcpyAsync(hs, h->d_stats, sizeof hs, hipMemcpyDeviceToHost, q));
+	HIP_TRY(h, hipEventRecord(h->ev_stop, q));
+	HIP_TRY(h, hipStreamSynchronize(q));
+	collect_timers(h);
+	if (stats) {
+		memset(stats, 0, sizeof *stats);
+		stats->primary_rays = (uint64_t)N * spp;
+		stats->shaded_hits = hs[ST_SHADED_HITS];
+		stats->shaded_misses = hs[ST_SHADED_MISSES];
+		stats->emitter_hits = hs[ST_EMITTER_HITS];
+		stats->unoccluded = hs[ST_UNOCCLUDED];
+		if (B > 0) stats->rays_per_bounce[0] = (uint64_t)N * spp;
+		for (uint32_t b = 1; b < B; b++) {
+			stats->rays_per_bounce[b] = hs[ST_RAYS_BOUNCE + b];
+			stats->indirect_rays += hs[ST_RAYS_BOUNCE + b];
+		}
+		for (uint32_t b = 0; b < B; b++) {
+			stats->occl_per_bounce[b] = hs[ST_OCCL_BOUNCE + b];
+			stats->occlusion_rays += hs[ST_OCCL_BOUNCE + b];
+		}
+		float ms = 0.0f;
+		(void)hipEventElapsedTime(&ms, h->ev_start, h->ev_stop);
+		stats->device_ms = ms;
+	}
+	return POLARIS_OK;
+}
+
+int polaris_hip_merge(polaris_hip_tracer *dst, polaris_hip_tracer *src, const PolarisBlockRequest *r) {
+	if (!dst || !src) return fail(dst, POLARIS_E_BAD_ARGUMENT, "merge: null tracer handle");
+	std::lock_guard<std::mutex> lk(dst->mu);
+	if (int rc = check_request(dst, r)) return rc;
+	if (src->W != dst->W || src->H != dst->H || !src->trace_acc)
+		return fail(dst, POLARIS_E_BAD_ARGUMENT, "merge: source tracer has different frame dimensions");
+	HIP_TRY(dst, hipSetDevice(dst->device));
+	const size_t off = (size_t)r->block_y * dst->W, n = (size_t)r->block_h * dst->W;
+	const float4 *rows = src->trace_acc + off;
+	if (src->device != dst->device) {
+		int can = 0;
+		HIP_TRY(dst, hipDeviceCanAccessPeer(&can, dst->device, src->device));
+		bool direct = false;
+		if (can) {
+			hipError_t e = hipDeviceEnablePeerAccess(src->device, 0);
+			if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) direct = true;
+			(void)hipGetLastError();
+		}
+		if (!direct) { // staged copy over xGMI / PCIe, then add
+			if (dst->staging_bytes < n * sizeof(float4)) {
+				if (dst->staging) (void)hipFree(dst->staging);
+				dst->staging = nullptr;
+				dst->staging_bytes = 0;
+				HIP_TRY(dst, hipMalloc(&dst->staging, n * sizeof(float4)));
+				dst->staging_bytes = n * sizeof(float4);
+			}
+			HIP_TRY(dst, hipMemcpyPeerAsync(dst->staging, dst->device, rows, src->device, n * sizeof(float4), dst->stream));
+			rows = (const float4 *)dst->staging;
+		}
+	}
+	{
+		Timed t(dst, "aggregate");
+		hipLaunchKernelGGL(k_aggregate, dim3(grid_for(n)), dim3(WG), 0, dst->stream, rows, dst->frame_acc + off, (uint32_t)n);
+	}
+	HIP_TRY(dst, hipGetLastError());
+	return POLARIS_OK; // asynchronous like Exec1DNoWait (resources.go:119); completed by sync_framebuffer
+}
+
+int polaris_hip_export_block(polaris_hip_tracer *h, const PolarisBlockRequest *r, void *device_dst) {
+	if (!h) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "handle is null");
+	std::lock_guard<std::mutex> lk(h->mu);
+	if (int rc = check_request(h, r)) return rc;
+	if (!device_dst) return fail(h, POLARIS_E_BAD_ARGUMENT, "export: destination is null");
+	HIP_TRY(h, hipSetDevice(h->device));
+	const size_t off = (size_t)r->block_y * h->W, n = (size_t)r->block_h * h->W;
+	HIP_TRY(h, hipMemcpyAsync(device_dst, h->trace_acc + off, n * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	return POLARIS_OK;
+}
+
+int polaris_hip_merge_device(polaris_hip_tracer *dst, const void *device_rows, const PolarisBlockRequest *r) {
+	if (!dst) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "handle is null");
+	std::lock_guard<std::mutex> lk(dst->mu);
+	if (int rc = check_request(dst, r)) return rc;
+	if (!device_rows) return fail(dst, POLARIS_E_BAD_ARGUMENT, "merge_device: source is null");
+	HIP_TRY(dst, hipSetDevice(dst->device));
+	const size_t off = (size_t)r->block_y * dst->W, n = (size_t)r->block_h * dst->W;
+	hipLaunchKernelGGL(k_aggregate, dim3(grid_for(n)), dim3(WG), 0, dst->stream, (const float4 *)device_rows, dst->frame_acc + off,
+	                   (uint32_t)n);
+	HIP_TRY(dst, hipGetLastError());
+	HIP_TRY(dst, hipStreamSynchronize(dst->stream)); // the caller owns device_rows: do not outlive it
+	return POLARIS_OK;
+}
+
+int polaris_hip_sync_framebuffer(polaris_hip_tracer *h, const PolarisBlockRequest *r) {
+	if (!h) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "handle is null");
+	std::lock_guard<std::mutex> lk(h->mu);
+	if (!h->have_scene) return fail(h, POLARIS_E_NO_SCENE_DATA, "no scene data uploaded"); // tracer.go:254-256
+	if (int rc = check_request(h, r)) return rc;
+	HIP_TRY(h, hipSetDevice(h->device));
+	const size_t off = (size_t)r->block_y * h->W, n = (size_t)r->block_h * h->W;
+	const float weight = (float)(1.0 / (float)(r->accumulated_samples + r->samples_per_pixel)); // resources.go:347
+	{
+		Timed t(h, "tonemap");
+		hipLaunchKernelGGL(k_tonemap, dim3(grid_for(n)), dim3(WG), 0, h->stream, h->frame_acc + off, h->framebuffer + off, (uint32_t)n,
+		                   weight, r->exposure);
+	}
+	HIP_TRY(h, hipGetLastError());
+	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	collect_timers(h);
+	return POLARIS_OK;
+}
+
+int polaris_hip_read_framebuffer(polaris_hip_tracer *h, uint8_t *rgba, size_t n_bytes) {
+	if (!h) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "handle is null");
+	std::lock_guard<std::mutex> lk(h->mu);
+	const size_t need = (size_t)h->W * h->H * 4;
+	if (!rgba || n_bytes < need || need == 0) return fail(h, POLARIS_E_BAD_ARGUMENT, "read_framebuffer: need %zu bytes", need);
+	HIP_TRY(h, hipSetDevice(h->device));
+	HIP_TRY(h, hipMemcpyAsync(rgba, h->framebuffer, need, hipMemcpyDeviceToHost, h->stream));
+	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	return POLARIS_OK;
+}
+
+int polaris_hip_read_accumulator(polaris_hip_tracer *h, int which, float *out, size_t n_floats) {
+	if (!h) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "handle is null");
+	std::lock_guard<std::mutex> lk(h->mu);
+	const size_t need = (size_t)h->W * h->H * 4;
+	if (!out || n_floats < need || need == 0 || which < 0 || which > 1)
+		return fail(h, POLARIS_E_BAD_ARGUMENT, "read_accumulator: need %zu floats, which in {0,1}", need);
+	HIP_TRY(h, hipSetDevice(h->device));
+	HIP_TRY(h, hipMemcpyAsync(out, which == 0 ? h->trace_acc : h->frame_acc, need * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	return POLARIS_OK;
+}
+
+int polaris_hip_tap_primary(polaris_hip_tracer *h, const PolarisBlockRequest *r, uint32_t seed, float *rays, int32_t *hit,
+                            float *wuvt, int32_t *tri) {
+	if (!h) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "handle is null");
+	std::lock_guard<std::mutex> lk(h->mu);
+	if (!h->have_scene) return fail(h, POLARIS_E_NO_SCENE_DATA, "no scene data uploaded");
+	if (int rc = check_request(h, r)) return rc;
+	if (!h->have_camera) return fail(h, POLARIS_E_BAD_ARGUMENT, "camera not set");
+	const uint32_t N = h->W * r->block_h, Npad = (N + WG - 1) / WG * WG;
+	HIP_TRY(h, hipSetDevice(h->device));
+	if (int rc = ensure_streams(h, std::max<size_t>(h->slots, Npad), true)) return rc;
+	if (h->seeds_cap < 1) {
+		HIP_TRY(h, hipMalloc((void **)&h->d_seeds, 64 * sizeof(uint32_t)));
+		h->seeds_cap = 64;
+	}
+	h->cam.texel = make_float2(1.0f / (float)h->W, 1.0f / (float)h->H);
+	hipStream_t q = h->stream;
+	HIP_TRY(h, hipMemcpyAsync(h->d_seeds, &seed, sizeof seed, hipMemcpyHostToDevice, q));
+	hipLaunchKernelGGL(k_generate, dim3(Npad / WG), dim3(WG), 0, q, h->st, h->cam, h->d_seeds, 1u, 0u, N, Npad, h->W, r->block_y, 1);
+	hipLaunchKernelGGL(k_intersect, dim3(Npad / WG), dim3(WG), 0, q, h->st, h->bvh);
+	HIP_TRY(h, hipGetLastError());
+	std::vector<float4> ro(N), rd(N), ht(N);
+	std::vector<int> inst(N);
+	HIP_TRY(h, hipMemcpyAsync(ro.data(), h->st.ray_o, N * sizeof(float4), hipMemcpyDeviceToHost, q));
+	HIP_TRY(h, hipMemcpyAsync(rd.data(), h->st.ray_d, N * sizeof(float4), hipMemcpyDeviceToHost, q));
+	HIP_TRY(h, hipMemcpyAsync(ht.data(), h->st.hit, N * sizeof(float4), hipMemcpyDeviceToHost, q));
+	HIP_TRY(h, hipMemcpyAsync(inst.data(), h->st.hit_inst, N * sizeof(int), hipMemcpyDeviceToHost, q));
+	HIP_TRY(h, hipStreamSynchronize(q));
+	for (uint32_t i = 0; i < N; i++) {
+		int t;
+		memcpy(&t, &ht[i].w, 4);
+		if (rays) {
+			int pw;
+			memcpy(&pw, &rd[i].w, 4);
+			float *o = rays + 8 * (size_t)i;
+			o[0] = ro[i].x; o[1] = ro[i].y; o[2] = ro[i].z; o[3] = ro[i].w;
+			o[4] = rd[i].x; o[5] = rd[i].y; o[6] = rd[i].z; o[7] = (float)(pw & 0xFFFFFF); // util/ray.cl:11
+		}
+		if (hit) hit[i] = t >= 0 ? 1 : 0;
+		if (t >= 0) {
+			if (wuvt) {
+				float *o = wuvt + 4 * (size_t)i;
+				o[0] = 1.0f - (ht[i].x + ht[i].y); o[1] = ht[i].x; o[2] = ht[i].y; o[3] = ht[i].z; // intersect.cl:283-288
+			}
+			if (tri) { tri[2 * (size_t)i] = inst[i]; tri[2 * (size_t)i + 1] = t; }
+		}
+	}
+	return POLARIS_OK;
+}
+
+int polaris_hip_kernel_ms(polaris_hip_tracer *h, const char *kernel, double *ms, uint64_t *launches) {
+	if (!h) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "handle is null");
+	std::lock_guard<std::mutex> lk(h->mu);
+	if (!kernel) return fail(h, POLARIS_E_BAD_ARGUMENT, "kernel name is null");
+	auto it = h->timers.find(kernel);
+	KernelTimer t = it == h->timers.end() ? KernelTimer{} : it->second;
+	if (it != h->timers.end()) h->timers.erase(it);
+	if (ms) *ms = t.ms;
+	if (launches) *launches = t.launches;
+	return POLARIS_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,207 @@
+"""Host-side mirror of the reference's tracer.Tracer interface over the C ABI (ctypes).
+
+Same method names, argument meaning and error behaviour as tracer/tracer.go:80-111 and its
+OpenCL implementation tracer/opencl/tracer.go, so tests and bench.py drive the HIP backend the way
+renderer/default.go drives a tracer.  This module is plumbing only: every method is one call into
+libpolaris_hip.so (include/polaris_hip.h); there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+import time
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import ctypes_api as T
+
+
+class Flag(enum.IntFlag):          # tracer/tracer.go:49-61
+    Local = 1
+    Remote = 2
+    CpuDevice = 4
+
+
+class UpdateMode(enum.IntEnum):    # tracer/tracer.go:63-69
+    Synchronous = 0
+    Asynchronous = 1
+
+
+class ChangeType(enum.IntEnum):    # tracer/tracer.go:71-78
+    FrameDimensions = 0
+    SceneData = 1
+    CameraData = 2
+
+
+@dataclass
+class Stats:                       # tracer/tracer.go:37-47 (durations in seconds)
+    BlockW: int = 0
+    BlockH: int = 0
+    UpdateTime: float = 0.0
+    RenderTime: float = 0.0
+
+
+class TracerError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"polaris_hip error {code}: {msg}")
+        self.code = code
+
+
+class ErrNoSceneData(TracerError):  # tracer/opencl/errors.go
+    pass
+
+
+E_NO_SCENE_DATA = 1
+
+
+class HipTracer:
+    """tracer.Tracer implemented on one MI355X through the C ABI."""
+
+    def __init__(self, id: str, device_index: int = 0, lib_path: str | None = None):
+        self._lib = T.load_library(lib_path)
+        self._id = id
+        self._device = device_index
+        self._h = C.c_void_p()
+        self._stats = Stats()
+        self._changes: dict[ChangeType, object] = {}
+        self._name = ""
+        self._speed = 0
+        self.last_trace_stats: T.TraceStats | None = None
+        self._keepalive = None
+
+    # ---- tracer.Tracer ---------------------------------------------------------------------
+    def Id(self) -> str:
+        return self._id
+
+    def Flags(self) -> Flag:
+        return Flag.Local
+
+    def Speed(self) -> int:
+        """compute units * MHz / 1000 (tracer/opencl/device/device.go:219)."""
+        return self._speed
+
+    def Init(self) -> None:
+        name = C.create_string_buffer(256)
+        cus, mhz, mem = C.c_uint32(), C.c_uint32(), C.c_uint64()
+        self._check(self._lib.polaris_hip_device_info(self._device, name, C.byref(cus), C.byref(mhz), C.byref(mem)), None)
+        self._name = name.value.decode()
+        self._speed = int(cus.value * mhz.value // 1000)
+        self._check(self._lib.polaris_hip_create(self._device, C.byref(self._h)), None)
+
+    def Close(self) -> None:
+        if self._h:
+            self._lib.polaris_hip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def Stats(self) -> Stats:
+        return self._stats
+
+    def UpdateState(self, mode: UpdateMode, change: ChangeType, data) -> float:
+        """Queue a state change; Synchronous commits at once, Asynchronous at the next Trace
+        (tracer/opencl/tracer.go:150-192)."""
+        self._changes[ChangeType(change)] = data
+        if mode == UpdateMode.Synchronous:
+            return self._commit()
+        return 0.0
+
+    def Trace(self, req: T.BlockRequest, seeds: np.ndarray | None = None) -> float:
+        """tracer/opencl/tracer.go:194-247.  `seeds` stands in for the Go math/rand draws (one
+        per sample + one per bounce); if omitted they are drawn from numpy's global RNG the way
+        the reference draws from math/rand."""
+        t0 = time.perf_counter()
+        self._commit()
+        n = req.samples_per_pixel * (1 + req.num_bounces)
+        if seeds is None:
+            seeds = np.random.randint(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32)
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+        st = T.TraceStats()
+        rc = self._lib.polaris_hip_trace(self._h, C.byref(req), seeds.ctypes.data_as(C.POINTER(C.c_uint32)), seeds.size, C.byref(st))
+        self._check(rc, self._h)
+        self.last_trace_stats = st
+        req.accumulated_samples += req.samples_per_pixel  # tracer.go:240 (on the caller's copy)
+        self._stats.BlockW, self._stats.BlockH = req.block_w, req.block_h
+        self._stats.RenderTime = time.perf_counter() - t0
+        return self._stats.RenderTime
+
+    def MergeOutput(self, other: "HipTracer", req: T.BlockRequest) -> float:
+        t0 = time.perf_counter()
+        if not isinstance(other, HipTracer):  # tracer.go:280-283
+            raise TracerError(6, "merge failed: unsupported tracer instance")
+        self._check(self._lib.polaris_hip_merge(self._h, other._h, C.byref(req)), self._h)
+        return time.perf_counter() - t0
+
+    def SyncFramebuffer(self, req: T.BlockRequest) -> float:
+        t0 = time.perf_counter()
+        self._check(self._lib.polaris_hip_sync_framebuffer(self._h, C.byref(req)), self._h)
+        return time.perf_counter() - t0
+
+    # ---- extras used by tests / bench --------------------------------------------------------
+    def set_option(self, key: str, value: int) -> None:
+        self._check(self._lib.polaris_hip_set_option(self._h, key.encode(), int(value)), self._h)
+
+    def read_accumulator(self, which: int = 0) -> np.ndarray:
+        out = np.zeros((self._H, self._W, 4), dtype=np.float32)
+        self._check(self._lib.polaris_hip_read_accumulator(self._h, which, out.ctypes.data, out.size), self._h)
+        return out
+
+    def read_framebuffer(self) -> np.ndarray:
+        out = np.zeros((self._H, self._W, 4), dtype=np.uint8)
+        self._check(self._lib.polaris_hip_read_framebuffer(self._h, out.ctypes.data, out.size), self._h)
+        return out
+
+    def tap_primary(self, req: T.BlockRequest, seed: int) -> dict:
+        n = req.frame_w * req.block_h
+        taps = {"primary_rays": np.zeros((n, 8), np.float32), "primary_hit": np.zeros(n, np.int32),
+                "primary_wuvt": np.zeros((n, 4), np.float32), "primary_tri": np.full((n, 2), -1, np.int32)}
+        self._check(self._lib.polaris_hip_tap_primary(self._h, C.byref(req), seed, taps["primary_rays"].ctypes.data,
+                                                      taps["primary_hit"].ctypes.data, taps["primary_wuvt"].ctypes.data,
+                                                      taps["primary_tri"].ctypes.data), self._h)
+        return taps
+
+    def kernel_ms(self, name: str) -> tuple[float, int]:
+        ms, n = C.c_double(), C.c_uint64()
+        self._check(self._lib.polaris_hip_kernel_ms(self._h, name.encode(), C.byref(ms), C.byref(n)), self._h)
+        return ms.value, n.value
+
+    def export_block(self, req: T.BlockRequest, device_ptr: int) -> None:
+        self._check(self._lib.polaris_hip_export_block(self._h, C.byref(req), C.c_void_p(device_ptr)), self._h)
+
+    def merge_device(self, device_ptr: int, req: T.BlockRequest) -> None:
+        self._check(self._lib.polaris_hip_merge_device(self._h, C.c_void_p(device_ptr), C.byref(req)), self._h)
+
+    @property
+    def device_name(self) -> str:
+        return self._name
+
+    # ---- internals ---------------------------------------------------------------------------
+    def _commit(self) -> float:
+        if not self._changes:
+            return 0.0
+        t0 = time.perf_counter()
+        for change, data in list(self._changes.items()):
+            if change == ChangeType.FrameDimensions:
+                self._W, self._H = int(data[0]), int(data[1])
+                self._check(self._lib.polaris_hip_resize(self._h, self._W, self._H), self._h)
+            elif change == ChangeType.SceneData:
+                view = T.scene_view(data)
+                self._check(self._lib.polaris_hip_upload_scene(self._h, C.byref(view)), self._h)
+            elif change == ChangeType.CameraData:
+                eye = np.ascontiguousarray(data.eye, dtype=np.float32)
+                fr = np.ascontiguousarray(data.frustum, dtype=np.float32)
+                self._check(self._lib.polaris_hip_set_camera(self._h, eye.ctypes.data_as(C.POINTER(C.c_float)),
+                                                             fr.ctypes.data_as(C.POINTER(C.c_float))), self._h)
+            else:
+                raise TracerError(2, f"unsupported change type {change}")
+        self._changes.clear()
+        self._stats.UpdateTime = time.perf_counter() - t0
+        return self._stats.UpdateTime
+
+    def _check(self, rc: int, h) -> None:
+        if rc == 0:
+            return
+        msg = self._lib.polaris_hip_last_error(h if h else None)
+        msg = msg.decode() if msg else ""
+        if rc == E_NO_SCENE_DATA:
+            raise ErrNoSceneData(rc, msg)
+        raise TracerError(rc, msg)
