@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s + ms/frame of the polaris tracer hot path on MI355X.
+
+A "step" is one frame of BASELINE.json's headline workload: the (layered) Cornell box at 512x512,
+128 spp, 5 bounces, Russian roulette from bounce 3, exposure 1.2 (CLI defaults, main.go:76-100),
+rendered the way renderer/default.go:106-171 renders a frame:
+
+    Schedule (naive, equal speeds -> FrameH/N rows each, remainder to tracer 0)
+    -> every tracer Trace()s its row block -> the primary MergeOutput()s every block
+    -> primary SyncFramebuffer() (tone-map)
+
+One process per GPU (torch.distributed, backend nccl = RCCL): rank r owns row block r; the single
+exchange step of the path -- the gather of the blocks' accumulator strips to the primary
+(renderer/default.go:191, tracer/opencl/resources.go:108-124) -- is a dist.gather of
+block_h*frame_w float4 per rank (512 KiB per peer at 8 GPUs).  The frame is fixed, so scaling is
+STRONG.  Scene and seeds are synthetic (polaris_amd/scenes.py); inputs are resident in HBM before
+the timed region starts.
+
+Prints ONE JSON line (rank 0).  `value` = rays traced by all ranks in the K timed frames / wall
+time (max over ranks); rays = primary + indirect + occlusion rays handed to an intersection kernel
+(BASELINE.md section 3).  `roofline` prices the dominant kernel against HBM: algorithmic bytes
+(SURVEY.md 8d split per kernel) / its HIP-event time.  `cpu_baseline` times the CPU
+restatement under oracle/ (the checker, never the product) on a bounded sample of the same
+workload on the host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+
+
+def naive_schedule(n_tracers: int, frame_h: int) -> list[int]:
+    """tracer/scheduler.go:83-106 assignBlocksBasedOnSpeed with equal speeds."""
+    scaler = frame_h / float(n_tracers)
+    rows = [int(max(1.0, 1.0 * scaler)) for _ in range(n_tracers)]
+    if sum(rows) < frame_h:
+        rows[0] += frame_h - sum(rows)
+    return rows
+
+
+def kernel_algorithmic_bytes(st: dict) -> dict:
+    """SURVEY.md 8d per-unit stream bytes, attributed to the kernel that moves them."""
+    rays = st["primary_rays"] + st["indirect_rays"]
+    return {
+        "generate": 52 * st["primary_rays"],
+        "intersect": 60 * rays,
+        "shade": 68 * st["shaded_hits"] + 32 * st["indirect_rays"] + 44 * st["occlusion_rays"]
+        + 60 * st["shaded_misses"] + 24 * st["emitter_hits"],
+        "occlusion": 36 * st["occlusion_rays"] + 44 * st["unoccluded"],
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="cornell")
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--spp", type=int, default=128)
+    ap.add_argument("--bounces", type=int, default=5)
+    ap.add_argument("--rr", type=int, default=3)
+    ap.add_argument("--samples-per-batch", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--save-png", default="")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the tracer has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+
+    from polaris_amd import ctypes_api as T
+    from polaris_amd import scenes
+    from polaris_amd.tracer import ChangeType, HipTracer, UpdateMode
+
+    W, H, spp, B = args.width, args.height, args.spp, args.bounces
+    sc = scenes.SCENES[args.scene](W / H)
+    seeds = scenes.make_seeds(spp, B)
+    rows = naive_schedule(world, H)
+    block_y = sum(rows[:rank])
+    block_h = rows[rank]
+
+    tr = HipTracer(f"hip-{rank}", local_rank)
+    tr.Init()
+    tr.UpdateState(UpdateMode.Synchronous, ChangeType.FrameDimensions, (W, H))
+    tr.UpdateState(UpdateMode.Synchronous, ChangeType.SceneData, sc)
+    tr.UpdateState(UpdateMode.Synchronous, ChangeType.CameraData, sc)
+    if args.samples_per_batch:
+        tr.set_option("samples_per_batch", args.samples_per_batch)
+    tr.set_option("time_kernels", 0 if args.no_kernel_timers else 1)
+
+    def make_req(by, bh):
+        r = T.BlockRequest()
+        r.frame_w, r.frame_h, r.block_x, r.block_y, r.block_w, r.block_h = W, H, 0, by, W, bh
+        r.samples_per_pixel, r.num_bounces, r.min_bounces_for_rr = spp, B, args.rr
+        r.exposure, r.seed, r.accumulated_samples = 1.2, 0, 0
+        return r
+
+    strip = torch.empty((block_h * W, 4), dtype=torch.float32, device=dev)
+    gather_list = [torch.empty((rows[i] * W, 4), dtype=torch.float32, device=dev) for i in range(world)] if rank == 0 and world > 1 else None
+    totals = {k: 0 for k in ("primary_rays", "indirect_rays", "occlusion_rays", "shaded_hits", "shaded_misses", "emitter_hits", "unoccluded")}
+
+    def frame(count: bool):
+        req = make_req(block_y, block_h)
+        tr.Trace(req, seeds)                       # Trace (tracer.go:194-247)
+        if count:
+            st = tr.last_trace_stats
+            for k in totals:
+                totals[k] += int(getattr(st, k))
+        if world == 1:
+            tr.MergeOutput(tr, make_req(block_y, block_h))  # primary merges its own block (default.go:191)
+        else:
+            tr.export_block(make_req(block_y, block_h), strip.data_ptr())
+            dist.gather(strip, gather_list, dst=0)  # the path's one exchange step
+            if rank == 0:
+                torch.cuda.synchronize()
+                y = 0
+                for i in range(world):
+                    tr.merge_device(gather_list[i].data_ptr(), make_req(y, rows[i]))
+                    y += rows[i]
+        if rank == 0:
+            full = make_req(0, H)
+            tr.SyncFramebuffer(full)               # default.go:159-161
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        frame(False)
+    for name in ("generate", "intersect", "shade", "scan", "occlusion", "resolve", "aggregate", "tonemap"):
+        tr.kernel_ms(name)  # reset timers accumulated during warm-up
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    kt = {}
+    if not args.no_kernel_timers:
+        for name in ("generate", "intersect", "shade", "scan", "occlusion", "resolve", "aggregate", "tonemap"):
+            ms, n = tr.kernel_ms(name)
+            kt[name] = (ms, n)
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    cnt = torch.tensor([totals[k] for k in sorted(totals)], dtype=torch.int64, device=dev)
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    elapsed = float(el.item())
+    tot = {k: int(v) for k, v in zip(sorted(totals), cnt.tolist())}
+    rays = tot["primary_rays"] + tot["indirect_rays"] + tot["occlusion_rays"]
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        out = {
+            "metric": "Mrays/s (primary+indirect+occlusion rays traced / wall), Cornell box 512x512x128spp",
+            "value": rays / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "ms_per_frame": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{sc.name} {W}x{H} {spp}spp {B} bounces rr>={args.rr}, {sc.num_triangles} tris, "
+                                   f"row blocks {rows} (naive scheduler), gather-to-primary + tonemap",
+                       "frame": [W, H], "spp": spp, "bounces": B, "rays_per_frame": rays // args.steps,
+                       "paths_per_s": W * H * spp * args.steps / elapsed},
+        }
+        # ---- roofline of the dominant kernel (rank 0's kernels; every rank runs the same mix) ----
+        if kt:
+            # rank 0's own counters for rank 0's kernel times
+            mine = {k: totals[k] for k in totals}
+            alg = kernel_algorithmic_bytes(mine)
+            dom = max(("generate", "intersect", "shade", "occlusion"), key=lambda k: kt[k][0])
+            ms, n = kt[dom]
+            achieved = alg[dom] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "algorithmic_bytes_per_launch": alg[dom] / max(n, 1), "avg_launch_ms": ms / max(n, 1),
+                               "launches": n}
+            out["kernels"] = {k: {"ms": round(v[0], 3), "launches": v[1],
+                                  "GBps_algorithmic": (round(alg[k] / (v[0] * 1e-3) / 1e9, 2) if v[0] > 0 and k in alg else None)}
+                              for k, v in kt.items()}
+            whole = (112 * mine["primary_rays"] + 68 * mine["shaded_hits"] + 92 * mine["indirect_rays"] + 80 * mine["occlusion_rays"]
+                     + 44 * mine["unoccluded"] + 60 * mine["shaded_misses"] + 24 * mine["emitter_hits"]
+                     + (48 + 16) * rows[0] * W * args.steps)
+            out["whole_path_algorithmic_GBps_rank0"] = whole / elapsed / 1e9
+        # ---- CPU baseline: the oracle (checker) on a bounded sample of the same workload ----
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                from oracle import pybind as ob
+
+                orc = ob.Oracle("oracle")
+                cpu_spp = 2
+                req = ob.make_request(W, H, spp=cpu_spp, bounces=B, rr=args.rr)
+                t = time.perf_counter()
+                _, cs, _ = orc.trace(sc, req, seeds[: cpu_spp * (1 + B)])
+                dt = time.perf_counter() - t
+                # scale the sample so the leg costs ~10-20 s of CPU work
+                more = int(min(32, max(0, 12.0 / max(dt / cpu_spp, 1e-3) - cpu_spp)))
+                if more >= 2:
+                    req2 = ob.make_request(W, H, spp=more, bounces=B, rr=args.rr)
+                    t = time.perf_counter()
+                    _, cs2, _ = orc.trace(sc, req2, seeds[: more * (1 + B)])
+                    dt2 = time.perf_counter() - t
+                    cpu_rays, cpu_dt, cpu_n = cs2.total_rays(), dt2, more
+                else:
+                    cpu_rays, cpu_dt, cpu_n = cs.total_rays(), dt, cpu_spp
+                out["cpu_baseline"] = {"value": cpu_rays / cpu_dt / 1e6, "unit": "Mrays/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": f"same scene/frame/options, first {cpu_n} of {spp} spp ({cpu_rays} rays, {cpu_dt:.1f} s), "
+                                                 f"oracle/polaris_oracle.cpp with OpenMP on all host cores",
+                                       "ms_per_frame_extrapolated": cpu_dt / cpu_n * spp * 1e3}
+            except Exception as e:  # the baseline is a reported extra, never a reason to lose the bench line
+                out["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+        if args.save_png:
+            from PIL import Image
+
+            Image.fromarray(tr.read_framebuffer()[..., :3]).save(args.save_png)
+        print(json.dumps(out))
+    tr.Close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

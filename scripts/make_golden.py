@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the COMPILED REFERENCE (oracle/_ref/libpolaris_ref_pm.so).
+
+Runs only where /root/reference exists (this container).  Each fixture holds the inputs (the
+compiled scene arrays, request, seeds) and the outputs of the reference's own OpenCL C executed
+on the host: the trace accumulator, the ray counters, and the primary-ray taps.  Fixtures are
+data; no reference source is stored.
+
+    python scripts/make_golden.py
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+from oracle import pybind as ob  # noqa: E402
+from polaris_amd import scene_io, scenes  # noqa: E402
+
+CASES = [
+    # name, scene key, W, H, spp, bounces, rr, block_y, block_h
+    ("cornell_diffuse_32", "cornell-diffuse", 32, 32, 4, 5, 3, 0, 32),
+    ("cornell_layered_32", "cornell", 32, 32, 4, 5, 3, 0, 32),
+    ("cornell_layered_block", "cornell", 40, 24, 2, 4, 2, 8, 11),   # ragged width, inner row block
+    ("sphere_env_32", "sphere", 32, 32, 4, 5, 3, 0, 32),
+    ("cubes_instanced_32", "cubes", 32, 32, 4, 5, 3, 0, 32),
+    ("materials_32", "materials", 32, 32, 4, 5, 3, 0, 32),
+    ("materials_norr_1bounce", "materials", 24, 16, 3, 1, 2, 0, 16),  # rr disabled: minRR = bounces+1 (cmd/render.go:42-45)
+]
+
+
+def main():
+    ob.build_ref()
+    ref = ob.Oracle("ref_pm")
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(out_dir, exist_ok=True)
+    for name, key, W, H, spp, B, rr, by, bh in CASES:
+        sc = scenes.SCENES[key](W / H)
+        seeds = scenes.make_seeds(spp, B, base=0xC0FFEE + len(name))
+        req = ob.make_request(W, H, spp=spp, bounces=B, rr=rr, block_y=by, block_h=bh)
+        acc, st, taps = ref.trace(sc, req, seeds, tap_sample=0)
+        fb = ref.tonemap(acc, 1.0 / spp, 1.2)
+        d = scene_io.scene_to_dict(sc)
+        d.update(req=np.array([W, H, spp, B, rr, by, bh], dtype=np.int64), seeds=seeds,
+                 accum=acc[..., :3].copy(), framebuffer=fb,
+                 rays_per_bounce=np.array(list(st.rays_per_bounce[:B]), dtype=np.int64),
+                 occl_per_bounce=np.array(list(st.occl_per_bounce[:B]), dtype=np.int64),
+                 counters=np.array([st.primary_rays, st.indirect_rays, st.occlusion_rays, st.shaded_hits, st.shaded_misses,
+                                    st.unoccluded], dtype=np.int64),
+                 primary_rays=taps["primary_rays"], primary_hit=taps["primary_hit"], primary_wuvt=taps["primary_wuvt"],
+                 primary_tri=taps["primary_tri"], throughput0=taps["throughput0"][:, :3].copy(),
+                 provenance=np.array(ref.describe()))
+        path = os.path.join(out_dir, name + ".npz")
+        np.savez_compressed(path, **d)
+        print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB, rays/bounce {list(st.rays_per_bounce[:B])}")
+
+
+if __name__ == "__main__":
+    main()

