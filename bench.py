@@ -76,6 +76,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--save-png", default="")
+    ap.add_argument("--opt", action="append", default=[], help="tracer option key=value (polaris_hip_set_option)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -115,6 +116,9 @@ def main() -> None:
     if args.samples_per_batch:
         tr.set_option("samples_per_batch", args.samples_per_batch)
     tr.set_option("time_kernels", 0 if args.no_kernel_timers else 1)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        tr.set_option(k, int(v))
 
     def make_req(by, bh):
         r = T.BlockRequest()

@@ -229,6 +229,216 @@ __global__ __launch_bounds__(WG) void k_occlusion(Streams st, BvhDev B, float4 *
 }
 
 // ------------------------------------------------------------------------------------------
+// Persistent traversal with lane refill ("k_trace").
+//
+// PMC counters of the one-ray-per-lane kernels above show the limiter: only ~28 % of the lanes
+// of an issued VALU instruction are live (SQ_THREAD_CYCLES_VALU / 64 / SQ_ACTIVE_INST_VALU) --
+// rays of a wave finish at very different times and lanes sit in different phases (box tests
+// vs triangle tests).  This kernel attacks both:
+//   * a wave is a persistent worker: it pulls 256-slot chunks (= one workgroup's compacted rays)
+//     from a global ticket counter and, whenever >= kRefillMin of its lanes are idle, hands them
+//     the next rays of the chunk (ballot/popcount ranks) -- the wave's tail is filled with new
+//     work instead of waiting for its longest ray;
+//   * "while-while" phases: all lanes first descend through inner nodes (lanes that already
+//     reached a leaf wait), then all lanes with a leaf test triangles.
+// The queue needs no co-residency: a wave exits when the ticket counter passes the chunk count.
+// Per-ray arithmetic is the same as traverse<> above (same slab test, same Moeller-Trumbore,
+// same tie rule), so results are bit-identical; only the schedule changes.
+// ------------------------------------------------------------------------------------------
+#ifndef POLARIS_REFILL_MIN
+#define POLARIS_REFILL_MIN 48
+#endif
+constexpr int kRefillMin = POLARIS_REFILL_MIN;
+
+__device__ __forceinline__ float slab_entry_hw(float4 lo, float4 hi, f3 o, f3 inv, float maxDist) {
+	// identical to slab_entry except that min/max are the hardware's IEEE minNum/maxNum
+	// (v_min_f32/v_max3_f32): they differ from pm_fmin/pm_fmax only in the sign of a zero result,
+	// which no comparison below can see.
+	float t0x = (lo.x - o.x) * inv.x, t0y = (lo.y - o.y) * inv.y, t0z = (lo.z - o.z) * inv.z;
+	float t1x = (hi.x - o.x) * inv.x, t1y = (hi.y - o.y) * inv.y, t1z = (hi.z - o.z) * inv.z;
+	float minmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)), __builtin_fmaxf(t0z, t1z));
+	float maxmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)), __builtin_fminf(t0z, t1z));
+	return (minmax < 0 || maxmin > minmax) ? kFltMax : (maxmin >= maxDist ? kFltMax : maxmin);
+}
+
+// Work distribution: chunks are dealt round-robin to the persistent workgroups (chunk c belongs
+// to workgroup c % gridDim.x) and the 4 waves of a workgroup share an LDS cursor.  A single global
+// ticket counter was measured first: it saturates at ~88 dequeues/us (MI355X_MICROARCH.md,
+// "dequeue"), a ~190 us floor under every launch of a 16 Ki-chunk batch.
+
+template <bool ANY_HIT, int STACK>
+__global__ __launch_bounds__(WG) void k_trace(Streams st, BvhDev B, uint32_t num_chunks, uint32_t *ticket, float4 *acc,
+                                              unsigned long long *stats) {
+	__shared__ int stk[STACK][WG]; // STACK = smallest of {16, 24, 32} that fits the scene: LDS per wave sets the occupancy
+	__shared__ uint32_t wg_cursor;
+	if (threadIdx.x == 0) wg_cursor = 0;
+	__syncthreads();
+	(void)ticket;
+	const int tid = threadIdx.x;
+	const uint32_t lane = tid & 63;
+	const unsigned long long below = (1ull << lane) - 1ull;
+	const uint32_t *cnts = ANY_HIT ? st.cnt_occ : st.cnt_ray;
+	const float4 *src_o = ANY_HIT ? st.occ_o : st.ray_o;
+	const float4 *src_d = ANY_HIT ? st.occ_d : st.ray_d;
+
+	// wave-uniform queue state
+	uint32_t chunk = 0, off = 0, cnt = 0;
+	bool drained = false;
+	// per-lane ray state
+	bool has = false;
+	uint32_t slot = 0;
+	f3 o = {0, 0, 0}, d = {0, 0, 0}, inv = {0, 0, 0};
+	float maxDist = 0.0f;
+	int sp = 0, cur = -1, inst = 0, cell = 0;
+	uint32_t irank = 0, unocc = 0;
+	HitRec best;
+	best.t = 0; best.u = best.v = 0; best.tri = -1; best.inst = 0; best.irank = best.trank = 0;
+
+	auto finish = [&](bool occluded) {
+		if (ANY_HIT) {
+			if (!occluded) {
+				const float4 e = st.occ_e[slot];
+				float4 a = acc[cell]; // one path per cell and launch: plain read-modify-write
+				a.x += e.x; a.y += e.y; a.z += e.z;
+				acc[cell] = a;
+				unocc++;
+			}
+		} else {
+			st.hit[slot] = make_float4(best.u, best.v, best.t, ibits(best.tri));
+			if (st.hit_inst) st.hit_inst[slot] = best.inst;
+		}
+		has = false;
+		cur = -1;
+	};
+	auto pop = [&]() {
+		for (;;) {
+			if (sp == 0) { finish(false); return; }
+			cur = stk[--sp][tid];
+			if (cur != kExitMarker) return;
+			const float4 o4 = src_o[slot], d4 = src_d[slot]; // leaving the instance: back to the world-space ray
+			o = xyz(o4); d = xyz(d4);
+			inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)};
+		}
+	};
+
+	for (;;) {
+		// ---- refill idle lanes ---------------------------------------------------------------
+		unsigned long long freem = __ballot(!has);
+		if (!drained && (freem == ~0ull || __popcll(freem) >= kRefillMin)) {
+			for (;;) {
+				if (off >= cnt) {
+					uint32_t c = 0;
+					if (lane == 0) c = atomicAdd(&wg_cursor, 1u);
+					c = blockIdx.x + __builtin_amdgcn_readfirstlane(c) * gridDim.x;
+					if (c >= num_chunks) { drained = true; break; }
+					chunk = c;
+					off = 0;
+					cnt = cnts[chunk];
+					continue;
+				}
+				freem = __ballot(!has);
+				const uint32_t nfree = __popcll(freem);
+				if (nfree == 0) break;
+				const uint32_t take = min(cnt - off, nfree);
+				const uint32_t rank = __popcll(freem & below);
+				if (!has && rank < take) {
+					slot = chunk * WG + off + rank;
+					const float4 o4 = src_o[slot], d4 = src_d[slot];
+					o = xyz(o4); d = xyz(d4);
+					maxDist = o4.w;
+					cell = fbits(d4.w);
+					inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)};
+					sp = 0;
+					cur = B.root_ref;
+					inst = 0; irank = 0;
+					best.t = maxDist; best.tri = -1; best.inst = 0; best.u = best.v = 0.0f; best.irank = best.trank = 0;
+					has = true;
+				}
+				off += take;
+			}
+		}
+		if (__ballot(has) == 0ull) {
+			if (drained) break;
+			continue;
+		}
+		// ---- phase 1: descend through inner nodes -----------------------------------------------
+		while (has && cur >= 0) {
+			const PairNode P = B.pairs[cur];
+			float t0 = slab_entry_hw(P.lo0, P.hi0, o, inv, maxDist);
+			float t1 = slab_entry_hw(P.lo1, P.hi1, o, inv, maxDist);
+			if (!ANY_HIT) {
+				const float lim = best.t * 1.001f;
+				if (t0 > lim) t0 = kFltMax;
+				if (t1 > lim) t1 = kFltMax;
+			}
+			int c0 = fbits(P.lo0.w), c1 = fbits(P.lo1.w);
+			const bool h0 = t0 < kFltMax, h1 = t1 < kFltMax;
+			if (h0 && h1) {
+				if (t1 < t0) { int t = c0; c0 = c1; c1 = t; }
+				stk[sp++][tid] = c1;
+				cur = c0;
+			} else if (h0 || h1) {
+				cur = h0 ? c0 : c1;
+			} else {
+				pop();
+			}
+		}
+		// ---- phase 2: leaves ---------------------------------------------------------------------
+		if (has) {
+			const int2 li = B.leaves[~cur];
+			if (li.y == 0) { // top-level leaf: enter the instance
+				inst = -li.x;
+				const InstRec I = B.insts[inst];
+				irank = (uint32_t)I.meta.y;
+				stk[sp++][tid] = kExitMarker;
+				f3 no = {I.r0.x * o.x + I.r0.y * o.y + I.r0.z * o.z + I.r0.w, I.r1.x * o.x + I.r1.y * o.y + I.r1.z * o.z + I.r1.w,
+				         I.r2.x * o.x + I.r2.y * o.y + I.r2.z * o.z + I.r2.w};
+				f3 nd = {I.r0.x * d.x + I.r0.y * d.y + I.r0.z * d.z, I.r1.x * d.x + I.r1.y * d.y + I.r1.z * d.z,
+				         I.r2.x * d.x + I.r2.y * d.y + I.r2.z * d.z};
+				o = no; d = nd;
+				inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)};
+				cur = I.meta.x;
+			} else {
+				const int first = -li.x;
+				bool occluded = false;
+				for (int t = first; t < first + li.y; t++) {
+					const TriRec T = B.tris[t];
+					f3 e1 = xyz(T.e1), e2 = xyz(T.e2);
+					f3 pv = cross(d, e2);
+					float det = dot(e1, pv);
+					if (pm_fabs(det) < kEps) continue;
+					float idet = pm_rcp(det);
+					f3 tv = o - xyz(T.v0);
+					float u = dot(tv, pv) * idet;
+					if (u < 0.0f || u > 1.0f) continue;
+					f3 qv = cross(tv, e1);
+					float v = dot(d, qv) * idet;
+					if (v < 0.0f || u + v > 1.0f) continue;
+					float tt = dot(e2, qv) * idet;
+					if (ANY_HIT) {
+						if (tt > kEps && tt < maxDist) { occluded = true; break; }
+					} else if (tt > kEps) {
+						const uint32_t trank = (uint32_t)fbits(T.v0.w);
+						const bool closer = tt < best.t;
+						const bool tie = tt == best.t && best.tri >= 0 && (irank < best.irank || (irank == best.irank && trank < best.trank));
+						if (closer || tie) { best.t = tt; best.u = u; best.v = v; best.tri = t; best.inst = inst; best.irank = irank; best.trank = trank; }
+					}
+				}
+				if (ANY_HIT && occluded) finish(true);
+				else pop();
+			}
+		}
+	}
+	if (ANY_HIT) {
+		// wave-level sum of the per-lane unoccluded counts, one atomic per wave
+		uint32_t v = unocc;
+#pragma unroll
+		for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
+		if (lane == 0 && v) atomicAdd(&stats[ST_UNOCCLUDED], (unsigned long long)v);
+	}
+}
+
+// ------------------------------------------------------------------------------------------
 // shadeHits (+ shadePrimaryRayMisses / shadeIndirectRayMisses), kernels/pt_integrator.cl:17-275
 // ------------------------------------------------------------------------------------------
 struct ShadeArgs {

@@ -58,13 +58,23 @@ struct polaris_hip_tracer {
 	bool have_camera = false;
 	CameraArgs cam{};
 
-	// wavefront batch state
-	size_t slots = 0; // capacity in slots
-	Streams st{};
-	std::vector<DevBuf> stream_bufs;
+	// wavefront batch state: two pipelines so consecutive batches overlap (the sparse late-bounce
+	// launches of batch i run beside the dense early bounces of batch i+1 on the other stream)
+	struct Pipe {
+		hipStream_t q = nullptr;
+		size_t slots = 0; // capacity in slots
+		Streams st{};
+		std::vector<DevBuf> bufs;
+		hipEvent_t done = nullptr; // recorded after the pipe's last resolve
+	};
+	static constexpr int kMaxPipes = 4;
+	Pipe pipe[kMaxPipes];
+	int opt_overlap = 4; // number of pipelines used (1 = no overlap)
 	uint32_t *d_seeds = nullptr;
 	size_t seeds_cap = 0;
 	unsigned long long *d_stats = nullptr;
+	uint32_t *d_tickets = nullptr; // work-queue ticket counters of the persistent traversal launches of one batch
+	int num_cus = 256;
 	void *staging = nullptr; // peer-merge staging strip
 	size_t staging_bytes = 0;
 
@@ -73,13 +83,15 @@ struct polaris_hip_tracer {
 	int opt_exact = 0;
 	int opt_packet_primary = 0;
 	int opt_time_kernels = 0;
+	int opt_trace_wgs_per_cu = 0; // 0 = auto (what the LDS stack admits)
+	int opt_traversal = 1; // 1 = persistent waves with lane refill (k_trace), 0 = one ray per lane (k_intersect/k_occlusion)
 
 	// per-kernel timing (option time_kernels)
 	struct Pending { const char *name; hipEvent_t a, b; };
 	std::vector<Pending> pending;
 	std::vector<hipEvent_t> event_pool;
 	std::map<std::string, KernelTimer> timers;
-	hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+	hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_fork = nullptr;
 };
 
 namespace {
@@ -129,8 +141,9 @@ void free_pool(std::vector<DevBuf> &pool) {
 struct Timed {
 	polaris_hip_tracer *h;
 	const char *name;
+	hipStream_t q;
 	hipEvent_t a = nullptr, b = nullptr;
-	Timed(polaris_hip_tracer *h_, const char *n) : h(h_), name(n) {
+	Timed(polaris_hip_tracer *h_, const char *n, hipStream_t q_ = nullptr) : h(h_), name(n), q(q_ ? q_ : h_->stream) {
 		if (!h->opt_time_kernels) return;
 		auto get = [&]() {
 			hipEvent_t e;
@@ -139,11 +152,11 @@ struct Timed {
 			return e;
 		};
 		a = get(); b = get();
-		if (a) (void)hipEventRecord(a, h->stream);
+		if (a) (void)hipEventRecord(a, q);
 	}
 	~Timed() {
 		if (!a || !b) return;
-		(void)hipEventRecord(b, h->stream);
+		(void)hipEventRecord(b, q);
 		h->pending.push_back({name, a, b});
 	}
 };
@@ -162,28 +175,29 @@ void collect_timers(polaris_hip_tracer *h) { // stream must be idle
 	h->pending.clear();
 }
 
-int ensure_streams(polaris_hip_tracer *h, size_t slots, bool want_inst) {
-	if (slots <= h->slots && (!want_inst || h->st.hit_inst)) return POLARIS_OK;
-	HIP_TRY(h, hipStreamSynchronize(h->stream));
-	free_pool(h->stream_bufs);
-	h->st = Streams{};
-	h->slots = 0;
+int ensure_streams(polaris_hip_tracer *h, int p, size_t slots, bool want_inst) {
+	polaris_hip_tracer::Pipe &P = h->pipe[p];
+	if (slots <= P.slots && (!want_inst || P.st.hit_inst)) return POLARIS_OK;
+	HIP_TRY(h, hipStreamSynchronize(P.q));
+	free_pool(P.bufs);
+	P.st = Streams{};
+	P.slots = 0;
 	const size_t wgs = slots / WG;
 	int rc = 0;
-	rc |= dev_alloc(h, h->stream_bufs, &h->st.ray_o, slots);
-	rc |= dev_alloc(h, h->stream_bufs, &h->st.ray_d, slots);
-	rc |= dev_alloc(h, h->stream_bufs, &h->st.thr, slots);
-	rc |= dev_alloc(h, h->stream_bufs, &h->st.hit, slots);
-	rc |= dev_alloc(h, h->stream_bufs, &h->st.occ_o, slots);
-	rc |= dev_alloc(h, h->stream_bufs, &h->st.occ_d, slots);
-	rc |= dev_alloc(h, h->stream_bufs, &h->st.occ_e, slots);
-	rc |= dev_alloc(h, h->stream_bufs, &h->st.lsum, slots);
-	rc |= dev_alloc(h, h->stream_bufs, &h->st.cnt_ray, wgs);
-	rc |= dev_alloc(h, h->stream_bufs, &h->st.cnt_occ, wgs);
-	rc |= dev_alloc(h, h->stream_bufs, &h->st.pfx, wgs);
-	if (want_inst) rc |= dev_alloc(h, h->stream_bufs, &h->st.hit_inst, slots);
-	if (rc) { free_pool(h->stream_bufs); h->st = Streams{}; return rc; }
-	h->slots = slots;
+	rc |= dev_alloc(h, P.bufs, &P.st.ray_o, slots);
+	rc |= dev_alloc(h, P.bufs, &P.st.ray_d, slots);
+	rc |= dev_alloc(h, P.bufs, &P.st.thr, slots);
+	rc |= dev_alloc(h, P.bufs, &P.st.hit, slots);
+	rc |= dev_alloc(h, P.bufs, &P.st.occ_o, slots);
+	rc |= dev_alloc(h, P.bufs, &P.st.occ_d, slots);
+	rc |= dev_alloc(h, P.bufs, &P.st.occ_e, slots);
+	rc |= dev_alloc(h, P.bufs, &P.st.lsum, slots);
+	rc |= dev_alloc(h, P.bufs, &P.st.cnt_ray, wgs);
+	rc |= dev_alloc(h, P.bufs, &P.st.cnt_occ, wgs);
+	rc |= dev_alloc(h, P.bufs, &P.st.pfx, wgs);
+	if (want_inst) rc |= dev_alloc(h, P.bufs, &P.st.hit_inst, slots);
+	if (rc) { free_pool(P.bufs); P.st = Streams{}; return rc; }
+	P.slots = slots;
 	return POLARIS_OK;
 }
 
@@ -201,15 +215,27 @@ int check_request(polaris_hip_tracer *h, const PolarisBlockRequest *r) {
 
 inline uint32_t grid_for(size_t n) { return (uint32_t)((n + WG - 1) / WG); }
 
-// One wavefront batch: K samples starting at sample s0.
-void launch_batch(polaris_hip_tracer *h, const PolarisBlockRequest *r, uint32_t s0, uint32_t K, uint32_t N, uint32_t Npad,
-                  bool exact) {
+template <bool ANY_HIT>
+void launch_trace(polaris_hip_tracer *h, polaris_hip_tracer::Pipe &P, uint32_t grid, uint32_t chunks, float4 *acc) {
+	hipStream_t q = P.q;
+	if (h->max_stack <= 16)
+		hipLaunchKernelGGL((k_trace<ANY_HIT, 16>), dim3(grid), dim3(WG), 0, q, P.st, h->bvh, chunks, h->d_tickets, acc, h->d_stats);
+	else if (h->max_stack <= 24)
+		hipLaunchKernelGGL((k_trace<ANY_HIT, 24>), dim3(grid), dim3(WG), 0, q, P.st, h->bvh, chunks, h->d_tickets, acc, h->d_stats);
+	else
+		hipLaunchKernelGGL((k_trace<ANY_HIT, 32>), dim3(grid), dim3(WG), 0, q, P.st, h->bvh, chunks, h->d_tickets, acc, h->d_stats);
+}
+
+// One wavefront batch: K samples starting at sample s0, on pipeline p.
+void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, uint32_t s0, uint32_t K, uint32_t N, uint32_t Npad,
+                  bool exact, hipEvent_t resolve_after) {
+	polaris_hip_tracer::Pipe &P = h->pipe[p];
 	const uint32_t B = r->num_bounces, stride = 1 + B;
 	const uint32_t wgs_per_sample = Npad / WG, wgs = K * wgs_per_sample;
-	hipStream_t q = h->stream;
+	hipStream_t q = P.q;
 	{
-		Timed t(h, "generate");
-		hipLaunchKernelGGL(k_generate, dim3(wgs), dim3(WG), 0, q, h->st, h->cam, h->d_seeds, stride, s0, N, Npad, h->W, r->block_y,
+		Timed t(h, "generate", q);
+		hipLaunchKernelGGL(k_generate, dim3(wgs), dim3(WG), 0, q, P.st, h->cam, h->d_seeds, stride, s0, N, Npad, h->W, r->block_y,
 		                   exact ? 0 : 1);
 	}
 	ShadeArgs A{};
@@ -217,31 +243,45 @@ void launch_batch(polaris_hip_tracer *h, const PolarisBlockRequest *r, uint32_t 
 	A.N = N; A.Npad = Npad; A.W = h->W; A.blockY = r->block_y;
 	A.min_rr = r->min_bounces_for_rr;
 	A.exact = exact ? 1 : 0;
-	A.acc = exact ? h->trace_acc : h->st.lsum;
+	A.acc = exact ? h->trace_acc : P.st.lsum;
+	// persistent grid: as many workgroups as the LDS stack lets a CU hold (16-entry stack: 16 KB per
+	// workgroup -> 8 by LDS, VGPRs allow 7-8 waves/SIMD; 32-entry: 5)
+	uint32_t per_cu = h->max_stack <= 16 ? 8u : (h->max_stack <= 24 ? 6u : 5u);
+	if (h->opt_trace_wgs_per_cu > 0) per_cu = (uint32_t)h->opt_trace_wgs_per_cu;
+	const uint32_t persistent = std::min<uint32_t>(wgs, (uint32_t)h->num_cus * per_cu);
 	for (uint32_t b = 0; b < B; b++) {
 		{
-			Timed t(h, "intersect");
-			hipLaunchKernelGGL(k_intersect, dim3(wgs), dim3(WG), 0, q, h->st, h->bvh);
+			Timed t(h, "intersect", q);
+			if (h->opt_traversal)
+				launch_trace<false>(h, P, persistent, wgs, nullptr);
+			else
+				hipLaunchKernelGGL(k_intersect, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh);
 		}
 		A.bounce = b;
 		A.last_bounce = (b + 1 == B) ? 1 : 0;
 		{
-			Timed t(h, "shade");
-			hipLaunchKernelGGL(k_shade, dim3(wgs), dim3(WG), 0, q, h->st, h->scene, A, h->d_stats);
+			Timed t(h, "shade", q);
+			hipLaunchKernelGGL(k_shade, dim3(wgs), dim3(WG), 0, q, P.st, h->scene, A, h->d_stats);
 		}
 		{
-			Timed t(h, "scan");
-			hipLaunchKernelGGL(k_scan, dim3(K), dim3(1024), 0, q, h->st, wgs_per_sample, b, A.last_bounce ? 0 : 1, h->d_stats);
+			Timed t(h, "scan", q);
+			hipLaunchKernelGGL(k_scan, dim3(K), dim3(1024), 0, q, P.st, wgs_per_sample, b, A.last_bounce ? 0 : 1, h->d_stats);
 		}
 		{
-			Timed t(h, "occlusion");
-			hipLaunchKernelGGL(k_occlusion, dim3(wgs), dim3(WG), 0, q, h->st, h->bvh, A.acc, h->d_stats);
+			Timed t(h, "occlusion", q);
+			if (h->opt_traversal)
+				launch_trace<true>(h, P, persistent, wgs, A.acc);
+			else
+				hipLaunchKernelGGL(k_occlusion, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, A.acc, h->d_stats);
 		}
 	}
 	if (!exact) {
-		Timed t(h, "resolve");
-		hipLaunchKernelGGL(k_resolve, dim3(grid_for(N)), dim3(WG), 0, q, h->st.lsum, h->trace_acc, K, N, Npad, r->block_y * h->W);
+		// batches resolve into the trace accumulator in sample order: wait for the previous batch's resolve
+		if (resolve_after) (void)hipStreamWaitEvent(q, resolve_after, 0);
+		Timed t(h, "resolve", q);
+		hipLaunchKernelGGL(k_resolve, dim3(grid_for(N)), dim3(WG), 0, q, P.st.lsum, h->trace_acc, K, N, Npad, r->block_y * h->W);
 	}
+	(void)hipEventRecord(P.done, q);
 }
 
 } // namespace
@@ -281,7 +321,16 @@ int polaris_hip_create(int device_index, polaris_hip_tracer **out) {
 	h->device = device_index;
 	hipError_t e = hipSetDevice(device_index);
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+	h->pipe[0].q = h->stream;
+	for (int p = 1; p < polaris_hip_tracer::kMaxPipes && e == hipSuccess; p++) e = hipStreamCreateWithFlags(&h->pipe[p].q, hipStreamNonBlocking);
+	for (int p = 0; p < polaris_hip_tracer::kMaxPipes && e == hipSuccess; p++) e = hipEventCreateWithFlags(&h->pipe[p].done, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipMalloc((void **)&h->d_stats, ST_COUNT * sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipMalloc((void **)&h->d_tickets, 2 * POLARIS_MAX_BOUNCES * sizeof(uint32_t));
+	if (e == hipSuccess) {
+		hipDeviceProp_t p;
+		if (hipGetDeviceProperties(&p, device_index) == hipSuccess && p.multiProcessorCount > 0) h->num_cus = p.multiProcessorCount;
+	}
 	if (e == hipSuccess) e = hipEventCreate(&h->ev_start);
 	if (e == hipSuccess) e = hipEventCreate(&h->ev_stop);
 	if (e != hipSuccess) {
@@ -299,15 +348,24 @@ void polaris_hip_destroy(polaris_hip_tracer *h) {
 		std::lock_guard<std::mutex> lk(h->mu);
 		(void)hipSetDevice(h->device);
 		if (h->stream) (void)hipStreamSynchronize(h->stream);
+		for (int p = 1; p < polaris_hip_tracer::kMaxPipes; p++)
+			if (h->pipe[p].q) (void)hipStreamSynchronize(h->pipe[p].q);
 		collect_timers(h);
 		for (auto e : h->event_pool) (void)hipEventDestroy(e);
-		free_pool(h->stream_bufs);
+		for (auto &P : h->pipe) {
+			free_pool(P.bufs);
+			if (P.done) (void)hipEventDestroy(P.done);
+		}
+		if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+		for (int p = 1; p < polaris_hip_tracer::kMaxPipes; p++)
+			if (h->pipe[p].q) (void)hipStreamDestroy(h->pipe[p].q);
 		free_pool(h->scene_bufs);
 		if (h->trace_acc) (void)hipFree(h->trace_acc);
 		if (h->frame_acc) (void)hipFree(h->frame_acc);
 		if (h->framebuffer) (void)hipFree(h->framebuffer);
 		if (h->d_seeds) (void)hipFree(h->d_seeds);
 		if (h->d_stats) (void)hipFree(h->d_stats);
+		if (h->d_tickets) (void)hipFree(h->d_tickets);
 		if (h->staging) (void)hipFree(h->staging);
 		if (h->ev_start) (void)hipEventDestroy(h->ev_start);
 		if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
@@ -404,6 +462,9 @@ int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value
 	else if (k == "exact_accumulate") h->opt_exact = value != 0;
 	else if (k == "packet_primary") h->opt_packet_primary = value != 0;
 	else if (k == "time_kernels") h->opt_time_kernels = value != 0;
+	else if (k == "traversal") h->opt_traversal = value != 0;
+	else if (k == "overlap") h->opt_overlap = (int)std::max<int64_t>(1, std::min<int64_t>(value, polaris_hip_tracer::kMaxPipes));
+	else if (k == "trace_wgs_per_cu") h->opt_trace_wgs_per_cu = (int)std::max<int64_t>(0, std::min<int64_t>(value, 64));
 	else return fail(h, POLARIS_E_BAD_ARGUMENT, "unknown option '%s'", key);
 	return POLARIS_OK;
 }
@@ -429,11 +490,20 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 	const bool exact = h->opt_exact != 0;
 	uint32_t K = 1;
 	if (!exact) {
+		// ~8 M paths per batch, but never fewer batches than pipelines (a 64-row block of an 8-GPU
+		// frame would otherwise collapse into one batch and lose the overlap)
 		if (h->opt_samples_per_batch > 0) K = (uint32_t)std::min<int64_t>(h->opt_samples_per_batch, 4096);
-		else K = std::max<uint32_t>(1u, (uint32_t)((4u << 20) / Npad)); // ~4 M paths in flight
+		else {
+			K = std::max<uint32_t>(1u, (uint32_t)((8u << 20) / Npad));
+			const uint32_t pipes = (uint32_t)std::max(1, h->opt_overlap);
+			K = std::min(K, std::max(1u, (spp + pipes - 1) / pipes));
+		}
 		K = std::max<uint32_t>(1u, std::min(K, std::max(spp, 1u)));
 	}
-	if (int rc = ensure_streams(h, (size_t)K * Npad, false)) return rc;
+	const uint32_t n_batches = spp ? (spp + K - 1) / K : 0;
+	const int n_pipes = exact ? 1 : (int)std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)h->opt_overlap, n_batches));
+	for (int p = 0; p < n_pipes; p++)
+		if (int rc = ensure_streams(h, p, (size_t)K * Npad, false)) return rc;
 	if (need_seeds > h->seeds_cap) {
 		if (h->d_seeds) (void)hipFree(h->d_seeds);
 		h->d_seeds = nullptr;
@@ -450,7 +520,16 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 	HIP_TRY(h, hipMemsetAsync(h->trace_acc, 0, F * sizeof(float4), q)); // ClearTraceAccumulator (tracer.go:215)
 	HIP_TRY(h, hipMemsetAsync(h->d_stats, 0, ST_COUNT * sizeof(unsigned long long), q));
 	if (need_seeds) HIP_TRY(h, hipMemcpyAsync(h->d_seeds, seeds, need_seeds * sizeof(uint32_t), hipMemcpyHostToDevice, q));
-	for (uint32_t s0 = 0; s0 < spp; s0 += K) launch_batch(h, r, s0, std::min(K, spp - s0), N, Npad, exact);
+	if (n_pipes > 1) { // fork: the other pipelines start after the clears and the seed upload
+		HIP_TRY(h, hipEventRecord(h->ev_fork, q));
+		for (int p = 1; p < n_pipes; p++) HIP_TRY(h, hipStreamWaitEvent(h->pipe[p].q, h->ev_fork, 0));
+	}
+	uint32_t bi = 0;
+	for (uint32_t s0 = 0; s0 < spp; s0 += K, bi++) {
+		const int p = (int)(bi % (uint32_t)n_pipes), prev = (int)((bi + (uint32_t)n_pipes - 1) % (uint32_t)n_pipes);
+		launch_batch(h, p, r, s0, std::min(K, spp - s0), N, Npad, exact, (n_pipes > 1 && bi > 0) ? h->pipe[prev].done : nullptr);
+	}
+	for (int p = 1; p < n_pipes; p++) HIP_TRY(h, hipStreamWaitEvent(q, h->pipe[p].done, 0)); // join
 	HIP_TRY(h, hipGetLastError());
 	unsigned long long hs[ST_COUNT];
 	HIP_TRY(h, hipMemcpyAsync(hs, h->d_stats, sizeof hs, hipMemcpyDeviceToHost, q));
@@ -595,7 +674,8 @@ int polaris_hip_tap_primary(polaris_hip_tracer *h, const PolarisBlockRequest *r,
 	if (!h->have_camera) return fail(h, POLARIS_E_BAD_ARGUMENT, "camera not set");
 	const uint32_t N = h->W * r->block_h, Npad = (N + WG - 1) / WG * WG;
 	HIP_TRY(h, hipSetDevice(h->device));
-	if (int rc = ensure_streams(h, std::max<size_t>(h->slots, Npad), true)) return rc;
+	if (int rc = ensure_streams(h, 0, std::max<size_t>(h->pipe[0].slots, Npad), true)) return rc;
+	Streams &st0 = h->pipe[0].st;
 	if (h->seeds_cap < 1) {
 		HIP_TRY(h, hipMalloc((void **)&h->d_seeds, 64 * sizeof(uint32_t)));
 		h->seeds_cap = 64;
@@ -603,15 +683,15 @@ int polaris_hip_tap_primary(polaris_hip_tracer *h, const PolarisBlockRequest *r,
 	h->cam.texel = make_float2(1.0f / (float)h->W, 1.0f / (float)h->H);
 	hipStream_t q = h->stream;
 	HIP_TRY(h, hipMemcpyAsync(h->d_seeds, &seed, sizeof seed, hipMemcpyHostToDevice, q));
-	hipLaunchKernelGGL(k_generate, dim3(Npad / WG), dim3(WG), 0, q, h->st, h->cam, h->d_seeds, 1u, 0u, N, Npad, h->W, r->block_y, 1);
-	hipLaunchKernelGGL(k_intersect, dim3(Npad / WG), dim3(WG), 0, q, h->st, h->bvh);
+	hipLaunchKernelGGL(k_generate, dim3(Npad / WG), dim3(WG), 0, q, st0, h->cam, h->d_seeds, 1u, 0u, N, Npad, h->W, r->block_y, 1);
+	hipLaunchKernelGGL(k_intersect, dim3(Npad / WG), dim3(WG), 0, q, st0, h->bvh);
 	HIP_TRY(h, hipGetLastError());
 	std::vector<float4> ro(N), rd(N), ht(N);
 	std::vector<int> inst(N);
-	HIP_TRY(h, hipMemcpyAsync(ro.data(), h->st.ray_o, N * sizeof(float4), hipMemcpyDeviceToHost, q));
-	HIP_TRY(h, hipMemcpyAsync(rd.data(), h->st.ray_d, N * sizeof(float4), hipMemcpyDeviceToHost, q));
-	HIP_TRY(h, hipMemcpyAsync(ht.data(), h->st.hit, N * sizeof(float4), hipMemcpyDeviceToHost, q));
-	HIP_TRY(h, hipMemcpyAsync(inst.data(), h->st.hit_inst, N * sizeof(int), hipMemcpyDeviceToHost, q));
+	HIP_TRY(h, hipMemcpyAsync(ro.data(), st0.ray_o, N * sizeof(float4), hipMemcpyDeviceToHost, q));
+	HIP_TRY(h, hipMemcpyAsync(rd.data(), st0.ray_d, N * sizeof(float4), hipMemcpyDeviceToHost, q));
+	HIP_TRY(h, hipMemcpyAsync(ht.data(), st0.hit, N * sizeof(float4), hipMemcpyDeviceToHost, q));
+	HIP_TRY(h, hipMemcpyAsync(inst.data(), st0.hit_inst, N * sizeof(int), hipMemcpyDeviceToHost, q));
 	HIP_TRY(h, hipStreamSynchronize(q));
 	for (uint32_t i = 0; i < N; i++) {
 		int t;

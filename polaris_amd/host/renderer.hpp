@@ -1,0 +1,76 @@
+// renderer.hpp -- the frame loop of renderer/default.go restated in C++ (no OpenGL, no CLI):
+// one worker thread per tracer, Schedule -> Trace per block -> primary.MergeOutput -> primary
+// SyncFramebuffer.  This is the caller side of the hot path ("next" row f-1 of SURVEY.md 8).
+#pragma once
+
+#include <condition_variable>
+#include <deque>
+#include <thread>
+
+#include "hip_tracer.hpp"
+
+namespace polaris {
+namespace renderer {
+
+struct Options { // renderer/options.go:3-23
+	uint32_t FrameW = 1024, FrameH = 1024;
+	uint32_t SamplesPerPixel = 16;
+	float Exposure = 1.2f;
+	uint32_t NumBounces = 5;
+	uint32_t MinBouncesForRR = 3;
+	std::vector<std::string> BlackListedDevices;
+	std::string ForcePrimaryDevice;
+};
+
+struct TracerStat { // renderer/stats.go
+	std::string Id;
+	bool IsPrimary = false;
+	uint32_t BlockH = 0;
+	float FramePercent = 0.0f;
+	tracer::Duration RenderTime{0};
+};
+struct FrameStats {
+	std::vector<TracerStat> Tracers;
+	tracer::Duration RenderTime{0};
+};
+
+class DefaultRenderer { // renderer/default.go:21-196
+public:
+	// tracers are created by the caller (the seam of INTEGRATION.md section 3) and owned here
+	DefaultRenderer(std::vector<std::unique_ptr<tracer::Tracer>> tracers, size_t primary, std::unique_ptr<tracer::BlockScheduler> scheduler,
+	                Options opts, tracer::hip::SeedSource seeds);
+	~DefaultRenderer();
+	Error UpdateAll(tracer::ChangeType type, const void *data); // the three synchronous UpdateState calls of NewDefault (:70-72)
+	Error Render() { return renderFrame(0); }                  // default.go:101-103
+	Error renderFrame(uint32_t accumulatedSamples);            // default.go:106-171
+	void Close();
+	const FrameStats &Stats() const { return stats_; }
+	const std::vector<uint32_t> &BlockAssignments() const { return blockAssignments_; }
+	tracer::Tracer *Primary() { return tracers_[primary_].get(); }
+	size_t NumTracers() const { return tracers_.size(); }
+
+private:
+	void jobWorker(size_t trIndex); // default.go:174-196
+	struct Channel {
+		std::mutex mu;
+		std::condition_variable cv;
+		std::deque<tracer::BlockRequest> q;
+		bool closed = false;
+	};
+	std::vector<std::unique_ptr<tracer::Tracer>> tracers_;
+	size_t primary_;
+	std::unique_ptr<tracer::BlockScheduler> scheduler_;
+	Options options_;
+	tracer::hip::SeedSource seeds_;
+	std::vector<std::unique_ptr<Channel>> jobChans_;
+	std::vector<std::thread> workers_;
+	std::mutex doneMu_;
+	std::condition_variable doneCv_;
+	std::deque<Error> done_;
+	std::vector<uint32_t> blockAssignments_;
+	FrameStats stats_;
+	bool closed_ = false;
+};
+
+} // namespace renderer
+} // namespace polaris

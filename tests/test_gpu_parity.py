@@ -61,7 +61,10 @@ def test_hip_vs_oracle_exact_and_batched(built, oracle, name):
     W, H, spp, B = 96, 80, 6, 5   # 96 columns: workgroups straddle rows; 7680 rays = 30 workgroups
     seeds = scenes.make_seeds(spp, B, base=1234)
     want, ws, wt = oracle.trace(sc, ob.make_request(W, H, spp=spp, bounces=B), seeds, tap_sample=0)
-    for opts, exact in (({"exact_accumulate": 1}, True), ({}, False), ({"samples_per_batch": 4}, False)):
+    variants = (({"exact_accumulate": 1}, True), ({"exact_accumulate": 1, "traversal": 0}, True), ({}, False),
+                ({"samples_per_batch": 4}, False), ({"samples_per_batch": 1, "overlap": 3}, False),
+                ({"samples_per_batch": 2, "overlap": 1, "traversal": 0}, False))
+    for opts, exact in variants:
         tr = make_hip_tracer(sc, W, H, **opts)
         try:
             req = ob.make_request(W, H, spp=spp, bounces=B)
