@@ -36,8 +36,11 @@ struct PairNode { float4 lo0, hi0, lo1, hi1; };  // .w of lo0/lo1 carry the chil
 struct TriRec { float4 v0, e1, e2; };             // v0.w carries the DFS rank (uint bits)
 struct InstRec { float4 r0, r1, r2; int4 meta; }; // meta.x = root ref, meta.y = rank
 
+constexpr int kLdsTopNodes = 128; // pair records (8 KB) of the top of the tree staged in LDS per workgroup
+
 struct BvhDev {
-	const PairNode *pairs;
+	const PairNode *pairs; // inner nodes in breadth-first order
+	uint32_t num_pairs;
 	const int2 *leaves;
 	const TriRec *tris;
 	const InstRec *insts;
@@ -53,7 +56,7 @@ struct Streams {
 };
 
 // device-side counters of one Trace call (mirrors PolarisTraceStats, all uint64)
-enum StatSlot { ST_SHADED_HITS = 0, ST_SHADED_MISSES, ST_EMITTER_HITS, ST_UNOCCLUDED, ST_RAYS_BOUNCE, ST_OCCL_BOUNCE = ST_RAYS_BOUNCE + POLARIS_MAX_BOUNCES, ST_COUNT = ST_OCCL_BOUNCE + POLARIS_MAX_BOUNCES };
+enum StatSlot { ST_SHADED_HITS = 0, ST_SHADED_MISSES, ST_EMITTER_HITS, ST_UNOCCLUDED, ST_RAYS_BOUNCE, ST_OCCL_BOUNCE = ST_RAYS_BOUNCE + POLARIS_MAX_BOUNCES, ST_DEBUG = ST_OCCL_BOUNCE + POLARIS_MAX_BOUNCES, ST_COUNT = ST_DEBUG + 16 };
 
 __device__ __forceinline__ int fbits(float f) { return __float_as_int(f); }
 __device__ __forceinline__ float ibits(int i) { return __int_as_float(i); }
@@ -249,6 +252,10 @@ __global__ __launch_bounds__(WG) void k_occlusion(Streams st, BvhDev B, float4 *
 #define POLARIS_REFILL_MIN 48
 #endif
 constexpr int kRefillMin = POLARIS_REFILL_MIN;
+#ifndef POLARIS_STRAGGLERS
+#define POLARIS_STRAGGLERS 8
+#endif
+constexpr int kStragglers = POLARIS_STRAGGLERS;
 
 __device__ __forceinline__ float slab_entry_hw(float4 lo, float4 hi, f3 o, f3 inv, float maxDist) {
 	// identical to slab_entry except that min/max are the hardware's IEEE minNum/maxNum
@@ -271,7 +278,13 @@ __global__ __launch_bounds__(WG) void k_trace(Streams st, BvhDev B, uint32_t num
                                               unsigned long long *stats) {
 	__shared__ int stk[STACK][WG]; // STACK = smallest of {16, 24, 32} that fits the scene: LDS per wave sets the occupancy
 	__shared__ uint32_t wg_cursor;
+	__shared__ float4 top[kLdsTopNodes * 4]; // first kLdsTopNodes PairNodes (breadth-first = the hot top of the tree)
 	if (threadIdx.x == 0) wg_cursor = 0;
+	{
+		const uint32_t n4 = min((uint32_t)kLdsTopNodes, B.num_pairs) * 4;
+		const float4 *src = reinterpret_cast<const float4 *>(B.pairs);
+		for (uint32_t i = threadIdx.x; i < n4; i += WG) top[i] = src[i];
+	}
 	__syncthreads();
 	(void)ticket;
 	const int tid = threadIdx.x;
@@ -321,10 +334,18 @@ __global__ __launch_bounds__(WG) void k_trace(Streams st, BvhDev B, uint32_t num
 		}
 	};
 
+#ifdef POLARIS_TRACE_COUNTERS
+	uint32_t c_node = 0, c_leaf = 0, c_tri = 0, c_iter1 = 0, c_iter2 = 0, c_outer = 0, c_refill = 0, c_triiter = 0;
+#define TC(x) x
+#else
+#define TC(x)
+#endif
 	for (;;) {
+		TC(c_outer++;)
 		// ---- refill idle lanes ---------------------------------------------------------------
 		unsigned long long freem = __ballot(!has);
 		if (!drained && (freem == ~0ull || __popcll(freem) >= kRefillMin)) {
+			TC(c_refill++;)
 			for (;;) {
 				if (off >= cnt) {
 					uint32_t c = 0;
@@ -362,8 +383,18 @@ __global__ __launch_bounds__(WG) void k_trace(Streams st, BvhDev B, uint32_t num
 			continue;
 		}
 		// ---- phase 1: descend through inner nodes -----------------------------------------------
-		while (has && cur >= 0) {
-			const PairNode P = B.pairs[cur];
+		// (the loop is left early once fewer than kStragglers lanes are still descending: they
+		// continue in the next round, packed together with the lanes that come back from their
+		// leaves, instead of dragging the whole wave through sparsely populated iterations)
+		for (int it1 = 0;; it1++) {
+			const bool descending = has && cur >= 0;
+			const int nd = __popcll(__ballot(descending));
+			if (nd == 0 || (it1 > 0 && nd < kStragglers)) break;
+			if (!descending) continue;
+			TC(c_node++; if (lane == __ffsll((long long)__ballot(true)) - 1) c_iter1++;)
+			PairNode P;
+			if (cur < kLdsTopNodes) { P.lo0 = top[4 * cur]; P.hi0 = top[4 * cur + 1]; P.lo1 = top[4 * cur + 2]; P.hi1 = top[4 * cur + 3]; }
+			else P = B.pairs[cur];
 			float t0 = slab_entry_hw(P.lo0, P.hi0, o, inv, maxDist);
 			float t1 = slab_entry_hw(P.lo1, P.hi1, o, inv, maxDist);
 			if (!ANY_HIT) {
@@ -384,7 +415,8 @@ __global__ __launch_bounds__(WG) void k_trace(Streams st, BvhDev B, uint32_t num
 			}
 		}
 		// ---- phase 2: leaves ---------------------------------------------------------------------
-		if (has) {
+		if (has && cur < 0) {
+			TC(c_leaf++; if (lane == __ffsll((long long)__ballot(true)) - 1) c_iter2++;)
 			const int2 li = B.leaves[~cur];
 			if (li.y == 0) { // top-level leaf: enter the instance
 				inst = -li.x;
@@ -402,6 +434,7 @@ __global__ __launch_bounds__(WG) void k_trace(Streams st, BvhDev B, uint32_t num
 				const int first = -li.x;
 				bool occluded = false;
 				for (int t = first; t < first + li.y; t++) {
+					TC(c_tri++; if (lane == __ffsll((long long)__ballot(true)) - 1) c_triiter++;)
 					const TriRec T = B.tris[t];
 					f3 e1 = xyz(T.e1), e2 = xyz(T.e2);
 					f3 pv = cross(d, e2);
@@ -429,6 +462,17 @@ __global__ __launch_bounds__(WG) void k_trace(Streams st, BvhDev B, uint32_t num
 			}
 		}
 	}
+#ifdef POLARIS_TRACE_COUNTERS
+	{
+		uint32_t v[8] = {c_node, c_leaf, c_tri, c_iter1, c_iter2, c_outer, c_refill, c_triiter};
+		for (int i = 0; i < 8; i++) {
+			uint32_t x = v[i];
+			if (i == 5 || i == 6) { if (lane != 0) x = 0; }
+			for (int s = 32; s > 0; s >>= 1) x += __shfl_xor(x, s);
+			if (lane == 0 && x) atomicAdd(&stats[ST_DEBUG + (ANY_HIT ? 8 : 0) + i], (unsigned long long)x);
+		}
+	}
+#endif
 	if (ANY_HIT) {
 		// wave-level sum of the per-lane unoccluded counts, one atomic per wave
 		uint32_t v = unocc;
@@ -607,6 +651,258 @@ __global__ __launch_bounds__(WG) void k_shade(Streams st, SceneDev S, ShadeArgs 
 		st.occ_o[d] = n_oo; st.occ_d[d] = n_od; st.occ_e[d] = n_oe;
 	}
 	__syncthreads();
+	if (tid == 0) {
+		st.cnt_ray[blockIdx.x] = tot_ind;
+		st.cnt_occ[blockIdx.x] = tot_occ;
+		if (blk_stats[0]) atomicAdd(&stats[ST_SHADED_HITS], (unsigned long long)blk_stats[0]);
+		if (blk_stats[1]) atomicAdd(&stats[ST_SHADED_MISSES], (unsigned long long)blk_stats[1]);
+		if (blk_stats[2]) atomicAdd(&stats[ST_EMITTER_HITS], (unsigned long long)blk_stats[2]);
+	}
+}
+
+// ------------------------------------------------------------------------------------------
+// k_shade_sorted: the same shading as k_shade, re-scheduled inside the workgroup.
+//
+// PMC counters put k_shade at ~31 % live lanes per VALU instruction.  The cause is not empty
+// slots but the 5-way BxDF switch: at bounce >= 1 the 64 rays of a wave land on walls, glass, the
+// metal/diffuse mix ... and the wave executes every family's sample + pdf + eval code in turn.
+// Here a workgroup shades in two phases with an LDS exchange in between:
+//   phase A (one lane per live ray, stream order): PRNG draws, surface interpolation, material
+//           tree walk, miss / emitter accumulation, Russian roulette.  Survivors are compacted
+//           (stable) to dense indices j and their state goes to LDS.
+//   sort    counting sort of the survivors by BxDF family (LDS atomics) -> k
+//   phase B (lane k): BxDF sample, light sample, MIS, NEE -- waves are now family-homogeneous.
+//   write   emit flags go back to LDS under the DENSE STREAM-ORDER index j, ranks are computed in
+//           j order (== original ray order, the compaction was stable) and lane k writes its rays
+//           at those ranks: the output streams are byte-identical to k_shade's.
+// ------------------------------------------------------------------------------------------
+constexpr int kShadeState = 27; // dwords of phase A -> phase B state per survivor
+
+__global__ __launch_bounds__(WG) void k_shade_sorted(Streams st, SceneDev S, ShadeArgs A, unsigned long long *stats) {
+	__shared__ uint32_t xs[kShadeState][WG];      // survivor state, one column per dense index j
+	__shared__ uint16_t s2j[WG];                  // sorted slot k -> dense index j
+	__shared__ uint16_t rank_ind[WG], rank_occ[WG];
+	__shared__ uint8_t flag_ind[WG], flag_occ[WG];
+	__shared__ uint32_t wave_a[4], wave_b[4], wave_c[4];
+	__shared__ uint32_t cls_count[8], cls_cursor[8];
+	__shared__ uint32_t blk_stats[3];
+	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const uint32_t cnt = st.cnt_ray[blockIdx.x];
+	if (cnt == 0) {
+		if (tid == 0) st.cnt_occ[blockIdx.x] = 0;
+		return;
+	}
+	if (tid < 3) blk_stats[tid] = 0;
+	if (tid < 8) { cls_count[tid] = 0; cls_cursor[tid] = 0; }
+	const uint32_t wgs_per_sample = A.Npad / WG;
+	const uint32_t s = blockIdx.x / wgs_per_sample;
+	const size_t base = (size_t)blockIdx.x * WG;
+	const unsigned long long below = (1ull << lane) - 1ull;
+	__syncthreads();
+
+	// ---------------------------------------------------------------- phase A
+	bool survive = false;
+	uint32_t cls = 0;
+	uint32_t n_hit = 0, n_miss = 0, n_emit = 0;
+	// survivor state (registers until the dense index is known)
+	f3 a_in = {0, 0, 0}, a_thr = {0, 0, 0}, a_tint = {1, 1, 1};
+	Surf a_sf = {{0, 0, 0}, {0, 0, 0}, {0, 0}};
+	f2 a_s0 = {0, 0}, a_s1 = {0, 0};
+	uint32_t a_node = 0, a_type = 0, a_pword = 0, a_cell = 0;
+	float a_iior = 0, a_eior = 0;
+	if (tid < cnt) {
+		const size_t slot = base + tid;
+		const float4 d4 = st.ray_d[slot];
+		const float4 t4 = st.thr[slot];
+		const float4 h4 = st.hit[slot];
+		const uint32_t pword = (uint32_t)fbits(d4.w);
+		const uint32_t path_index = pword & 0xFFFFFFu;
+		uint32_t flags = pword >> 24;
+		const uint32_t pixel_index = A.blockY * A.W + path_index;
+		const uint32_t cell = A.exact ? pixel_index : (uint32_t)(s * A.Npad + path_index);
+		f3 thr = xyz(t4);
+		const int tri = fbits(h4.w);
+		if (tri < 0) {
+			if (S.bg_node >= 0) {
+				const PolarisMaterialNode *bg = S.nodes + S.bg_node;
+				f2 uv = latlong_uv(xyz(d4));
+				f3 kd = mat_color(uv, bg->k, bg->tex, S);
+				f3 add = A.bounce == 0 ? kd : thr * kd;
+				float4 a = A.acc[cell];
+				a.x += add.x; a.y += add.y; a.z += add.z;
+				A.acc[cell] = a;
+				n_miss = 1;
+			}
+		} else {
+			n_hit = 1;
+			Rng rng = {A.seeds[(size_t)(A.first_sample + s) * A.seed_stride + 1 + A.bounce], st.pfx[blockIdx.x] + tid};
+			const f2 sample0 = rng_next(rng), sample1 = rng_next(rng), sample2 = rng_next(rng);
+			const f3 in_dir = -xyz(d4);
+			const float bu = h4.x, bv = h4.y, bw = 1.0f - (bu + bv);
+			const uint32_t off = (uint32_t)tri * 3;
+			Surf sf;
+			{
+				float4 a = S.vertices[off], b = S.vertices[off + 1], c = S.vertices[off + 2];
+				sf.p = mk3(bw * a.x + bu * b.x + bv * c.x, bw * a.y + bu * b.y + bv * c.y, bw * a.z + bu * b.z + bv * c.z);
+				a = S.normals[off]; b = S.normals[off + 1]; c = S.normals[off + 2];
+				sf.n = normalize(mk3(bw * a.x + bu * b.x + bv * c.x, bw * a.y + bu * b.y + bv * c.y, bw * a.z + bu * b.z + bv * c.z));
+				float2 ua = S.uvs[off], ub = S.uvs[off + 1], uc = S.uvs[off + 2];
+				sf.uv = {bw * ua.x + bu * ub.x + bv * uc.x, bw * ua.y + bu * ub.y + bv * uc.y};
+			}
+			f3 tint = splat(1.0f);
+			const Mat m = select_material(S.mat_index[tri], sf, flags, tint, rng, S);
+			const float in_dot_n = dot(in_dir, sf.n);
+			if (m.type == POLARIS_BXDF_EMISSIVE) {
+				if (in_dot_n > 0.0f) {
+					f3 add = thr * m.nd->scale * mat_color(sf.uv, m.nd->k, m.nd->tex, S);
+					float4 a = A.acc[cell];
+					a.x += add.x; a.y += add.y; a.z += add.z;
+					A.acc[cell] = a;
+					n_emit = 1;
+				}
+			} else {
+				bool reject = m.type == POLARIS_BXDF_INVALID;
+				if (A.bounce >= A.min_rr) {
+					float p = pm_max(pm_min(0.5f, 0.2126f * thr.x + 0.7152f * thr.y + 0.0722f * thr.z), 0.01f);
+					if (p < sample2.x) reject = true;
+					else thr = thr / p;
+				}
+				if (!reject) {
+					survive = true;
+					cls = m.type == POLARIS_BXDF_DIFFUSE ? 0u : (m.type == POLARIS_BXDF_CONDUCTOR ? 1u : (m.type == POLARIS_BXDF_ROUGH_CONDUCTOR ? 2u : (m.type == POLARIS_BXDF_DIELECTRIC ? 3u : 4u)));
+					a_in = in_dir; a_thr = thr; a_tint = tint; a_sf = sf; a_s0 = sample0; a_s1 = sample1;
+					a_node = (uint32_t)(m.nd - S.nodes); a_type = m.type; a_iior = m.int_ior; a_eior = m.ext_ior;
+					a_pword = path_index | (flags << 24); a_cell = cell;
+				}
+			}
+		}
+	}
+	// stable compaction of the survivors -> dense stream-order index j
+	const unsigned long long m_sv = __ballot(survive);
+	if (lane == 0) wave_a[wave] = __popcll(m_sv);
+	const unsigned long long mh = __ballot(n_hit != 0), mm = __ballot(n_miss != 0), me = __ballot(n_emit != 0);
+	if (lane == 0) {
+		if (mh) atomicAdd(&blk_stats[0], (uint32_t)__popcll(mh));
+		if (mm) atomicAdd(&blk_stats[1], (uint32_t)__popcll(mm));
+		if (me) atomicAdd(&blk_stats[2], (uint32_t)__popcll(me));
+	}
+	__syncthreads(); // (also: every stream load of the workgroup is done before any in-place store below)
+	uint32_t jbase = 0, S_total = 0;
+#pragma unroll
+	for (int w = 0; w < 4; w++) { if (w < (int)wave) jbase += wave_a[w]; S_total += wave_a[w]; }
+	if (survive) {
+		const uint32_t j = jbase + __popcll(m_sv & below);
+		xs[0][j] = fbits(a_in.x); xs[1][j] = fbits(a_in.y); xs[2][j] = fbits(a_in.z);
+		xs[3][j] = fbits(a_thr.x); xs[4][j] = fbits(a_thr.y); xs[5][j] = fbits(a_thr.z);
+		xs[6][j] = fbits(a_sf.p.x); xs[7][j] = fbits(a_sf.p.y); xs[8][j] = fbits(a_sf.p.z);
+		xs[9][j] = fbits(a_sf.n.x); xs[10][j] = fbits(a_sf.n.y); xs[11][j] = fbits(a_sf.n.z);
+		xs[12][j] = fbits(a_sf.uv.x); xs[13][j] = fbits(a_sf.uv.y);
+		xs[14][j] = fbits(a_tint.x); xs[15][j] = fbits(a_tint.y); xs[16][j] = fbits(a_tint.z);
+		xs[17][j] = fbits(a_s0.x); xs[18][j] = fbits(a_s0.y); xs[19][j] = fbits(a_s1.x); xs[20][j] = fbits(a_s1.y);
+		xs[21][j] = a_node; xs[22][j] = a_type; xs[23][j] = fbits(a_iior); xs[24][j] = fbits(a_eior);
+		xs[25][j] = a_pword; xs[26][j] = a_cell;
+		atomicAdd(&cls_count[cls], 1u);
+		a_node = j; // keep j in a register for the scatter below
+	}
+	__syncthreads();
+	if (survive) { // counting sort by BxDF family (order inside a family is irrelevant)
+		uint32_t cb = 0;
+#pragma unroll
+		for (uint32_t c = 0; c < 5; c++) if (c < cls) cb += cls_count[c];
+		const uint32_t k = cb + atomicAdd(&cls_cursor[cls], 1u);
+		s2j[k] = (uint16_t)a_node;
+	}
+	__syncthreads();
+
+	// ---------------------------------------------------------------- phase B
+	bool emit_ind = false, emit_occ = false;
+	float4 n_ro, n_rd, n_thr, n_oo, n_od, n_oe;
+	uint32_t j = 0;
+	if (tid < S_total) {
+		j = s2j[tid];
+		const f3 in_dir = mk3(ibits(xs[0][j]), ibits(xs[1][j]), ibits(xs[2][j]));
+		const f3 thr = mk3(ibits(xs[3][j]), ibits(xs[4][j]), ibits(xs[5][j]));
+		Surf sf;
+		sf.p = mk3(ibits(xs[6][j]), ibits(xs[7][j]), ibits(xs[8][j]));
+		sf.n = mk3(ibits(xs[9][j]), ibits(xs[10][j]), ibits(xs[11][j]));
+		sf.uv = {ibits(xs[12][j]), ibits(xs[13][j])};
+		const f3 tint = mk3(ibits(xs[14][j]), ibits(xs[15][j]), ibits(xs[16][j]));
+		const f2 sample0 = {ibits(xs[17][j]), ibits(xs[18][j])}, sample1 = {ibits(xs[19][j]), ibits(xs[20][j])};
+		const Mat m = {S.nodes + xs[21][j], xs[22][j], ibits(xs[23][j]), ibits(xs[24][j])};
+		const uint32_t pword = xs[25][j], cell = xs[26][j];
+
+		f3 out_dir = splat(0.0f);
+		float bxdf_pdf = 1.0f, bxdf_weight = 1.0f;
+		const f3 bxdf_val = bxdf_sample(sf, m, S, sample0, in_dir, out_dir, bxdf_pdf);
+		const float displace = pm_sign(dot(sf.n, out_dir));
+		const f3 ind_origin = sf.p + (sf.n * displace) * kEps;
+		const f3 occ_origin = sf.p + sf.n * kEps;
+		f3 e_dir = splat(0.0f), e_rad = splat(0.0f);
+		float e_pdf = 0.0f, sel_pdf = 0.0f, e_weight = 0.0f, e_dist = 0.0f;
+		const PolarisEmissive *em = nullptr;
+		if (S.num_emissives > 0) {
+			sel_pdf = pm_rcp((float)(int)S.num_emissives);
+			const int ei = pm_clampi((int)(sample1.x * (int)S.num_emissives), 0, (int)S.num_emissives - 1);
+			em = S.emissives + ei;
+			const LightSample L = light_sample(sf, em, S, sample1);
+			e_dir = L.dir; e_rad = L.radiance; e_pdf = L.pdf; e_dist = L.dist;
+		}
+		const float n_dot_e = pm_max(0.0f, dot(sf.n, e_dir));
+		const bool want_nee = maxcomp(e_rad) > 0.0f && e_pdf > 0.0f && n_dot_e > 0.0f;
+		if (em) {
+			float bxdf_e_pdf;
+			f3 bxdf_e_val;
+			bxdf_pdf_eval(sf, m, S, in_dir, e_dir, want_nee, bxdf_e_pdf, bxdf_e_val);
+			e_weight = (e_pdf * e_pdf) / (e_pdf * e_pdf + bxdf_e_pdf * bxdf_e_pdf);
+			const float e_bxdf_pdf = light_pdf(sf, em, S, out_dir);
+			bxdf_weight = (bxdf_pdf * bxdf_pdf) / (bxdf_pdf * bxdf_pdf + e_bxdf_pdf * e_bxdf_pdf);
+			if (want_nee) {
+				e_rad = e_rad * (e_weight * bxdf_e_val * thr * n_dot_e / (e_pdf * sel_pdf));
+				if (maxcomp(e_rad) > 0.0f) {
+					emit_occ = true;
+					n_oo = make_float4(occ_origin.x, occ_origin.y, occ_origin.z, e_dist - kLightEps);
+					n_od = make_float4(e_dir.x, e_dir.y, e_dir.z, ibits((int)cell));
+					n_oe = make_float4(e_rad.x, e_rad.y, e_rad.z, 0.0f);
+				}
+			}
+		}
+		if ((m.type & (POLARIS_BXDF_CONDUCTOR | POLARIS_BXDF_DIELECTRIC)) != 0) bxdf_weight = 1.0f;
+		const f3 tp = bxdf_weight * bxdf_val * tint * pm_fabs(dot(sf.n, out_dir));
+		if (maxcomp(tp) > 0.0f && bxdf_pdf > 0.0f && !A.last_bounce) {
+			const f3 nt = thr * tp / bxdf_pdf;
+			emit_ind = true;
+			n_ro = make_float4(ind_origin.x, ind_origin.y, ind_origin.z, kFltMax);
+			n_rd = make_float4(out_dir.x, out_dir.y, out_dir.z, ibits((int)pword));
+			n_thr = make_float4(nt.x, nt.y, nt.z, 0.0f);
+		}
+		flag_ind[j] = emit_ind ? 1 : 0;
+		flag_occ[j] = emit_occ ? 1 : 0;
+	}
+	__syncthreads();
+	// ranks in dense stream order j (thread t plays j = t)
+	const bool fi = tid < S_total && flag_ind[tid] != 0, fo = tid < S_total && flag_occ[tid] != 0;
+	const unsigned long long m_ind = __ballot(fi), m_occ = __ballot(fo);
+	if (lane == 0) { wave_b[wave] = __popcll(m_ind); wave_c[wave] = __popcll(m_occ); }
+	__syncthreads();
+	uint32_t b_ind = 0, b_occ = 0, tot_ind = 0, tot_occ = 0;
+#pragma unroll
+	for (int w = 0; w < 4; w++) {
+		if (w < (int)wave) { b_ind += wave_b[w]; b_occ += wave_c[w]; }
+		tot_ind += wave_b[w]; tot_occ += wave_c[w];
+	}
+	if (tid < S_total) {
+		rank_ind[tid] = (uint16_t)(b_ind + __popcll(m_ind & below));
+		rank_occ[tid] = (uint16_t)(b_occ + __popcll(m_occ & below));
+	}
+	__syncthreads();
+	if (emit_ind) {
+		const size_t d = base + rank_ind[j];
+		st.ray_o[d] = n_ro; st.ray_d[d] = n_rd; st.thr[d] = n_thr;
+	}
+	if (emit_occ) {
+		const size_t d = base + rank_occ[j];
+		st.occ_o[d] = n_oo; st.occ_d[d] = n_od; st.occ_e[d] = n_oe;
+	}
 	if (tid == 0) {
 		st.cnt_ray[blockIdx.x] = tot_ind;
 		st.cnt_occ[blockIdx.x] = tot_occ;

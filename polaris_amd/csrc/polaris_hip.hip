@@ -84,6 +84,7 @@ struct polaris_hip_tracer {
 	int opt_packet_primary = 0;
 	int opt_time_kernels = 0;
 	int opt_trace_wgs_per_cu = 0; // 0 = auto (what the LDS stack admits)
+	int opt_shade_sorted = 0; // 1 = two-phase shade with an LDS sort by BxDF family (measured: no gain), 0 = straight through
 	int opt_traversal = 1; // 1 = persistent waves with lane refill (k_trace), 0 = one ray per lane (k_intersect/k_occlusion)
 
 	// per-kernel timing (option time_kernels)
@@ -261,7 +262,10 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 		A.last_bounce = (b + 1 == B) ? 1 : 0;
 		{
 			Timed t(h, "shade", q);
-			hipLaunchKernelGGL(k_shade, dim3(wgs), dim3(WG), 0, q, P.st, h->scene, A, h->d_stats);
+			if (h->opt_shade_sorted)
+				hipLaunchKernelGGL(k_shade_sorted, dim3(wgs), dim3(WG), 0, q, P.st, h->scene, A, h->d_stats);
+			else
+				hipLaunchKernelGGL(k_shade, dim3(wgs), dim3(WG), 0, q, P.st, h->scene, A, h->d_stats);
 		}
 		{
 			Timed t(h, "scan", q);
@@ -432,7 +436,7 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 	rc |= dev_upload(h, h->scene_bufs, &tex_data, sc->texture_data, sc->texture_data_bytes);
 	if (rc) { free_pool(h->scene_bufs); return rc; }
 	HIP_TRY(h, hipStreamSynchronize(h->stream)); // host vectors in L die at return
-	h->bvh = BvhDev{pairs, leaves, tris, insts, L.root_ref};
+	h->bvh = BvhDev{pairs, (uint32_t)L.pairs.size(), leaves, tris, insts, L.root_ref};
 	h->scene = SceneDev{vertices, normals, uvs, mat_index, nodes, emissives, tex_meta, tex_data, sc->num_emissives,
 	                    sc->scene_diffuse_mat_index};
 	h->max_stack = L.max_stack;
@@ -463,6 +467,7 @@ int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value
 	else if (k == "packet_primary") h->opt_packet_primary = value != 0;
 	else if (k == "time_kernels") h->opt_time_kernels = value != 0;
 	else if (k == "traversal") h->opt_traversal = value != 0;
+	else if (k == "shade_sorted") h->opt_shade_sorted = value != 0;
 	else if (k == "overlap") h->opt_overlap = (int)std::max<int64_t>(1, std::min<int64_t>(value, polaris_hip_tracer::kMaxPipes));
 	else if (k == "trace_wgs_per_cu") h->opt_trace_wgs_per_cu = (int)std::max<int64_t>(0, std::min<int64_t>(value, 64));
 	else return fail(h, POLARIS_E_BAD_ARGUMENT, "unknown option '%s'", key);
@@ -555,6 +560,11 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 		float ms = 0.0f;
 		(void)hipEventElapsedTime(&ms, h->ev_start, h->ev_stop);
 		stats->device_ms = ms;
+#ifdef POLARIS_TRACE_COUNTERS
+		static const char *names[8] = {"node_tests", "leaf_visits", "tri_tests", "wave_iters_inner", "wave_iters_leaf", "wave_outer", "wave_refills", "wave_iters_tri"};
+		for (int a = 0; a < 2; a++)
+			for (int i = 0; i < 8; i++) fprintf(stderr, "[trace %s] %s = %llu\n", a ? "anyhit" : "closest", names[i], hs[ST_DEBUG + 8 * a + i]);
+#endif
 	}
 	return POLARIS_OK;
 }

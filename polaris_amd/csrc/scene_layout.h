@@ -39,7 +39,7 @@ static_assert(sizeof(PairNodeH) == 64 && sizeof(TriH) == 48 && sizeof(InstH) == 
 constexpr int kTraversalStack = 32; // entries per ray, == BVH_MAX_STACK_SIZE (intersect.cl:4)
 
 struct SceneLayout {
-	std::vector<PairNodeH> pairs;   // indexed by node id (only inner nodes meaningful)
+	std::vector<PairNodeH> pairs;   // inner nodes only, in breadth-first order (the first kLdsTopNodes are staged in LDS)
 	std::vector<LeafInfoH> leaves;  // indexed by node id (only leaves meaningful)
 	std::vector<TriH> tris;
 	std::vector<InstH> insts;
@@ -188,6 +188,54 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out) {
 	if (out.max_stack > kTraversalStack)
 		return "BVH needs a traversal stack of " + std::to_string(out.max_stack) + " entries; the kernel (like the reference, "
 		       "intersect.cl:4) has " + std::to_string(kTraversalStack);
+
+	// ---- renumber inner nodes breadth-first ----------------------------------------------------
+	// The traversal kernels keep the first kLdsTopNodes pair records in LDS: every ray walks the top
+	// of the tree, so those fetches come from LDS (broadcast when lanes agree) instead of 64
+	// per-lane L1 gathers.  BFS continues through an instance leaf into the mesh BVH while the scene
+	// has few instances (a single-mesh scene's hot nodes are the top of that mesh's tree).
+	{
+		std::vector<int32_t> new_id(NN, -1);
+		std::vector<int32_t> order;
+		order.reserve(NN);
+		auto visit = [&](int32_t root) {
+			size_t head = order.size();
+			if (is_leaf(sc.bvh_nodes[root]) || new_id[root] >= 0) return;
+			new_id[root] = (int32_t)order.size();
+			order.push_back(root);
+			while (head < order.size()) {
+				const PolarisBvhNode &n = sc.bvh_nodes[order[head++]];
+				const int32_t kids[2] = {n.ldata, n.rdata};
+				for (int32_t c : kids) {
+					const PolarisBvhNode &cn = sc.bvh_nodes[c];
+					int32_t next = c;
+					if (is_leaf(cn)) {
+						if (cn.rdata != 0 || NI > 16) continue;
+						next = (int32_t)sc.mesh_instances[(uint32_t)(-(int64_t)cn.ldata)].bvh_root; // into the instance
+						if (is_leaf(sc.bvh_nodes[next])) continue;
+					}
+					if (new_id[next] < 0) {
+						new_id[next] = (int32_t)order.size();
+						order.push_back(next);
+					}
+				}
+			}
+		};
+		visit(0);
+		for (uint32_t i = 0; i < NI; i++) visit((int32_t)sc.mesh_instances[i].bvh_root);
+		auto remap = [&](int32_t ref) { return ref >= 0 ? new_id[ref] : ref; };
+		std::vector<PairNodeH> compact(order.size());
+		for (size_t k = 0; k < order.size(); k++) {
+			PairNodeH p = out.pairs[order[k]];
+			p.ref0 = remap(p.ref0);
+			p.ref1 = remap(p.ref1);
+			compact[k] = p;
+		}
+		out.pairs.swap(compact);
+		if (out.pairs.empty()) out.pairs.push_back(PairNodeH{}); // never an empty device array
+		out.root_ref = remap(out.root_ref);
+		for (uint32_t i = 0; i < NI; i++) out.insts[i].root_ref = remap(out.insts[i].root_ref);
+	}
 
 	for (uint32_t t = 0; t < NT; t++) {
 		const float *v0 = sc.vertices + 4 * (size_t)(3 * t), *v1 = v0 + 4, *v2 = v0 + 8;

@@ -63,7 +63,8 @@ def test_hip_vs_oracle_exact_and_batched(built, oracle, name):
     want, ws, wt = oracle.trace(sc, ob.make_request(W, H, spp=spp, bounces=B), seeds, tap_sample=0)
     variants = (({"exact_accumulate": 1}, True), ({"exact_accumulate": 1, "traversal": 0}, True), ({}, False),
                 ({"samples_per_batch": 4}, False), ({"samples_per_batch": 1, "overlap": 3}, False),
-                ({"samples_per_batch": 2, "overlap": 1, "traversal": 0}, False))
+                ({"samples_per_batch": 2, "overlap": 1, "traversal": 0}, False),
+                ({"exact_accumulate": 1, "shade_sorted": 1}, True), ({"shade_sorted": 1, "samples_per_batch": 3}, False))
     for opts, exact in variants:
         tr = make_hip_tracer(sc, W, H, **opts)
         try:
