@@ -206,25 +206,39 @@ def main() -> None:
                        "frame": [W, H], "spp": spp, "bounces": B, "rays_per_frame": rays // args.steps,
                        "paths_per_s": W * H * spp * args.steps / elapsed},
         }
-        # ---- roofline of the dominant kernel (rank 0's kernels; every rank runs the same mix) ----
+        # ---- roofline of the dominant kernel ---------------------------------------------------
+        # Kernel durations come from HIP events on the tracer's own streams (the library brackets
+        # every launch when time_kernels=1).  In the timed region up to four batches are in flight
+        # on separate streams, so a kernel's event time there includes the time it shares the GPU
+        # with other kernels; the roofline therefore uses one extra frame traced with overlap=1
+        # (same kernels, same inputs, one batch at a time), reported next to the overlapped times.
         if kt:
-            # rank 0's own counters for rank 0's kernel times
-            mine = {k: totals[k] for k in totals}
+            mine = {k: totals[k] // args.steps for k in totals}     # per-frame counters of rank 0
+            tr.set_option("overlap", 1)
+            frame(False)
+            iso = {name: tr.kernel_ms(name) for name in ("generate", "intersect", "shade", "scan", "occlusion", "resolve")}
             alg = kernel_algorithmic_bytes(mine)
-            dom = max(("generate", "intersect", "shade", "occlusion"), key=lambda k: kt[k][0])
-            ms, n = kt[dom]
+            dom = max(("generate", "intersect", "shade", "occlusion"), key=lambda k: iso[k][0])
+            ms, n = iso[dom]
             achieved = alg[dom] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+            if os.path.exists(tpath) and (W, H, spp, B, args.scene) == (512, 512, 128, 5, "cornell"):
+                kn = {"intersect": "pol::k_trace<false, 16>", "occlusion": "pol::k_trace<true, 16>", "shade": "pol::k_shade",
+                      "generate": "pol::k_generate"}[dom]
+                tk = json.load(open(tpath))["kernels"].get(kn)
+                if tk:
+                    traffic = tk["hbm_bytes_per_launch"]    # PMC (FETCH_SIZE x2 + WRITE_SIZE), scripts/traffic.sh
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                               "algorithmic_bytes_per_launch": alg[dom] / max(n, 1), "avg_launch_ms": ms / max(n, 1),
-                               "launches": n}
-            out["kernels"] = {k: {"ms": round(v[0], 3), "launches": v[1],
-                                  "GBps_algorithmic": (round(alg[k] / (v[0] * 1e-3) / 1e9, 2) if v[0] > 0 and k in alg else None)}
-                              for k, v in kt.items()}
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "algorithmic_bytes_per_launch": alg[dom] / max(n, 1), "avg_launch_ms": ms / max(n, 1), "launches": n,
+                               "measured": "HIP events, one extra frame with overlap=1 after the timed region"}
+            out["kernels_isolated_ms_per_frame"] = {k: round(v[0], 3) for k, v in iso.items()}
+            out["kernels_isolated_GBps_algorithmic"] = {k: round(alg[k] / (iso[k][0] * 1e-3) / 1e9, 1) for k in alg if iso[k][0] > 0}
+            out["kernels_timed_region_ms"] = {k: round(v[0], 3) for k, v in kt.items()}
             whole = (112 * mine["primary_rays"] + 68 * mine["shaded_hits"] + 92 * mine["indirect_rays"] + 80 * mine["occlusion_rays"]
-                     + 44 * mine["unoccluded"] + 60 * mine["shaded_misses"] + 24 * mine["emitter_hits"]
-                     + (48 + 16) * rows[0] * W * args.steps)
-            out["whole_path_algorithmic_GBps_rank0"] = whole / elapsed / 1e9
+                     + 44 * mine["unoccluded"] + 60 * mine["shaded_misses"] + 24 * mine["emitter_hits"] + (48 + 16) * rows[0] * W)
+            out["whole_path_algorithmic_GBps_rank0"] = whole / (elapsed / args.steps) / 1e9
         # ---- CPU baseline: the oracle (checker) on a bounded sample of the same workload ----
         if not args.no_cpu_baseline and world == 1:
             try:

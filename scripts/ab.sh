@@ -6,7 +6,7 @@ for spec in "$@"; do
   python bench.py --steps 3 --warmup 1 --no-cpu-baseline $args 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
-k=d.get('kernels',{})
+k={n:{'ms':v*d['steps']} for n,v in d.get('kernels_isolated_ms_per_frame',{}).items()}
 print('$label', 'Mrays/s=%.0f ms/frame=%.2f' % (d['value'], d['ms_per_frame']), ' '.join('%s=%.1f' % (n, v['ms']/d['steps']) for n,v in k.items() if v['ms']>0.05))
 "
 done
