@@ -40,6 +40,8 @@ typedef struct PolarisOracleTaps {
                                                 instead of the block-local
                                                path index of pt_integrator.cl:106 */
 #define POLARIS_ORACLE_SERIAL 2u            /* do not use OpenMP (restatement only)  */
+#define POLARIS_ORACLE_PARALLEL_SAMPLES 4u  /* restatement only, CPU-baseline mode: threads take whole
+                                               samples (private buffers), per-pixel sums re-associated */
 
 /*
  * One tracer.Trace call (tracer/opencl/tracer.go:194-247 + pipeline.go:94-213) on a single

@@ -931,6 +931,158 @@ struct Timer {
 	double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 };
 
+// One sample of Tracer.Trace: generate -> query -> bounce loop, into `accum` (frame-sized).
+// All buffers are owned by the caller so the sample-parallel mode can give each thread its own.
+struct SampleBuffers {
+	std::vector<Ray> rays[3];
+	std::vector<Path> paths;
+	std::vector<int> hitFlags;
+	std::vector<Intersection> isects;
+	std::vector<float> emissiveSamples;
+	std::vector<ShadeOut> souts;
+	explicit SampleBuffers(int N) : paths(N), hitFlags(N), isects(N), emissiveSamples((size_t)N * 4), souts(N) {
+		for (auto &r : rays) r.resize(N);
+	}
+};
+
+struct TraceCtx {
+	const PolarisSceneView *sc;
+	const PolarisBlockRequest *req;
+	const float *frustum;
+	V3 eye;
+	V2 texel;
+	SceneRefs R;
+	int N;
+	bool fixEmitter, serial;
+};
+
+static void trace_sample(const TraceCtx &C, SampleBuffers &Bf, uint32_t s, const uint32_t *sseed, float *accum, PolarisTraceStats &st,
+                         bool &overflow, const PolarisOracleTaps *taps) {
+	const PolarisSceneView *sc = C.sc;
+	const PolarisBlockRequest *req = C.req;
+	const uint32_t W = req->frame_w, BH = req->block_h, BY = req->block_y, B = req->num_bounces;
+	const int N = C.N;
+	const bool serial = C.serial;
+	const int bg = sc->scene_diffuse_mat_index;
+	auto &rays = Bf.rays;
+	auto &paths = Bf.paths;
+	auto &hitFlags = Bf.hitFlags;
+	auto &isects = Bf.isects;
+	auto &emissiveSamples = Bf.emissiveSamples;
+	auto &souts = Bf.souts;
+	int counters[3] = {0, 0, 0};
+	const bool tap = taps && taps->tap_sample == s;
+
+	auto query = [&](uint32_t buf) {
+		const int n = counters[buf];
+		bool ovf = false;
+#pragma omp parallel for schedule(dynamic, 64) reduction(|| : ovf) if (!serial)
+		for (int g = 0; g < n; g++) {
+			bool o = false;
+			hitFlags[g] = traverse<false>(rays[buf][g], sc, &isects[g], &o);
+			ovf = ovf || o;
+		}
+		overflow = overflow || ovf;
+	};
+
+#pragma omp parallel for schedule(static) if (!serial)
+	for (int y = 0; y < (int)BH; y++)
+		for (uint32_t x = 0; x < W; x++)
+			generatePrimaryRay(x, (uint32_t)y, rays[0].data(), paths.data(), C.frustum, C.eye, C.texel, BY, W, sseed[0]);
+	counters[0] = N; // camera.cl:27-29
+	st.primary_rays += (uint64_t)N;
+	if (tap && taps->primary_rays) memcpy(taps->primary_rays, rays[0].data(), (size_t)N * sizeof(Ray));
+
+	uint32_t cur = 0;
+	query(cur); // pipeline.go:107-111, CPU branch
+	if (tap)
+		for (int g = 0; g < N; g++) {
+			if (taps->primary_hit) taps->primary_hit[g] = hitFlags[g];
+			if (hitFlags[g]) {
+				if (taps->primary_wuvt) memcpy(taps->primary_wuvt + 4 * g, isects[g].wuvt, 16);
+				if (taps->primary_tri) {
+					taps->primary_tri[2 * g] = (int32_t)isects[g].meshInstance;
+					taps->primary_tri[2 * g + 1] = (int32_t)isects[g].triIndex;
+				}
+			}
+		}
+
+	for (uint32_t b = 0; b < B; b++) {
+		const int n = counters[cur];
+		st.rays_per_bounce[b] += (uint64_t)n;
+		if (b > 0) st.indirect_rays += (uint64_t)n;
+		// pipeline.go:134-143
+		int nhit = 0;
+		for (int g = 0; g < n; g++) nhit += hitFlags[g] ? 1 : 0;
+		st.shaded_hits += (uint64_t)nhit;
+		if (bg != -1) {
+			st.shaded_misses += (uint64_t)(n - nhit);
+#pragma omp parallel for schedule(static) if (!serial)
+			for (int g = 0; g < n; g++)
+				if (!hitFlags[g]) shadeMiss(g, rays[cur].data(), paths.data(), C.R, (uint32_t)bg, b == 0, accum);
+		}
+		// ShadeHits (resources.go:226-273)
+#pragma omp parallel for schedule(dynamic, 64) if (!serial)
+		for (int g = 0; g < n; g++) {
+			souts[g].occl = souts[g].indirect = souts[g].emitterHit = false;
+			if (hitFlags[g])
+				shadeHit(g, rays[cur].data(), paths.data(), isects.data(), C.R, sc->num_emissives, b, req->min_bounces_for_rr, sseed[1 + b],
+				         accum, C.fixEmitter, &souts[g]);
+		}
+		// stable compaction == atomic compaction with work-group size 1 (pt_integrator.cl:188-210)
+		int nocc = 0, nind = 0;
+		for (int g = 0; g < n; g++) {
+			const ShadeOut &o = souts[g];
+			if (o.emitterHit) st.emitter_hits++;
+			if (o.occl) {
+				rays[2][nocc] = o.occlRay;
+				memcpy(&emissiveSamples[4 * (size_t)nocc], o.sample, 16);
+				nocc++;
+			}
+			if (o.indirect) rays[1 - cur][nind++] = o.indirectRay;
+		}
+		counters[2] = nocc;
+		counters[1 - cur] = nind;
+		if (tap && b == 0 && taps->throughput0)
+			for (int g = 0; g < N; g++) memcpy(taps->throughput0 + 4 * g, paths[g].throughput, 16);
+		if (tap && taps->num_rays) {
+			taps->num_rays[2 * b] = n;
+			taps->num_rays[2 * b + 1] = nocc;
+		}
+		st.occl_per_bounce[b] += (uint64_t)nocc;
+		st.occlusion_rays += (uint64_t)nocc;
+		// RayIntersectionTest + AccumulateEmissiveSamples (pipeline.go:160-168, pt_integrator.cl:278-296)
+		uint64_t unocc = 0;
+		bool ovf = false;
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : unocc) reduction(|| : ovf) if (!serial)
+		for (int g = 0; g < nocc; g++) {
+			bool o = false;
+			int hit = traverse<true>(rays[2][g], sc, nullptr, &o);
+			ovf = ovf || o;
+			if (!hit) {
+				unocc++;
+				uint32_t pathIndex = (uint32_t)rays[2][g].dir[3];
+				float *a = accum + 4 * (size_t)paths[pathIndex].pixelIndex;
+				a[0] += emissiveSamples[4 * (size_t)g];
+				a[1] += emissiveSamples[4 * (size_t)g + 1];
+				a[2] += emissiveSamples[4 * (size_t)g + 2];
+			}
+		}
+		overflow = overflow || ovf;
+		st.unoccluded += unocc;
+		if (b + 1 < B) { // pipeline.go:203-208
+			cur = 1 - cur;
+			query(cur);
+		}
+	}
+}
+
+static void add_stats(PolarisTraceStats &a, const PolarisTraceStats &b) {
+	a.primary_rays += b.primary_rays; a.indirect_rays += b.indirect_rays; a.occlusion_rays += b.occlusion_rays;
+	a.shaded_hits += b.shaded_hits; a.shaded_misses += b.shaded_misses; a.emitter_hits += b.emitter_hits; a.unoccluded += b.unoccluded;
+	for (int i = 0; i < POLARIS_MAX_BOUNCES; i++) { a.rays_per_bounce[i] += b.rays_per_bounce[i]; a.occl_per_bounce[i] += b.occl_per_bounce[i]; }
+}
+
 } // namespace
 
 // =========================================================================================
@@ -947,132 +1099,41 @@ extern "C" int polaris_oracle_trace(const PolarisSceneView *sc, const float eye[
 	if (n_seeds < (size_t)spp * (1 + B)) return 2;
 	const int N = (int)(W * BH);
 	const size_t F = (size_t)W * H;
-	const bool fixEmitter = (flags & POLARIS_ORACLE_FIX_EMITTER_INDEX) != 0;
-	const bool serial = (flags & POLARIS_ORACLE_SERIAL) != 0;
-	(void)serial;
+	const bool sample_parallel = (flags & POLARIS_ORACLE_PARALLEL_SAMPLES) != 0 && !taps;
 	Timer timer;
 
-	SceneRefs R{sc, sc->vertices, sc->normals, sc->uvs, sc->material_nodes, sc->texture_meta, sc->texture_data};
-	std::vector<Ray> rays[3];
-	for (auto &r : rays) r.resize(N);
-	std::vector<Path> paths(N);
-	std::vector<int> hitFlags(N);
-	std::vector<Intersection> isects(N);
-	std::vector<float> emissiveSamples((size_t)N * 4);
-	std::vector<ShadeOut> souts(N);
-	int counters[3] = {0, 0, 0};
+	TraceCtx C{sc, req, frustum, ld3(eye), {1.0f / (float)W, 1.0f / (float)H} /* resources.go:130-133 */,
+	           SceneRefs{sc, sc->vertices, sc->normals, sc->uvs, sc->material_nodes, sc->texture_meta, sc->texture_data}, N,
+	           (flags & POLARIS_ORACLE_FIX_EMITTER_INDEX) != 0, (flags & POLARIS_ORACLE_SERIAL) != 0 || sample_parallel};
 	bool overflow = false;
 	PolarisTraceStats st;
 	memset(&st, 0, sizeof st);
-
 	memset(trace_accum, 0, F * 4 * sizeof(float)); // ClearTraceAccumulator, tracer.go:215
-	const V2 texel = {1.0f / (float)W, 1.0f / (float)H}; // resources.go:130-133
-	const V3 eyeP = ld3(eye);
-	const int bg = sc->scene_diffuse_mat_index;
 
-	auto query = [&](uint32_t buf) {
-		const int n = counters[buf];
-		bool ovf = false;
-#pragma omp parallel for schedule(dynamic, 64) reduction(|| : ovf) if (!serial)
-		for (int g = 0; g < n; g++) {
-			bool o = false;
-			hitFlags[g] = traverse<false>(rays[buf][g], sc, &isects[g], &o);
-			ovf = ovf || o;
-		}
-		overflow = overflow || ovf;
-	};
-
-	for (uint32_t s = 0; s < spp; s++) {
-		const uint32_t *sseed = seeds + (size_t)s * (1 + B);
-		const bool tap = taps && taps->tap_sample == s;
-#pragma omp parallel for schedule(static) if (!serial)
-		for (int y = 0; y < (int)BH; y++)
-			for (uint32_t x = 0; x < W; x++)
-				generatePrimaryRay(x, (uint32_t)y, rays[0].data(), paths.data(), frustum, eyeP, texel, BY, W, sseed[0]);
-		counters[0] = N; // camera.cl:27-29
-		st.primary_rays += (uint64_t)N;
-		if (tap && taps->primary_rays) memcpy(taps->primary_rays, rays[0].data(), (size_t)N * sizeof(Ray));
-
-		uint32_t cur = 0;
-		query(cur); // pipeline.go:107-111, CPU branch
-		if (tap)
-			for (int g = 0; g < N; g++) {
-				if (taps->primary_hit) taps->primary_hit[g] = hitFlags[g];
-				if (hitFlags[g]) {
-					if (taps->primary_wuvt) memcpy(taps->primary_wuvt + 4 * g, isects[g].wuvt, 16);
-					if (taps->primary_tri) {
-						taps->primary_tri[2 * g] = (int32_t)isects[g].meshInstance;
-						taps->primary_tri[2 * g + 1] = (int32_t)isects[g].triIndex;
-					}
-				}
-			}
-
-		for (uint32_t b = 0; b < B; b++) {
-			const int n = counters[cur];
-			st.rays_per_bounce[b] += (uint64_t)n;
-			if (b > 0) st.indirect_rays += (uint64_t)n;
-			// pipeline.go:134-143
-			int nhit = 0;
-			for (int g = 0; g < n; g++) nhit += hitFlags[g] ? 1 : 0;
-			st.shaded_hits += (uint64_t)nhit;
-			if (bg != -1) {
-				st.shaded_misses += (uint64_t)(n - nhit);
-#pragma omp parallel for schedule(static) if (!serial)
-				for (int g = 0; g < n; g++)
-					if (!hitFlags[g]) shadeMiss(g, rays[cur].data(), paths.data(), R, (uint32_t)bg, b == 0, trace_accum);
-			}
-			// ShadeHits (resources.go:226-273)
-#pragma omp parallel for schedule(dynamic, 64) if (!serial)
-			for (int g = 0; g < n; g++) {
-				souts[g].occl = souts[g].indirect = souts[g].emitterHit = false;
-				if (hitFlags[g])
-					shadeHit(g, rays[cur].data(), paths.data(), isects.data(), R, sc->num_emissives, b, req->min_bounces_for_rr,
-					         sseed[1 + b], trace_accum, fixEmitter, &souts[g]);
-			}
-			// stable compaction == atomic compaction with work-group size 1 (pt_integrator.cl:188-210)
-			int nocc = 0, nind = 0;
-			for (int g = 0; g < n; g++) {
-				const ShadeOut &o = souts[g];
-				if (o.emitterHit) st.emitter_hits++;
-				if (o.occl) {
-					rays[2][nocc] = o.occlRay;
-					memcpy(&emissiveSamples[4 * (size_t)nocc], o.sample, 16);
-					nocc++;
-				}
-				if (o.indirect) rays[1 - cur][nind++] = o.indirectRay;
-			}
-			counters[2] = nocc;
-			counters[1 - cur] = nind;
-			if (tap && b == 0 && taps->throughput0)
-				for (int g = 0; g < N; g++) memcpy(taps->throughput0 + 4 * g, paths[g].throughput, 16);
-			if (tap && taps->num_rays) {
-				taps->num_rays[2 * b] = n;
-				taps->num_rays[2 * b + 1] = nocc;
-			}
-			st.occl_per_bounce[b] += (uint64_t)nocc;
-			st.occlusion_rays += (uint64_t)nocc;
-			// RayIntersectionTest + AccumulateEmissiveSamples (pipeline.go:160-168, pt_integrator.cl:278-296)
-			uint64_t unocc = 0;
-			bool ovf = false;
-#pragma omp parallel for schedule(dynamic, 64) reduction(+ : unocc) reduction(|| : ovf) if (!serial)
-			for (int g = 0; g < nocc; g++) {
-				bool o = false;
-				int hit = traverse<true>(rays[2][g], sc, nullptr, &o);
-				ovf = ovf || o;
-				if (!hit) {
-					unocc++;
-					uint32_t pathIndex = (uint32_t)rays[2][g].dir[3];
-					float *a = trace_accum + 4 * (size_t)paths[pathIndex].pixelIndex;
-					a[0] += emissiveSamples[4 * (size_t)g];
-					a[1] += emissiveSamples[4 * (size_t)g + 1];
-					a[2] += emissiveSamples[4 * (size_t)g + 2];
-				}
-			}
-			overflow = overflow || ovf;
-			st.unoccluded += unocc;
-			if (b + 1 < B) { // pipeline.go:203-208
-				cur = 1 - cur;
-				query(cur);
+	if (!sample_parallel) {
+		// reference order: samples one after the other, every contribution added straight into the
+		// accumulator (bit-exact with the compiled reference)
+		SampleBuffers Bf(N);
+		for (uint32_t s = 0; s < spp; s++) trace_sample(C, Bf, s, seeds + (size_t)s * (1 + B), trace_accum, st, overflow, taps);
+	} else {
+		// CPU-baseline mode: samples are independent, so threads take whole samples with private
+		// buffers and a private accumulator strip; strips are added in thread order at the end
+		// (same paths, per-pixel sums re-associated like the GPU's batched mode).
+		const size_t strip0 = (size_t)BY * W * 4, strip_n = (size_t)BH * W * 4;
+#pragma omp parallel
+		{
+			SampleBuffers Bf(N);
+			std::vector<float> acc(F * 4, 0.0f);
+			PolarisTraceStats lst;
+			memset(&lst, 0, sizeof lst);
+			bool lovf = false;
+#pragma omp for schedule(dynamic, 1)
+			for (int s = 0; s < (int)spp; s++) trace_sample(C, Bf, (uint32_t)s, seeds + (size_t)s * (1 + B), acc.data(), lst, lovf, nullptr);
+#pragma omp critical
+			{
+				for (size_t i = 0; i < strip_n; i++) trace_accum[strip0 + i] += acc[strip0 + i];
+				add_stats(st, lst);
+				overflow = overflow || lovf;
 			}
 		}
 	}
@@ -1080,6 +1141,7 @@ extern "C" int polaris_oracle_trace(const PolarisSceneView *sc, const float eye[
 	if (stats) *stats = st;
 	return overflow ? 3 : 0; // 3: the reference's 32-entry traversal stack would have overflowed
 }
+
 
 extern "C" int polaris_oracle_tonemap(const float *accum, uint32_t n_pixels, float sample_weight, float exposure,
                                       uint8_t *rgba) { // kernels/hdr.cl:5-28

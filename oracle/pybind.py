@@ -23,6 +23,7 @@ ROOT = os.path.dirname(HERE)
 
 FIX_EMITTER_INDEX = 1
 SERIAL = 2
+PARALLEL_SAMPLES = 4
 
 
 class Taps(C.Structure):

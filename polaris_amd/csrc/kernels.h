@@ -483,6 +483,135 @@ __global__ __launch_bounds__(WG) void k_trace(Streams st, BvhDev B, uint32_t num
 }
 
 // ------------------------------------------------------------------------------------------
+// Wave-packet traversal for PRIMARY rays (the role of rayPacketIntersectionQuery,
+// kernels/intersect.cl:353-575, without its two defects -- SURVEY.md 8a-3).
+//
+// One wave64 = one packet of 64 consecutive pixels walking the tree together: the node index is
+// wave-uniform, so the 64 B pair record, the leaf header and the triangles are fetched ONCE per
+// packet through the scalar cache instead of 64 per-lane gathers; the stack (node, 64-bit active
+// mask) is wave-shared in LDS; child order and "does anybody want this child" are decided by
+// __ballot votes.  Every lane keeps its own active bit: a lane takes part in a subtree only if ITS
+// slab test passed at every ancestor, which is exactly the set of leaves its own traversal (and the
+// reference's rayIntersectionQuery) visits -- so per-ray results are bit-identical to k_trace.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_trace_packet(Streams st, BvhDev B) {
+	__shared__ int p_ref[4][kTraversalStack];
+	__shared__ unsigned long long p_mask[4][kTraversalStack];
+	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const uint32_t cnt = st.cnt_ray[blockIdx.x];
+	if (wave * 64 >= cnt) return; // nothing live in this wave's 64 slots (uniform per wave)
+	const bool valid = tid < cnt;
+	const size_t slot = (size_t)blockIdx.x * WG + tid;
+	const float4 o4 = valid ? st.ray_o[slot] : make_float4(0, 0, 0, 0);
+	const float4 d4 = valid ? st.ray_d[slot] : make_float4(1, 1, 1, 0);
+	const f3 O = xyz(o4), D = xyz(d4);
+	const float maxDist = o4.w;
+	f3 o = O, d = D;
+	f3 inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)};
+	HitRec best;
+	best.t = maxDist; best.tri = -1; best.inst = 0; best.u = best.v = 0.0f; best.irank = best.trank = 0;
+	int inst = 0;
+	uint32_t irank = 0;
+	int sp = 0;
+	int cur = B.root_ref;
+	bool active = valid;
+	int *refs = p_ref[wave];
+	unsigned long long *masks = p_mask[wave];
+	for (;;) {
+		bool need_pop = false;
+		if (cur >= 0) {
+			const int ucur = __builtin_amdgcn_readfirstlane(cur);
+			const PairNode P = B.pairs[ucur]; // uniform address: scalar loads
+			float t0 = slab_entry_hw(P.lo0, P.hi0, o, inv, maxDist);
+			float t1 = slab_entry_hw(P.lo1, P.hi1, o, inv, maxDist);
+			const float lim = best.t * 1.001f;
+			const bool w0 = active && t0 < kFltMax && !(t0 > lim), w1 = active && t1 < kFltMax && !(t1 > lim);
+			const unsigned long long m0 = __ballot(w0), m1 = __ballot(w1);
+			const int c0 = fbits(P.lo0.w), c1 = fbits(P.lo1.w);
+			if (m0 != 0ull && m1 != 0ull) {
+				// packet-coherence vote: visit first the child that more lanes reach first
+				const int near0 = __popcll(__ballot(w0 && (!w1 || t0 <= t1))), near1 = __popcll(__ballot(w1 && (!w0 || t1 < t0)));
+				const bool first0 = near0 >= near1;
+				if (lane == 0) { refs[sp] = first0 ? c1 : c0; masks[sp] = first0 ? m1 : m0; }
+				__builtin_amdgcn_wave_barrier();
+				sp++;
+				cur = first0 ? c0 : c1;
+				active = first0 ? w0 : w1;
+			} else if (m0 != 0ull) { cur = c0; active = w0; }
+			else if (m1 != 0ull) { cur = c1; active = w1; }
+			else need_pop = true;
+		} else {
+			const int unode = __builtin_amdgcn_readfirstlane(~cur);
+			const int2 li = B.leaves[unode];
+			if (li.y == 0) { // enter the instance (all lanes transform; only active ones matter)
+				inst = -li.x;
+				const InstRec I = B.insts[inst];
+				irank = (uint32_t)I.meta.y;
+				const unsigned long long am = __ballot(active);
+				if (lane == 0) { refs[sp] = kExitMarker; masks[sp] = am; }
+				__builtin_amdgcn_wave_barrier();
+				sp++;
+				f3 no = {I.r0.x * o.x + I.r0.y * o.y + I.r0.z * o.z + I.r0.w, I.r1.x * o.x + I.r1.y * o.y + I.r1.z * o.z + I.r1.w,
+				         I.r2.x * o.x + I.r2.y * o.y + I.r2.z * o.z + I.r2.w};
+				f3 nd = {I.r0.x * d.x + I.r0.y * d.y + I.r0.z * d.z, I.r1.x * d.x + I.r1.y * d.y + I.r1.z * d.z,
+				         I.r2.x * d.x + I.r2.y * d.y + I.r2.z * d.z};
+				o = no; d = nd;
+				inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)};
+				cur = I.meta.x;
+			} else {
+				const int first = -li.x;
+				for (int t = first; t < first + li.y; t++) {
+					const TriRec T = B.tris[t]; // uniform address
+					if (active) {
+						f3 e1 = xyz(T.e1), e2 = xyz(T.e2);
+						f3 pv = cross(d, e2);
+						float det = dot(e1, pv);
+						if (!(pm_fabs(det) < kEps)) {
+							float idet = pm_rcp(det);
+							f3 tv = o - xyz(T.v0);
+							float u = dot(tv, pv) * idet;
+							if (!(u < 0.0f || u > 1.0f)) {
+								f3 qv = cross(tv, e1);
+								float v = dot(d, qv) * idet;
+								if (!(v < 0.0f || u + v > 1.0f)) {
+									float tt = dot(e2, qv) * idet;
+									if (tt > kEps) {
+										const uint32_t trank = (uint32_t)fbits(T.v0.w);
+										const bool closer = tt < best.t;
+										const bool tie = tt == best.t && best.tri >= 0 && (irank < best.irank || (irank == best.irank && trank < best.trank));
+										if (closer || tie) { best.t = tt; best.u = u; best.v = v; best.tri = t; best.inst = inst; best.irank = irank; best.trank = trank; }
+									}
+								}
+							}
+						}
+					}
+				}
+				need_pop = true;
+			}
+		}
+		if (need_pop) {
+			bool done = false;
+			for (;;) {
+				if (sp == 0) { done = true; break; }
+				sp--;
+				__builtin_amdgcn_wave_barrier();
+				cur = refs[sp];
+				const unsigned long long m = masks[sp];
+				active = ((m >> lane) & 1ull) != 0ull;
+				if (cur != kExitMarker) break;
+				o = O; d = D; // leaving the instance
+				inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)};
+			}
+			if (done) break;
+		}
+	}
+	if (valid) {
+		st.hit[slot] = make_float4(best.u, best.v, best.t, ibits(best.tri));
+		if (st.hit_inst) st.hit_inst[slot] = best.inst;
+	}
+}
+
+// ------------------------------------------------------------------------------------------
 // shadeHits (+ shadePrimaryRayMisses / shadeIndirectRayMisses), kernels/pt_integrator.cl:17-275
 // ------------------------------------------------------------------------------------------
 struct ShadeArgs {

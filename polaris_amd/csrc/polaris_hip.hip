@@ -81,7 +81,7 @@ struct polaris_hip_tracer {
 	// options
 	int64_t opt_samples_per_batch = 0; // 0 = auto
 	int opt_exact = 0;
-	int opt_packet_primary = 0;
+	int opt_packet_primary = 1; // wave-packet traversal (k_trace_packet) for bounce 0
 	int opt_time_kernels = 0;
 	int opt_trace_wgs_per_cu = 0; // 0 = auto (what the LDS stack admits)
 	int opt_shade_sorted = 0; // 1 = two-phase shade with an LDS sort by BxDF family (measured: no gain), 0 = straight through
@@ -253,7 +253,9 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 	for (uint32_t b = 0; b < B; b++) {
 		{
 			Timed t(h, "intersect", q);
-			if (h->opt_traversal)
+			if (b == 0 && h->opt_packet_primary)
+				hipLaunchKernelGGL(k_trace_packet, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh);
+			else if (h->opt_traversal)
 				launch_trace<false>(h, P, persistent, wgs, nullptr);
 			else
 				hipLaunchKernelGGL(k_intersect, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh);
@@ -694,7 +696,8 @@ int polaris_hip_tap_primary(polaris_hip_tracer *h, const PolarisBlockRequest *r,
 	hipStream_t q = h->stream;
 	HIP_TRY(h, hipMemcpyAsync(h->d_seeds, &seed, sizeof seed, hipMemcpyHostToDevice, q));
 	hipLaunchKernelGGL(k_generate, dim3(Npad / WG), dim3(WG), 0, q, st0, h->cam, h->d_seeds, 1u, 0u, N, Npad, h->W, r->block_y, 1);
-	hipLaunchKernelGGL(k_intersect, dim3(Npad / WG), dim3(WG), 0, q, st0, h->bvh);
+	if (h->opt_packet_primary) hipLaunchKernelGGL(k_trace_packet, dim3(Npad / WG), dim3(WG), 0, q, st0, h->bvh);
+	else hipLaunchKernelGGL(k_intersect, dim3(Npad / WG), dim3(WG), 0, q, st0, h->bvh);
 	HIP_TRY(h, hipGetLastError());
 	std::vector<float4> ro(N), rd(N), ht(N);
 	std::vector<int> inst(N);

@@ -18,6 +18,7 @@ for name in ["cornell-diffuse", "cornell", "sphere", "cubes", "materials"]:
         tr.UpdateState(UpdateMode.Synchronous, ChangeType.SceneData, sc)
         tr.UpdateState(UpdateMode.Synchronous, ChangeType.CameraData, sc)
         tr.set_option("exact_accumulate", exact)
+        tr.set_option("packet_primary", int(os.environ.get("PACKET", "0")))
         req = ob.make_request(W, H, spp=spp, bounces=B)
         tr.Trace(req, seeds)
         got = tr.read_accumulator(0); gs = tr.last_trace_stats

@@ -32,7 +32,12 @@ def test_hip_reproduces_reference_golden(built, path):
     B, spp = req.num_bounces, req.samples_per_pixel
     tr = make_hip_tracer(sc, req.frame_w, req.frame_h, exact_accumulate=1)
     try:
-        taps = tr.tap_primary(req, int(d["seeds"][0]))
+        taps = tr.tap_primary(req, int(d["seeds"][0]))          # wave-packet kernel (default)
+        tr.set_option("packet_primary", 0)
+        taps_ray = tr.tap_primary(req, int(d["seeds"][0]))      # one-ray-per-lane kernel
+        tr.set_option("packet_primary", 1)
+        for k in taps:
+            assert np.array_equal(bits(taps[k]), bits(taps_ray[k])), k
         tr.Trace(req, d["seeds"])
         acc, st = tr.read_accumulator(0), tr.last_trace_stats
         tr.MergeOutput(tr, req)
@@ -61,7 +66,8 @@ def test_hip_vs_oracle_exact_and_batched(built, oracle, name):
     W, H, spp, B = 96, 80, 6, 5   # 96 columns: workgroups straddle rows; 7680 rays = 30 workgroups
     seeds = scenes.make_seeds(spp, B, base=1234)
     want, ws, wt = oracle.trace(sc, ob.make_request(W, H, spp=spp, bounces=B), seeds, tap_sample=0)
-    variants = (({"exact_accumulate": 1}, True), ({"exact_accumulate": 1, "traversal": 0}, True), ({}, False),
+    variants = (({"exact_accumulate": 1}, True), ({"exact_accumulate": 1, "traversal": 0, "packet_primary": 0}, True),
+                ({"exact_accumulate": 1, "packet_primary": 0}, True), ({}, False),
                 ({"samples_per_batch": 4}, False), ({"samples_per_batch": 1, "overlap": 3}, False),
                 ({"samples_per_batch": 2, "overlap": 1, "traversal": 0}, False),
                 ({"exact_accumulate": 1, "shade_sorted": 1}, True), ({"shade_sorted": 1, "samples_per_batch": 3}, False))

@@ -59,3 +59,19 @@ def test_prng_matches_numpy_restatement(oracle):
         assert list(st) == [nsx, nsy]
         assert out[0] == np.float32(np.float32(a) * np.float32(1.0 / 4294967296.0))
         assert out[1] == np.float32(np.float32(b) * np.float32(1.0 / 4294967296.0))
+
+
+def test_sample_parallel_mode_matches_reference_order(oracle):
+    """The CPU-baseline mode of the restatement (threads take whole samples) traces the same paths:
+    identical counters, radiance equal up to the association of per-pixel sums."""
+    from oracle import pybind as ob
+    from polaris_amd import scenes
+
+    sc = scenes.SCENES["cornell"]()
+    W, H, spp, B = 48, 40, 12, 5
+    seeds = scenes.make_seeds(spp, B)
+    a, sa, _ = oracle.trace(sc, ob.make_request(W, H, spp=spp, bounces=B), seeds)
+    b, sb, _ = oracle.trace(sc, ob.make_request(W, H, spp=spp, bounces=B), seeds, flags=ob.FIX_EMITTER_INDEX | ob.PARALLEL_SAMPLES)
+    assert list(sa.rays_per_bounce[:B]) == list(sb.rays_per_bounce[:B]) and list(sa.occl_per_bounce[:B]) == list(sb.occl_per_bounce[:B])
+    assert sa.unoccluded == sb.unoccluded and sa.emitter_hits == sb.emitter_hits
+    assert float(np.sqrt(np.mean((a[..., :3] / spp - b[..., :3] / spp) ** 2))) <= 1e-6
