@@ -37,6 +37,7 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
+KERNELS = ("generate", "intersect_packet", "intersect", "shade", "scan", "occlusion", "resolve", "aggregate", "tonemap")
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
 
@@ -50,11 +51,12 @@ def naive_schedule(n_tracers: int, frame_h: int) -> list[int]:
 
 
 def kernel_algorithmic_bytes(st: dict) -> dict:
-    """SURVEY.md 8d per-unit stream bytes, attributed to the kernel that moves them."""
-    rays = st["primary_rays"] + st["indirect_rays"]
+    """SURVEY.md 8d per-unit stream bytes, attributed to the kernel that moves them
+    (intersect_packet = k_trace_packet on camera rays, intersect = k_trace<closest> on bounce rays)."""
     return {
         "generate": 52 * st["primary_rays"],
-        "intersect": 60 * rays,
+        "intersect_packet": 60 * st["primary_rays"],
+        "intersect": 60 * st["indirect_rays"],
         "shade": 68 * st["shaded_hits"] + 32 * st["indirect_rays"] + 44 * st["occlusion_rays"]
         + 60 * st["shaded_misses"] + 24 * st["emitter_hits"],
         "occlusion": 36 * st["occlusion_rays"] + 44 * st["unoccluded"],
@@ -77,6 +79,8 @@ def main() -> None:
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--save-png", default="")
     ap.add_argument("--opt", action="append", default=[], help="tracer option key=value (polaris_hip_set_option)")
+    ap.add_argument("--emulate-rank", default="", help="R/N: on ONE GPU, trace only the row block rank R of N would own "
+                    "(tuning aid for the strong-scaling path; not a valid bench line)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -107,6 +111,11 @@ def main() -> None:
     rows = naive_schedule(world, H)
     block_y = sum(rows[:rank])
     block_h = rows[rank]
+    if args.emulate_rank:
+        er, en = (int(v) for v in args.emulate_rank.split("/"))
+        erows = naive_schedule(en, H)
+        block_y, block_h = sum(erows[:er]), erows[er]
+        rows = [block_h]
 
     tr = HipTracer(f"hip-{rank}", local_rank)
     tr.Init()
@@ -150,7 +159,7 @@ def main() -> None:
                     tr.merge_device(gather_list[i].data_ptr(), make_req(y, rows[i]))
                     y += rows[i]
         if rank == 0:
-            full = make_req(0, H)
+            full = make_req(0, H) if not args.emulate_rank else make_req(block_y, block_h)
             tr.SyncFramebuffer(full)               # default.go:159-161
 
     def fence():
@@ -161,7 +170,7 @@ def main() -> None:
 
     for _ in range(args.warmup):
         frame(False)
-    for name in ("generate", "intersect", "shade", "scan", "occlusion", "resolve", "aggregate", "tonemap"):
+    for name in KERNELS:
         tr.kernel_ms(name)  # reset timers accumulated during warm-up
     fence()
     t0 = time.perf_counter()
@@ -172,7 +181,7 @@ def main() -> None:
 
     kt = {}
     if not args.no_kernel_timers:
-        for name in ("generate", "intersect", "shade", "scan", "occlusion", "resolve", "aggregate", "tonemap"):
+        for name in KERNELS:
             ms, n = tr.kernel_ms(name)
             kt[name] = (ms, n)
 
@@ -216,20 +225,22 @@ def main() -> None:
             mine = {k: totals[k] // args.steps for k in totals}     # per-frame counters of rank 0
             tr.set_option("overlap", 1)
             frame(False)
-            iso = {name: tr.kernel_ms(name) for name in ("generate", "intersect", "shade", "scan", "occlusion", "resolve")}
+            iso = {name: tr.kernel_ms(name) for name in KERNELS[:-2]}
             alg = kernel_algorithmic_bytes(mine)
-            dom = max(("generate", "intersect", "shade", "occlusion"), key=lambda k: iso[k][0])
+            dom = max(("generate", "intersect_packet", "intersect", "shade", "occlusion"), key=lambda k: iso[k][0])
             ms, n = iso[dom]
             achieved = alg[dom] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
             if os.path.exists(tpath) and (W, H, spp, B, args.scene) == (512, 512, 128, 5, "cornell"):
                 kn = {"intersect": "pol::k_trace<false, 16>", "occlusion": "pol::k_trace<true, 16>", "shade": "pol::k_shade",
-                      "generate": "pol::k_generate"}[dom]
+                      "generate": "pol::k_generate", "intersect_packet": "pol::k_trace_packet<false>"}[dom]
                 tk = json.load(open(tpath))["kernels"].get(kn)
                 if tk:
                     traffic = tk["hbm_bytes_per_launch"]    # PMC (FETCH_SIZE x2 + WRITE_SIZE), scripts/traffic.sh
-            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            names = {"intersect": "k_trace<false,16> (closest hit, bounce rays)", "intersect_packet": "k_trace_packet<false> (camera rays)",
+                     "occlusion": "k_trace<true,16> (any hit + NEE accumulate)", "shade": "k_shade", "generate": "k_generate"}
+            out["roofline"] = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "algorithmic_bytes_per_launch": alg[dom] / max(n, 1), "avg_launch_ms": ms / max(n, 1), "launches": n,
                                "measured": "HIP events, one extra frame with overlap=1 after the timed region"}

@@ -494,16 +494,20 @@ __global__ __launch_bounds__(WG) void k_trace(Streams st, BvhDev B, uint32_t num
 // slab test passed at every ancestor, which is exactly the set of leaves its own traversal (and the
 // reference's rayIntersectionQuery) visits -- so per-ray results are bit-identical to k_trace.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG) void k_trace_packet(Streams st, BvhDev B) {
+template <bool ANY_HIT>
+__global__ __launch_bounds__(WG) void k_trace_packet(Streams st, BvhDev B, float4 *acc, unsigned long long *stats) {
 	__shared__ int p_ref[4][kTraversalStack];
 	__shared__ unsigned long long p_mask[4][kTraversalStack];
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const uint32_t cnt = st.cnt_ray[blockIdx.x];
+	const uint32_t cnt = (ANY_HIT ? st.cnt_occ : st.cnt_ray)[blockIdx.x];
+	const float4 *src_o = ANY_HIT ? st.occ_o : st.ray_o;
+	const float4 *src_d = ANY_HIT ? st.occ_d : st.ray_d;
 	if (wave * 64 >= cnt) return; // nothing live in this wave's 64 slots (uniform per wave)
 	const bool valid = tid < cnt;
 	const size_t slot = (size_t)blockIdx.x * WG + tid;
-	const float4 o4 = valid ? st.ray_o[slot] : make_float4(0, 0, 0, 0);
-	const float4 d4 = valid ? st.ray_d[slot] : make_float4(1, 1, 1, 0);
+	const float4 o4 = valid ? src_o[slot] : make_float4(0, 0, 0, 0);
+	const float4 d4 = valid ? src_d[slot] : make_float4(1, 1, 1, 0);
+	bool occluded = false; // ANY_HIT: a lane that found its blocker leaves the packet for good
 	const f3 O = xyz(o4), D = xyz(d4);
 	const float maxDist = o4.w;
 	f3 o = O, d = D;
@@ -524,7 +528,7 @@ __global__ __launch_bounds__(WG) void k_trace_packet(Streams st, BvhDev B) {
 			const PairNode P = B.pairs[ucur]; // uniform address: scalar loads
 			float t0 = slab_entry_hw(P.lo0, P.hi0, o, inv, maxDist);
 			float t1 = slab_entry_hw(P.lo1, P.hi1, o, inv, maxDist);
-			const float lim = best.t * 1.001f;
+			const float lim = ANY_HIT ? kFltMax : best.t * 1.001f;
 			const bool w0 = active && t0 < kFltMax && !(t0 > lim), w1 = active && t1 < kFltMax && !(t1 > lim);
 			const unsigned long long m0 = __ballot(w0), m1 = __ballot(w1);
 			const int c0 = fbits(P.lo0.w), c1 = fbits(P.lo1.w);
@@ -575,7 +579,9 @@ __global__ __launch_bounds__(WG) void k_trace_packet(Streams st, BvhDev B) {
 								float v = dot(d, qv) * idet;
 								if (!(v < 0.0f || u + v > 1.0f)) {
 									float tt = dot(e2, qv) * idet;
-									if (tt > kEps) {
+									if (ANY_HIT) {
+										if (tt > kEps && tt < maxDist) { occluded = true; active = false; }
+									} else if (tt > kEps) {
 										const uint32_t trank = (uint32_t)fbits(T.v0.w);
 										const bool closer = tt < best.t;
 										const bool tie = tt == best.t && best.tri >= 0 && (irank < best.irank || (irank == best.irank && trank < best.trank));
@@ -597,15 +603,29 @@ __global__ __launch_bounds__(WG) void k_trace_packet(Streams st, BvhDev B) {
 				__builtin_amdgcn_wave_barrier();
 				cur = refs[sp];
 				const unsigned long long m = masks[sp];
-				active = ((m >> lane) & 1ull) != 0ull;
-				if (cur != kExitMarker) break;
+				active = ((m >> lane) & 1ull) != 0ull && !occluded;
+				if (cur != kExitMarker) {
+					if (__ballot(active) == 0ull) continue; // nobody left for this subtree
+					break;
+				}
 				o = O; d = D; // leaving the instance
 				inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)};
 			}
 			if (done) break;
 		}
 	}
-	if (valid) {
+	if (ANY_HIT) {
+		const bool clear = valid && !occluded;
+		if (clear) {
+			const float4 e = st.occ_e[slot];
+			float4 *cell = acc + (uint32_t)fbits(d4.w);
+			float4 a = *cell;
+			a.x += e.x; a.y += e.y; a.z += e.z;
+			*cell = a;
+		}
+		const unsigned long long m = __ballot(clear);
+		if (lane == 0 && m) atomicAdd(&stats[ST_UNOCCLUDED], (unsigned long long)__popcll(m));
+	} else if (valid) {
 		st.hit[slot] = make_float4(best.u, best.v, best.t, ibits(best.tri));
 		if (st.hit_inst) st.hit_inst[slot] = best.inst;
 	}

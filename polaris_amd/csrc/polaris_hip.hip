@@ -81,6 +81,7 @@ struct polaris_hip_tracer {
 	// options
 	int64_t opt_samples_per_batch = 0; // 0 = auto
 	int opt_exact = 0;
+	int opt_packet_shadow = 0;  // shadow rays of the first N bounces go through the packet kernel too
 	int opt_packet_primary = 1; // wave-packet traversal (k_trace_packet) for bounce 0
 	int opt_time_kernels = 0;
 	int opt_trace_wgs_per_cu = 0; // 0 = auto (what the LDS stack admits)
@@ -252,9 +253,9 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 	const uint32_t persistent = std::min<uint32_t>(wgs, (uint32_t)h->num_cus * per_cu);
 	for (uint32_t b = 0; b < B; b++) {
 		{
-			Timed t(h, "intersect", q);
+			Timed t(h, (b == 0 && h->opt_packet_primary) ? "intersect_packet" : "intersect", q);
 			if (b == 0 && h->opt_packet_primary)
-				hipLaunchKernelGGL(k_trace_packet, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh);
+				hipLaunchKernelGGL(k_trace_packet<false>, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, (float4 *)nullptr, h->d_stats);
 			else if (h->opt_traversal)
 				launch_trace<false>(h, P, persistent, wgs, nullptr);
 			else
@@ -275,7 +276,9 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 		}
 		{
 			Timed t(h, "occlusion", q);
-			if (h->opt_traversal)
+			if ((int)b < h->opt_packet_shadow)
+				hipLaunchKernelGGL(k_trace_packet<true>, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, A.acc, h->d_stats);
+			else if (h->opt_traversal)
 				launch_trace<true>(h, P, persistent, wgs, A.acc);
 			else
 				hipLaunchKernelGGL(k_occlusion, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, A.acc, h->d_stats);
@@ -467,6 +470,7 @@ int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value
 	if (k == "samples_per_batch") h->opt_samples_per_batch = value < 0 ? 0 : value;
 	else if (k == "exact_accumulate") h->opt_exact = value != 0;
 	else if (k == "packet_primary") h->opt_packet_primary = value != 0;
+	else if (k == "packet_shadow") h->opt_packet_shadow = (int)std::max<int64_t>(0, std::min<int64_t>(value, POLARIS_MAX_BOUNCES));
 	else if (k == "time_kernels") h->opt_time_kernels = value != 0;
 	else if (k == "traversal") h->opt_traversal = value != 0;
 	else if (k == "shade_sorted") h->opt_shade_sorted = value != 0;
@@ -696,7 +700,7 @@ int polaris_hip_tap_primary(polaris_hip_tracer *h, const PolarisBlockRequest *r,
 	hipStream_t q = h->stream;
 	HIP_TRY(h, hipMemcpyAsync(h->d_seeds, &seed, sizeof seed, hipMemcpyHostToDevice, q));
 	hipLaunchKernelGGL(k_generate, dim3(Npad / WG), dim3(WG), 0, q, st0, h->cam, h->d_seeds, 1u, 0u, N, Npad, h->W, r->block_y, 1);
-	if (h->opt_packet_primary) hipLaunchKernelGGL(k_trace_packet, dim3(Npad / WG), dim3(WG), 0, q, st0, h->bvh);
+	if (h->opt_packet_primary) hipLaunchKernelGGL(k_trace_packet<false>, dim3(Npad / WG), dim3(WG), 0, q, st0, h->bvh, (float4 *)nullptr, h->d_stats);
 	else hipLaunchKernelGGL(k_intersect, dim3(Npad / WG), dim3(WG), 0, q, st0, h->bvh);
 	HIP_TRY(h, hipGetLastError());
 	std::vector<float4> ro(N), rd(N), ht(N);
