@@ -1,7 +1,7 @@
 """CPU oracle (oracle/polaris_oracle.cpp) against the committed golden vectors.
 
 The vectors were produced by the reference's own OpenCL C compiled for the host
-(scripts/make_golden.py -> oracle/_ref/libpolaris_ref_pm.so); the bar is BIT equality of the
+(tests/tools/make_golden.py -> oracle/_ref/libpolaris_ref_pm.so); the bar is BIT equality of the
 radiance accumulator, every ray counter and the primary hit tables.
 """
 import numpy as np

@@ -1,6 +1,6 @@
 """Ad-hoc GPU check: HIP trace vs CPU oracle on every synthetic scene (run through gpurun)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from polaris_amd import scenes
 from polaris_amd.tracer import HipTracer, UpdateMode, ChangeType

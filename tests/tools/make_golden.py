@@ -6,12 +6,12 @@ compiled scene arrays, request, seeds) and the outputs of the reference's own Op
 on the host: the trace accumulator, the ray counters, and the primary-ray taps.  Fixtures are
 data; no reference source is stored.
 
-    python scripts/make_golden.py
+    python tests/tools/make_golden.py
 """
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
