@@ -5,6 +5,7 @@
 #include <random>
 
 #include "renderer.hpp"
+#include "scene_compiler.hpp"
 
 using namespace polaris;
 
@@ -114,5 +115,76 @@ void polaris_host_renderer_free(void *h) {
 	auto *box = static_cast<RendererBox *>(h);
 	if (box) { box->r->Close(); delete box; }
 }
+
+
+// ---- scene compiler (polaris_amd/host/scene_compiler.cpp) ------------------------------------
+// bvh.Build over boxes [n][6] = (min.xyz, max.xyz); centers = box centers.  Returns the node
+// count; out_nodes (capacity cap) receives the nodes, leaf_sizes the item count of every leaf
+// callback in call order.
+uint32_t polaris_host_bvh_build(const float *boxes, uint32_t n, int min_leaf, PolarisBvhNode *out_nodes, uint32_t cap,
+                                uint32_t *leaf_sizes, uint32_t *n_leaves) {
+	std::vector<compiler::bvh::BoundedVolume> vols(n);
+	for (uint32_t i = 0; i < n; i++) {
+		const float *b = boxes + 6 * i;
+		vols[i] = {{{b[0], b[1], b[2]}, {b[3], b[4], b[5]}}, {0.5f * (b[0] + b[3]), 0.5f * (b[1] + b[4]), 0.5f * (b[2] + b[5])}};
+	}
+	uint32_t leaves = 0;
+	auto nodes = compiler::bvh::Build(vols, min_leaf, [&](PolarisBvhNode *leaf, const std::vector<uint32_t> &items) {
+		leaf->ldata = -int32_t(items[0]);
+		leaf->rdata = int32_t(items.size());
+		if (leaf_sizes) leaf_sizes[leaves] = uint32_t(items.size());
+		leaves++;
+	});
+	if (n_leaves) *n_leaves = leaves;
+	for (uint32_t i = 0; i < nodes.size() && i < cap; i++) out_nodes[i] = nodes[i];
+	return uint32_t(nodes.size());
+}
+
+struct CompiledBox { compiler::Output out; PolarisSceneView view; };
+
+void *polaris_host_compile_scene(const float *prim_vertices, const float *prim_normals, const float *prim_uvs, const int32_t *prim_material,
+                                 const uint32_t *mesh_prim_offsets, uint32_t n_meshes, const uint32_t *inst_mesh,
+                                 const float *inst_transforms, uint32_t n_instances, const PolarisMaterialNode *nodes, uint32_t n_nodes,
+                                 const int32_t *material_roots, uint32_t n_materials, const PolarisTextureMetadata *tex_meta, uint32_t n_tex,
+                                 const uint8_t *tex_data, uint32_t n_tex_bytes, int32_t scene_diffuse, int32_t scene_emissive, int min_leaf,
+                                 char err[256]) {
+	compiler::Input in;
+	in.meshes.resize(n_meshes);
+	for (uint32_t m = 0; m < n_meshes; m++)
+		for (uint32_t p = mesh_prim_offsets[m]; p < mesh_prim_offsets[m + 1]; p++) {
+			compiler::Primitive pr{};
+			for (int k = 0; k < 3; k++) {
+				const float *v = prim_vertices + (size_t)p * 9 + 3 * k, *nn = prim_normals + (size_t)p * 9 + 3 * k;
+				pr.vertices[k] = {v[0], v[1], v[2]};
+				pr.normals[k] = {nn[0], nn[1], nn[2]};
+				pr.uvs[k][0] = prim_uvs[(size_t)p * 6 + 2 * k];
+				pr.uvs[k][1] = prim_uvs[(size_t)p * 6 + 2 * k + 1];
+			}
+			pr.materialIndex = prim_material[p];
+			in.meshes[m].primitives.push_back(pr);
+		}
+	in.instances.resize(n_instances);
+	for (uint32_t i = 0; i < n_instances; i++) {
+		in.instances[i].meshIndex = inst_mesh[i];
+		memcpy(in.instances[i].transform, inst_transforms + 16 * (size_t)i, 64);
+	}
+	in.materialNodes.assign(nodes, nodes + n_nodes);
+	in.materialRoots.assign(material_roots, material_roots + n_materials);
+	if (n_tex) in.textureMeta.assign(tex_meta, tex_meta + n_tex);
+	if (n_tex_bytes) in.textureData.assign(tex_data, tex_data + n_tex_bytes);
+	in.sceneDiffuseMatIndex = scene_diffuse;
+	in.sceneEmissiveMatIndex = scene_emissive;
+	in.minPrimitivesPerLeaf = min_leaf;
+	auto *box = new CompiledBox();
+	if (Error e = compiler::Compile(in, &box->out)) {
+		if (err) snprintf(err, 256, "%s", e.msg.c_str());
+		delete box;
+		return nullptr;
+	}
+	box->view = box->out.View();
+	return box;
+}
+const PolarisSceneView *polaris_host_compiled_view(void *h) { return &static_cast<CompiledBox *>(h)->view; }
+void polaris_host_compiled_free(void *h) { delete static_cast<CompiledBox *>(h); }
 
 } // extern "C"

@@ -1,0 +1,295 @@
+#include "scene_compiler.hpp"
+
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+namespace polaris {
+namespace compiler {
+
+static inline Vec3 vmin(Vec3 a, Vec3 b) { return {std::fmin(a.x, b.x), std::fmin(a.y, b.y), std::fmin(a.z, b.z)}; }
+static inline Vec3 vmax(Vec3 a, Vec3 b) { return {std::fmax(a.x, b.x), std::fmax(a.y, b.y), std::fmax(a.z, b.z)}; }
+static inline float axis_of(const Vec3 &v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
+
+namespace bvh {
+
+namespace {
+constexpr float minSideLength = 1e-3f; // bvh_builder.go:19-21
+constexpr float minSplitStep = 1e-5f;  // bvh_builder.go:23-26
+
+struct Builder {
+	const std::vector<BoundedVolume> &items;
+	int minLeafItems;
+	const LeafCallback &leafCb;
+	std::vector<PolarisBvhNode> nodes;
+
+	// surfaceAreaHeuristic.ScorePartition (bvh_builder.go:288-308)
+	float scorePartition(const std::vector<uint32_t> &w) const {
+		if (w.empty()) return FLT_MAX;
+		Vec3 lo{FLT_MAX, FLT_MAX, FLT_MAX}, hi{-FLT_MAX, -FLT_MAX, -FLT_MAX};
+		for (uint32_t i : w) { lo = vmin(lo, items[i].bbox[0]); hi = vmax(hi, items[i].bbox[1]); }
+		const float sx = hi.x - lo.x, sy = hi.y - lo.y, sz = hi.z - lo.z;
+		return float(w.size()) * (sx * sy + sy * sz + sx * sz);
+	}
+	// surfaceAreaHeuristic.ScoreSplit (bvh_builder.go:246-283)
+	float scoreSplit(const std::vector<uint32_t> &w, int axis, float splitPoint, int *lc, int *rc) const {
+		Vec3 lmin{FLT_MAX, FLT_MAX, FLT_MAX}, rmin = lmin, lmax{-FLT_MAX, -FLT_MAX, -FLT_MAX}, rmax = lmax;
+		int l = 0, r = 0;
+		for (uint32_t i : w) {
+			const BoundedVolume &it = items[i];
+			if (axis_of(it.center, axis) < splitPoint) { l++; lmin = vmin(lmin, it.bbox[0]); lmax = vmax(lmax, it.bbox[1]); }
+			else { r++; rmin = vmin(rmin, it.bbox[0]); rmax = vmax(rmax, it.bbox[1]); }
+		}
+		*lc = l; *rc = r;
+		if (l == 0 || r == 0) return FLT_MAX;
+		const float lx = lmax.x - lmin.x, ly = lmax.y - lmin.y, lz = lmax.z - lmin.z;
+		const float rx = rmax.x - rmin.x, ry = rmax.y - rmin.y, rz = rmax.z - rmin.z;
+		return float(l) * (lx * ly + ly * lz + lx * lz) + float(r) * (rx * ry + ry * rz + rx * rz);
+	}
+
+	uint32_t createLeaf(PolarisBvhNode node, const std::vector<uint32_t> &w) { // bvh_builder.go:215-229
+		leafCb(&node, w);
+		nodes.push_back(node);
+		return uint32_t(nodes.size() - 1);
+	}
+
+	uint32_t partition(const std::vector<uint32_t> &w, int depth) { // bvh_builder.go:127-211
+		PolarisBvhNode node{};
+		Vec3 lo{FLT_MAX, FLT_MAX, FLT_MAX}, hi{-FLT_MAX, -FLT_MAX, -FLT_MAX};
+		for (uint32_t i : w) { lo = vmin(lo, items[i].bbox[0]); hi = vmax(hi, items[i].bbox[1]); }
+		node.min[0] = lo.x; node.min[1] = lo.y; node.min[2] = lo.z;
+		node.max[0] = hi.x; node.max[1] = hi.y; node.max[2] = hi.z;
+		if ((int)w.size() <= minLeafItems) return createLeaf(node, w);
+
+		float bestScore = scorePartition(w);
+		bool haveSplit = false;
+		int bestAxis = 0;
+		float bestPoint = 0.0f;
+		const float side[3] = {hi.x - lo.x, hi.y - lo.y, hi.z - lo.z};
+		const float mn[3] = {lo.x, lo.y, lo.z}, mx[3] = {hi.x, hi.y, hi.z};
+		for (int axis = 0; axis < 3; axis++) {
+			if (side[axis] < minSideLength) continue;
+			const float splitStep = side[axis] / (1024.0f / float(depth + 1));
+			if (splitStep < minSplitStep) continue;
+			// candidates are scored concurrently by the reference (one goroutine each) and the
+			// best is kept with a strict "<": ties go to whichever goroutine reports first.
+			// Here: ascending (axis, splitPoint) order, deterministic.
+			std::vector<float> points;
+			for (float p = mn[axis]; p < mx[axis]; p += splitStep) points.push_back(p);
+			std::vector<float> scores(points.size());
+#pragma omp parallel for schedule(static) if (points.size() * w.size() > (1u << 16))
+			for (long k = 0; k < (long)points.size(); k++) {
+				int l, r;
+				scores[k] = scoreSplit(w, axis, points[k], &l, &r);
+			}
+			for (size_t k = 0; k < points.size(); k++)
+				if (scores[k] < bestScore) { bestScore = scores[k]; haveSplit = true; bestAxis = axis; bestPoint = points[k]; }
+		}
+		if (!haveSplit) return createLeaf(node, w);
+
+		std::vector<uint32_t> left, right;
+		for (uint32_t i : w) (axis_of(items[i].center, bestAxis) < bestPoint ? left : right).push_back(i);
+		const uint32_t nodeIndex = uint32_t(nodes.size());
+		nodes.push_back(node);
+		const uint32_t l = partition(left, depth + 1);
+		const uint32_t r = partition(right, depth + 1);
+		nodes[nodeIndex].ldata = int32_t(l); // SetChildNodes, optimized_scene.go:39-42
+		nodes[nodeIndex].rdata = int32_t(r);
+		return nodeIndex;
+	}
+};
+} // namespace
+
+std::vector<PolarisBvhNode> Build(const std::vector<BoundedVolume> &workList, int minLeafItems, const LeafCallback &leafCb) {
+	Builder b{workList, minLeafItems, leafCb, {}};
+	std::vector<uint32_t> all(workList.size());
+	for (size_t i = 0; i < all.size(); i++) all[i] = uint32_t(i);
+	b.partition(all, 0);
+	return std::move(b.nodes);
+}
+
+} // namespace bvh
+
+PolarisSceneView Output::View() const {
+	PolarisSceneView v{};
+	v.bvh_nodes = bvhNodes.data(); v.num_bvh_nodes = uint32_t(bvhNodes.size());
+	v.mesh_instances = meshInstances.data(); v.num_mesh_instances = uint32_t(meshInstances.size());
+	v.material_nodes = materialNodes.data(); v.num_material_nodes = uint32_t(materialNodes.size());
+	v.emissives = emissives.data(); v.num_emissives = uint32_t(emissives.size());
+	v.texture_data = textureData.data(); v.texture_data_bytes = uint32_t(textureData.size());
+	v.texture_meta = textureMeta.data(); v.num_textures = uint32_t(textureMeta.size());
+	v.vertices = vertices.data(); v.normals = normals.data(); v.uvs = uvs.data();
+	v.material_index = materialIndex.data(); v.num_triangles = uint32_t(materialIndex.size());
+	v.scene_diffuse_mat_index = sceneDiffuseMatIndex;
+	v.scene_emissive_mat_index = sceneEmissiveMatIndex;
+	return v;
+}
+
+int32_t FindMaterialNodeByBxdf(const std::vector<PolarisMaterialNode> &nodes, uint32_t nodeIndex, uint32_t bxdf) {
+	if (nodeIndex >= nodes.size()) return -1;
+	const PolarisMaterialNode &n = nodes[nodeIndex];
+	if (n.type < POLARIS_MAT_OP_MIX) return n.type == bxdf ? int32_t(nodeIndex) : -1;
+	int32_t out = FindMaterialNodeByBxdf(nodes, n.left_child, bxdf);
+	if (out != -1) return out;
+	if (n.type == POLARIS_MAT_OP_MIX) out = FindMaterialNodeByBxdf(nodes, uint32_t(n.right_child), bxdf);
+	return out;
+}
+
+// 4x4 inverse (general), column major
+static bool invert4(const float m[16], float out[16]) {
+	double a[16], inv[16];
+	for (int i = 0; i < 16; i++) a[i] = m[i];
+	inv[0] = a[5] * a[10] * a[15] - a[5] * a[11] * a[14] - a[9] * a[6] * a[15] + a[9] * a[7] * a[14] + a[13] * a[6] * a[11] - a[13] * a[7] * a[10];
+	inv[4] = -a[4] * a[10] * a[15] + a[4] * a[11] * a[14] + a[8] * a[6] * a[15] - a[8] * a[7] * a[14] - a[12] * a[6] * a[11] + a[12] * a[7] * a[10];
+	inv[8] = a[4] * a[9] * a[15] - a[4] * a[11] * a[13] - a[8] * a[5] * a[15] + a[8] * a[7] * a[13] + a[12] * a[5] * a[11] - a[12] * a[7] * a[9];
+	inv[12] = -a[4] * a[9] * a[14] + a[4] * a[10] * a[13] + a[8] * a[5] * a[14] - a[8] * a[6] * a[13] - a[12] * a[5] * a[10] + a[12] * a[6] * a[9];
+	inv[1] = -a[1] * a[10] * a[15] + a[1] * a[11] * a[14] + a[9] * a[2] * a[15] - a[9] * a[3] * a[14] - a[13] * a[2] * a[11] + a[13] * a[3] * a[10];
+	inv[5] = a[0] * a[10] * a[15] - a[0] * a[11] * a[14] - a[8] * a[2] * a[15] + a[8] * a[3] * a[14] + a[12] * a[2] * a[11] - a[12] * a[3] * a[10];
+	inv[9] = -a[0] * a[9] * a[15] + a[0] * a[11] * a[13] + a[8] * a[1] * a[15] - a[8] * a[3] * a[13] - a[12] * a[1] * a[11] + a[12] * a[3] * a[9];
+	inv[13] = a[0] * a[9] * a[14] - a[0] * a[10] * a[13] - a[8] * a[1] * a[14] + a[8] * a[2] * a[13] + a[12] * a[1] * a[10] - a[12] * a[2] * a[9];
+	inv[2] = a[1] * a[6] * a[15] - a[1] * a[7] * a[14] - a[5] * a[2] * a[15] + a[5] * a[3] * a[14] + a[13] * a[2] * a[7] - a[13] * a[3] * a[6];
+	inv[6] = -a[0] * a[6] * a[15] + a[0] * a[7] * a[14] + a[4] * a[2] * a[15] - a[4] * a[3] * a[14] - a[12] * a[2] * a[7] + a[12] * a[3] * a[6];
+	inv[10] = a[0] * a[5] * a[15] - a[0] * a[7] * a[13] - a[4] * a[1] * a[15] + a[4] * a[3] * a[13] + a[12] * a[1] * a[7] - a[12] * a[3] * a[5];
+	inv[14] = -a[0] * a[5] * a[14] + a[0] * a[6] * a[13] + a[4] * a[1] * a[14] - a[4] * a[2] * a[13] - a[12] * a[1] * a[6] + a[12] * a[2] * a[5];
+	inv[3] = -a[1] * a[6] * a[11] + a[1] * a[7] * a[10] + a[5] * a[2] * a[11] - a[5] * a[3] * a[10] - a[9] * a[2] * a[7] + a[9] * a[3] * a[6];
+	inv[7] = a[0] * a[6] * a[11] - a[0] * a[7] * a[10] - a[4] * a[2] * a[11] + a[4] * a[3] * a[10] + a[8] * a[2] * a[7] - a[8] * a[3] * a[6];
+	inv[11] = -a[0] * a[5] * a[11] + a[0] * a[7] * a[9] + a[4] * a[1] * a[11] - a[4] * a[3] * a[9] - a[8] * a[1] * a[7] + a[8] * a[3] * a[5];
+	inv[15] = a[0] * a[5] * a[10] - a[0] * a[6] * a[9] - a[4] * a[1] * a[10] + a[4] * a[2] * a[9] + a[8] * a[1] * a[6] - a[8] * a[2] * a[5];
+	double det = a[0] * inv[0] + a[1] * inv[4] + a[2] * inv[8] + a[3] * inv[12];
+	if (det == 0.0) return false;
+	det = 1.0 / det;
+	for (int i = 0; i < 16; i++) out[i] = float(inv[i] * det);
+	return true;
+}
+
+static Vec3 xform(const float m[16], Vec3 v) {
+	return {m[0] * v.x + m[4] * v.y + m[8] * v.z + m[12], m[1] * v.x + m[5] * v.y + m[9] * v.z + m[13], m[2] * v.x + m[6] * v.y + m[10] * v.z + m[14]};
+}
+
+Error Compile(const Input &in, Output *out) { // compiler.go:81-231
+	if (!out) return Error{POLARIS_E_BAD_ARGUMENT, "output is null"};
+	if (in.meshes.empty() || in.instances.empty()) return Error{POLARIS_E_BAD_SCENE, "scene has no meshes or no mesh instances"};
+	*out = Output{};
+	out->materialNodes = in.materialNodes;
+	out->textureMeta = in.textureMeta;
+	out->textureData = in.textureData;
+	out->sceneDiffuseMatIndex = in.sceneDiffuseMatIndex;
+	out->sceneEmissiveMatIndex = in.sceneEmissiveMatIndex;
+
+	// mesh bounding boxes (raw_scene.go:98-114) and instance volumes (world-space box of the 8 corners)
+	std::vector<Vec3> meshLo(in.meshes.size()), meshHi(in.meshes.size());
+	for (size_t m = 0; m < in.meshes.size(); m++) {
+		Vec3 lo{FLT_MAX, FLT_MAX, FLT_MAX}, hi{-FLT_MAX, -FLT_MAX, -FLT_MAX};
+		for (const Primitive &p : in.meshes[m].primitives)
+			for (int k = 0; k < 3; k++) { lo = vmin(lo, p.vertices[k]); hi = vmax(hi, p.vertices[k]); }
+		meshLo[m] = lo; meshHi[m] = hi;
+	}
+	std::vector<bvh::BoundedVolume> instVols(in.instances.size());
+	for (size_t i = 0; i < in.instances.size(); i++) {
+		const MeshInstance &mi = in.instances[i];
+		if (mi.meshIndex >= in.meshes.size()) return Error{POLARIS_E_BAD_SCENE, "mesh instance references a missing mesh"};
+		Vec3 lo{FLT_MAX, FLT_MAX, FLT_MAX}, hi{-FLT_MAX, -FLT_MAX, -FLT_MAX};
+		const Vec3 a = meshLo[mi.meshIndex], b = meshHi[mi.meshIndex];
+		for (int c = 0; c < 8; c++) {
+			Vec3 p = xform(mi.transform, {c & 1 ? b.x : a.x, c & 2 ? b.y : a.y, c & 4 ? b.z : a.z});
+			lo = vmin(lo, p); hi = vmax(hi, p);
+		}
+		instVols[i] = {{lo, hi}, {0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)}};
+	}
+	// top-level tree: one mesh instance per leaf (compiler.go:88-103)
+	out->bvhNodes = bvh::Build(instVols, 1, [](PolarisBvhNode *leaf, const std::vector<uint32_t> &items) {
+		leaf->ldata = -int32_t(items[0]); // SetMeshIndex
+		leaf->rdata = 0;
+	});
+
+	size_t totalPrims = 0;
+	for (const Mesh &m : in.meshes) totalPrims += m.primitives.size();
+	out->vertices.assign(totalPrims * 3 * 4, 0.0f);
+	out->normals.assign(totalPrims * 3 * 4, 0.0f);
+	out->uvs.assign(totalPrims * 3 * 2, 0.0f);
+	out->materialIndex.assign(totalPrims, 0);
+
+	struct MeshEmissive { uint32_t mesh; PolarisEmissive e; };
+	std::vector<MeshEmissive> meshEmissives;
+	std::vector<uint32_t> meshBvhRoots(in.meshes.size());
+	uint32_t vertexOffset = 0, primOffset = 0;
+	Error err;
+	for (size_t mIndex = 0; mIndex < in.meshes.size(); mIndex++) { // compiler.go:120-180
+		const Mesh &pm = in.meshes[mIndex];
+		std::vector<bvh::BoundedVolume> vols(pm.primitives.size());
+		for (size_t i = 0; i < vols.size(); i++) {
+			const Primitive &p = pm.primitives[i];
+			Vec3 lo = vmin(vmin(p.vertices[0], p.vertices[1]), p.vertices[2]), hi = vmax(vmax(p.vertices[0], p.vertices[1]), p.vertices[2]);
+			vols[i] = {{lo, hi}, {0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)}};
+		}
+		std::vector<PolarisBvhNode> nodes = bvh::Build(vols, in.minPrimitivesPerLeaf, [&](PolarisBvhNode *leaf, const std::vector<uint32_t> &items) {
+			leaf->ldata = -int32_t(primOffset); // SetPrimitives
+			leaf->rdata = int32_t(items.size());
+			for (uint32_t it : items) {
+				const Primitive &prim = pm.primitives[it];
+				for (int k = 0; k < 3; k++) {
+					float *v = &out->vertices[(size_t)(vertexOffset + k) * 4], *n = &out->normals[(size_t)(vertexOffset + k) * 4];
+					v[0] = prim.vertices[k].x; v[1] = prim.vertices[k].y; v[2] = prim.vertices[k].z;
+					n[0] = prim.normals[k].x; n[1] = prim.normals[k].y; n[2] = prim.normals[k].z;
+					out->uvs[(size_t)(vertexOffset + k) * 2] = prim.uvs[k][0];
+					out->uvs[(size_t)(vertexOffset + k) * 2 + 1] = prim.uvs[k][1];
+				}
+				if (prim.materialIndex < 0 || (size_t)prim.materialIndex >= in.materialRoots.size()) {
+					err = Error{POLARIS_E_BAD_SCENE, "primitive references a missing material"};
+				} else {
+					const int32_t root = in.materialRoots[prim.materialIndex];
+					out->materialIndex[primOffset] = uint32_t(root);
+					const int32_t emissiveNode = FindMaterialNodeByBxdf(in.materialNodes, uint32_t(root), POLARIS_BXDF_EMISSIVE);
+					if (emissiveNode != -1) { // compiler.go:147-160
+						PolarisEmissive e{};
+						const Vec3 &a = prim.vertices[0], &b = prim.vertices[1], &c = prim.vertices[2];
+						const Vec3 u{c.x - a.x, c.y - a.y, c.z - a.z}, w{c.x - b.x, c.y - b.y, c.z - b.z};
+						const Vec3 cr{u.y * w.z - u.z * w.y, u.z * w.x - u.x * w.z, u.x * w.y - u.y * w.x};
+						e.area = 0.5f * std::sqrt(cr.x * cr.x + cr.y * cr.y + cr.z * cr.z);
+						e.tri_index = primOffset;
+						e.mat_node_index = uint32_t(emissiveNode);
+						e.type = POLARIS_EMISSIVE_AREA;
+						meshEmissives.push_back({uint32_t(mIndex), e});
+					}
+				}
+				vertexOffset += 3;
+				primOffset++;
+			}
+		});
+		if (err) return err;
+		const int32_t offset = int32_t(out->bvhNodes.size()); // compiler.go:172-179
+		meshBvhRoots[mIndex] = uint32_t(offset);
+		for (PolarisBvhNode &n : nodes)
+			if (n.ldata > 0) { n.ldata += offset; n.rdata += offset; } // OffsetChildNodes
+		out->bvhNodes.insert(out->bvhNodes.end(), nodes.begin(), nodes.end());
+	}
+
+	out->meshInstances.resize(in.instances.size()); // compiler.go:185-192
+	for (size_t i = 0; i < in.instances.size(); i++) {
+		PolarisMeshInstance &mi = out->meshInstances[i];
+		memset(&mi, 0, sizeof mi);
+		mi.mesh_index = in.instances[i].meshIndex;
+		mi.bvh_root = meshBvhRoots[mi.mesh_index];
+		if (!invert4(in.instances[i].transform, mi.inv_transform)) return Error{POLARIS_E_BAD_SCENE, "singular mesh instance transform"};
+	}
+	for (const PolarisMeshInstance &mi : out->meshInstances) // compiler.go:200-211 (instance order, then mesh emissive order)
+		for (const MeshEmissive &me : meshEmissives) {
+			if (me.mesh != mi.mesh_index) continue;
+			PolarisEmissive e = me.e;
+			memcpy(e.transform, mi.inv_transform, sizeof e.transform); // the reference stores the instance's (inverse) matrix
+			out->emissives.push_back(e);
+		}
+	if (in.sceneEmissiveMatIndex != -1) { // compiler.go:214-220
+		const int32_t en = FindMaterialNodeByBxdf(in.materialNodes, uint32_t(in.sceneEmissiveMatIndex), POLARIS_BXDF_EMISSIVE);
+		if (en != -1) {
+			PolarisEmissive e{};
+			e.mat_node_index = uint32_t(en);
+			e.type = POLARIS_EMISSIVE_ENVIRONMENT;
+			out->emissives.push_back(e);
+		}
+	}
+	return Error::Nil();
+}
+
+} // namespace compiler
+} // namespace polaris

@@ -36,6 +36,15 @@ def load() -> C.CDLL:
         lib.polaris_host_renderer_error.restype = C.c_char_p
         lib.polaris_host_renderer_free.argtypes = [vp]
         lib.polaris_host_renderer_free.restype = None
+        lib.polaris_host_bvh_build.restype = C.c_uint32
+        lib.polaris_host_bvh_build.argtypes = [vp, C.c_uint32, C.c_int, vp, C.c_uint32, vp, vp]
+        lib.polaris_host_compile_scene.restype = vp
+        lib.polaris_host_compile_scene.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, vp,
+                                                   C.c_uint32, vp, C.c_uint32, C.c_int32, C.c_int32, C.c_int, C.c_char_p]
+        lib.polaris_host_compiled_view.restype = C.POINTER(T.SceneView)
+        lib.polaris_host_compiled_view.argtypes = [vp]
+        lib.polaris_host_compiled_free.argtypes = [vp]
+        lib.polaris_host_compiled_free.restype = None
         _lib = lib
     return _lib
 
@@ -108,3 +117,66 @@ class Renderer:
             self._h = None
 
     __del__ = close
+
+
+def bvh_build(boxes, min_leaf: int):
+    """bvh.Build (asset/compiler/bvh/bvh_builder.go:100-124) over boxes (n, 6) = min.xyz, max.xyz.
+    Returns (nodes as T.BVH_NODE array, list of leaf sizes in callback order)."""
+    lib = load()
+    b = np.ascontiguousarray(boxes, dtype=np.float32).reshape(-1, 6)
+    cap = 2 * len(b) + 1
+    nodes = np.zeros(cap, dtype=T.BVH_NODE)
+    sizes = np.zeros(cap, dtype=np.uint32)
+    nl = C.c_uint32()
+    n = lib.polaris_host_bvh_build(b.ctypes.data, len(b), min_leaf, nodes.ctypes.data, cap, sizes.ctypes.data, C.byref(nl))
+    return nodes[:n].copy(), [int(v) for v in sizes[: nl.value]]
+
+
+def compile_scene(meshes, instances, mats, *, scene_diffuse=-1, scene_emissive=-1, min_leaf=10, name="compiled"):
+    """The C++ scene compiler (polaris_amd/host/scene_compiler.cpp = compiler.go partitionGeometry) on
+    the same inputs polaris_amd.scenes.compile_scene takes: list[scenes.Mesh], list[(mesh index, 4x4
+    world matrix)], scenes.MaterialTable (per-triangle `mat` values are material root nodes).
+    Returns a polaris_amd.scenes.Scene holding copies of the compiled arrays."""
+    from .scenes import Scene
+
+    lib = load()
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    V = f32(np.concatenate([m.verts for m in meshes]))
+    Nn = f32(np.concatenate([m.normals for m in meshes]))
+    U = f32(np.concatenate([m.uvs for m in meshes]))
+    roots = sorted({int(r) for m in meshes for r in np.asarray(m.mat)})
+    root_to_mat = {r: i for i, r in enumerate(roots)}
+    M = np.ascontiguousarray([root_to_mat[int(r)] for m in meshes for r in np.asarray(m.mat)], dtype=np.int32)
+    offs = np.zeros(len(meshes) + 1, dtype=np.uint32)
+    offs[1:] = np.cumsum([len(m.verts) for m in meshes])
+    inst_mesh = np.ascontiguousarray([i for i, _ in instances], dtype=np.uint32)
+    inst_xf = f32(np.stack([np.asarray(x, dtype=np.float64).T.reshape(-1) for _, x in instances]))  # column major
+    nodes, tex_meta, tex_blob = mats.arrays()
+    mroots = np.ascontiguousarray(roots, dtype=np.int32)
+    err = C.create_string_buffer(256)
+    h = lib.polaris_host_compile_scene(V.ctypes.data, Nn.ctypes.data, U.ctypes.data, M.ctypes.data, offs.ctypes.data, len(meshes),
+                                       inst_mesh.ctypes.data, inst_xf.ctypes.data, len(instances), nodes.ctypes.data, len(nodes),
+                                       mroots.ctypes.data, len(mroots), T._ptr(tex_meta), len(tex_meta), T._ptr(tex_blob), tex_blob.size,
+                                       scene_diffuse, scene_emissive, min_leaf, err)
+    if not h:
+        raise RuntimeError(f"compile_scene: {err.value.decode()}")
+    try:
+        v = lib.polaris_host_compiled_view(h).contents
+
+        def grab(ptr, count, dtype):
+            if not ptr or count == 0:
+                return np.zeros(0, dtype=dtype)
+            nbytes = count * np.dtype(dtype).itemsize
+            return np.frombuffer(C.string_at(ptr, nbytes), dtype=dtype).copy()
+
+        nt = v.num_triangles
+        sc = Scene(
+            bvh_nodes=grab(v.bvh_nodes, v.num_bvh_nodes, T.BVH_NODE), mesh_instances=grab(v.mesh_instances, v.num_mesh_instances, T.MESH_INSTANCE),
+            material_nodes=grab(v.material_nodes, v.num_material_nodes, T.MATERIAL_NODE), emissives=grab(v.emissives, v.num_emissives, T.EMISSIVE),
+            texture_data=grab(v.texture_data, v.texture_data_bytes, np.uint8), texture_meta=grab(v.texture_meta, v.num_textures, T.TEXTURE_META),
+            vertices=grab(v.vertices, nt * 12, np.float32).reshape(-1, 4), normals=grab(v.normals, nt * 12, np.float32).reshape(-1, 4),
+            uvs=grab(v.uvs, nt * 6, np.float32).reshape(-1, 2), material_index=grab(v.material_index, nt, np.uint32),
+            scene_diffuse_mat_index=int(v.scene_diffuse_mat_index), scene_emissive_mat_index=int(v.scene_emissive_mat_index), name=name)
+    finally:
+        lib.polaris_host_compiled_free(h)
+    return sc
