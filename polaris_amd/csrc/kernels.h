@@ -52,6 +52,7 @@ struct Streams {
 	float4 *occ_o, *occ_d, *occ_e;
 	float4 *lsum;
 	uint32_t *cnt_ray, *cnt_occ, *pfx;
+	uint32_t *wg_stat; // per workgroup, written by shade: hits | misses << 10 | emitter hits << 20 (summed by k_scan)
 	int *hit_inst; // optional (test tap): instance id per slot, may be null
 };
 
@@ -474,11 +475,17 @@ __global__ __launch_bounds__(WG) void k_trace(Streams st, BvhDev B, uint32_t num
 	}
 #endif
 	if (ANY_HIT) {
-		// wave-level sum of the per-lane unoccluded counts, one atomic per wave
+		// wave sum -> workgroup sum in LDS -> ONE global atomic per workgroup (contended atomics on a
+		// single address run at ~80/us; see k_shade)
 		uint32_t v = unocc;
 #pragma unroll
 		for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
-		if (lane == 0 && v) atomicAdd(&stats[ST_UNOCCLUDED], (unsigned long long)v);
+		__syncthreads();
+		if (threadIdx.x == 0) wg_cursor = 0;
+		__syncthreads();
+		if (lane == 0 && v) atomicAdd(&wg_cursor, v);
+		__syncthreads();
+		if (threadIdx.x == 0 && wg_cursor) atomicAdd(&stats[ST_UNOCCLUDED], (unsigned long long)wg_cursor);
 	}
 }
 
@@ -640,17 +647,44 @@ struct ShadeArgs {
 	uint32_t bounce, min_rr;
 	int last_bounce;   // no closest-hit query follows (pipeline.go:203): do not emit indirect rays
 	int exact;         // accumulate into acc[pixelIndex] (trace accumulator) instead of lsum[path slot]
+	int stage_lds;     // k_shade: stage material nodes / lights / texture metadata in LDS when they fit
 	float4 *acc;       // trace accumulator (exact) or lsum (batched)
 };
 
-__global__ __launch_bounds__(WG) void k_shade(Streams st, SceneDev S, ShadeArgs A, unsigned long long *stats) {
+constexpr uint32_t kLdsMatNodes = 64, kLdsLights = 16, kLdsTextures = 16;
+
+__global__ __launch_bounds__(WG) void k_shade(Streams st, SceneDev Sg, ShadeArgs A, unsigned long long *stats) {
 	__shared__ uint32_t wave_ind[4], wave_occ[4];
 	__shared__ uint32_t blk_stats[3];
+	// material nodes, emissive records and texture metadata are tiny tables that EVERY ray walks
+	// through dependent loads (tree node -> texture record -> texel; light -> its material): when
+	// they fit they are staged in LDS once per workgroup, concurrently with the stream loads, which
+	// takes those round trips out of the wave's latency chain (the kernel is bound by exactly that
+	// chain times its occupancy: PMC shows waves waiting on memory 59 % of their life).
+	__shared__ float4 lds_nodes[kLdsMatNodes * 4];
+	__shared__ float4 lds_lights[kLdsLights * 5];
+	__shared__ float4 lds_texmeta[kLdsTextures];
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const uint32_t cnt = st.cnt_ray[blockIdx.x];
 	if (cnt == 0) { // uniform exit: nothing live in this workgroup
-		if (tid == 0) st.cnt_occ[blockIdx.x] = 0;
+		if (tid == 0) { st.cnt_occ[blockIdx.x] = 0; st.wg_stat[blockIdx.x] = 0; }
 		return;
+	}
+	SceneDev S = Sg;
+	if (A.stage_lds) {
+		if (Sg.num_nodes <= kLdsMatNodes) {
+			for (uint32_t i = tid; i < Sg.num_nodes * 4; i += WG) lds_nodes[i] = reinterpret_cast<const float4 *>(Sg.nodes)[i];
+			S.nodes = reinterpret_cast<const PolarisMaterialNode *>(lds_nodes);
+		}
+		if (Sg.num_emissives <= kLdsLights) {
+			for (uint32_t i = tid; i < Sg.num_emissives * 5; i += WG) lds_lights[i] = reinterpret_cast<const float4 *>(Sg.emissives)[i];
+			S.emissives = reinterpret_cast<const PolarisEmissive *>(lds_lights);
+		}
+		if (Sg.num_textures <= kLdsTextures) {
+			for (uint32_t i = tid; i < Sg.num_textures; i += WG) lds_texmeta[i] = reinterpret_cast<const float4 *>(Sg.tex_meta)[i];
+			S.tex_meta = reinterpret_cast<const PolarisTextureMetadata *>(lds_texmeta);
+		}
+		__syncthreads();
 	}
 	if (tid < 3) blk_stats[tid] = 0;
 	const uint32_t wgs_per_sample = A.Npad / WG;
@@ -803,9 +837,10 @@ __global__ __launch_bounds__(WG) void k_shade(Streams st, SceneDev S, ShadeArgs 
 	if (tid == 0) {
 		st.cnt_ray[blockIdx.x] = tot_ind;
 		st.cnt_occ[blockIdx.x] = tot_occ;
-		if (blk_stats[0]) atomicAdd(&stats[ST_SHADED_HITS], (unsigned long long)blk_stats[0]);
-		if (blk_stats[1]) atomicAdd(&stats[ST_SHADED_MISSES], (unsigned long long)blk_stats[1]);
-		if (blk_stats[2]) atomicAdd(&stats[ST_EMITTER_HITS], (unsigned long long)blk_stats[2]);
+		// no global atomics here: 32 Ki workgroups adding to three shared counters serialise at the
+		// memory side (~80 atomics/us on one address) and were, measured, the whole cost of this kernel
+		st.wg_stat[blockIdx.x] = blk_stats[0] | (blk_stats[1] << 10) | (blk_stats[2] << 20);
+		(void)stats;
 	}
 }
 
@@ -838,7 +873,7 @@ __global__ __launch_bounds__(WG) void k_shade_sorted(Streams st, SceneDev S, Sha
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const uint32_t cnt = st.cnt_ray[blockIdx.x];
 	if (cnt == 0) {
-		if (tid == 0) st.cnt_occ[blockIdx.x] = 0;
+		if (tid == 0) { st.cnt_occ[blockIdx.x] = 0; st.wg_stat[blockIdx.x] = 0; }
 		return;
 	}
 	if (tid < 3) blk_stats[tid] = 0;
@@ -1055,9 +1090,10 @@ __global__ __launch_bounds__(WG) void k_shade_sorted(Streams st, SceneDev S, Sha
 	if (tid == 0) {
 		st.cnt_ray[blockIdx.x] = tot_ind;
 		st.cnt_occ[blockIdx.x] = tot_occ;
-		if (blk_stats[0]) atomicAdd(&stats[ST_SHADED_HITS], (unsigned long long)blk_stats[0]);
-		if (blk_stats[1]) atomicAdd(&stats[ST_SHADED_MISSES], (unsigned long long)blk_stats[1]);
-		if (blk_stats[2]) atomicAdd(&stats[ST_EMITTER_HITS], (unsigned long long)blk_stats[2]);
+		// no global atomics here: 32 Ki workgroups adding to three shared counters serialise at the
+		// memory side (~80 atomics/us on one address) and were, measured, the whole cost of this kernel
+		st.wg_stat[blockIdx.x] = blk_stats[0] | (blk_stats[1] << 10) | (blk_stats[2] << 20);
+		(void)stats;
 	}
 }
 
@@ -1070,14 +1106,23 @@ __global__ __launch_bounds__(1024) void k_scan(Streams st, uint32_t wgs_per_samp
                                                unsigned long long *stats) {
 	__shared__ uint32_t part[1024];
 	__shared__ uint32_t part_occ[1024];
+	__shared__ uint32_t red[3][16];
 	const uint32_t tid = threadIdx.x;
 	const uint32_t per = (wgs_per_sample + 1023) / 1024;
 	const uint32_t b0 = blockIdx.x * wgs_per_sample;
 	const uint32_t lo = tid * per, hi = min(lo + per, wgs_per_sample);
-	uint32_t sum = 0, socc = 0;
-	for (uint32_t i = lo; i < hi; i++) { sum += st.cnt_ray[b0 + i]; socc += st.cnt_occ[b0 + i]; }
+	uint32_t sum = 0, socc = 0, s_hit = 0, s_miss = 0, s_emit = 0;
+	for (uint32_t i = lo; i < hi; i++) {
+		sum += st.cnt_ray[b0 + i];
+		socc += st.cnt_occ[b0 + i];
+		const uint32_t w = st.wg_stat[b0 + i]; // shading statistics of the workgroup (k_shade)
+		s_hit += w & 1023u; s_miss += (w >> 10) & 1023u; s_emit += (w >> 20) & 1023u;
+	}
 	part[tid] = sum;
 	part_occ[tid] = socc;
+	// wave reduction of the three shading counters, then 16 wave totals through LDS
+	for (int s = 32; s > 0; s >>= 1) { s_hit += __shfl_xor(s_hit, s); s_miss += __shfl_xor(s_miss, s); s_emit += __shfl_xor(s_emit, s); }
+	if ((tid & 63) == 0) { red[0][tid >> 6] = s_hit; red[1][tid >> 6] = s_miss; red[2][tid >> 6] = s_emit; }
 	__syncthreads();
 	// Hillis-Steele inclusive scan over the 1024 partials
 	for (uint32_t off = 1; off < 1024; off <<= 1) {
@@ -1092,6 +1137,11 @@ __global__ __launch_bounds__(1024) void k_scan(Streams st, uint32_t wgs_per_samp
 	if (tid == 1023) {
 		if (count_next_rays && part[1023]) atomicAdd(&stats[ST_RAYS_BOUNCE + bounce + 1], (unsigned long long)part[1023]);
 		if (part_occ[1023]) atomicAdd(&stats[ST_OCCL_BOUNCE + bounce], (unsigned long long)part_occ[1023]);
+	}
+	if (tid < 3) {
+		uint32_t t = 0;
+		for (int w = 0; w < 16; w++) t += red[tid][w];
+		if (t) atomicAdd(&stats[tid == 0 ? ST_SHADED_HITS : (tid == 1 ? ST_SHADED_MISSES : ST_EMITTER_HITS)], (unsigned long long)t);
 	}
 }
 

@@ -85,6 +85,7 @@ struct polaris_hip_tracer {
 	int opt_packet_primary = 1; // wave-packet traversal (k_trace_packet) for bounce 0
 	int opt_time_kernels = 0;
 	int opt_trace_wgs_per_cu = 0; // 0 = auto (what the LDS stack admits)
+	int opt_stage_lds = 1;    // k_shade stages material nodes / lights / texture metadata in LDS when they fit
 	int opt_shade_sorted = 0; // 1 = two-phase shade with an LDS sort by BxDF family (measured: no gain), 0 = straight through
 	int opt_traversal = 1; // 1 = persistent waves with lane refill (k_trace), 0 = one ray per lane (k_intersect/k_occlusion)
 
@@ -197,6 +198,7 @@ int ensure_streams(polaris_hip_tracer *h, int p, size_t slots, bool want_inst) {
 	rc |= dev_alloc(h, P.bufs, &P.st.cnt_ray, wgs);
 	rc |= dev_alloc(h, P.bufs, &P.st.cnt_occ, wgs);
 	rc |= dev_alloc(h, P.bufs, &P.st.pfx, wgs);
+	rc |= dev_alloc(h, P.bufs, &P.st.wg_stat, wgs);
 	if (want_inst) rc |= dev_alloc(h, P.bufs, &P.st.hit_inst, slots);
 	if (rc) { free_pool(P.bufs); P.st = Streams{}; return rc; }
 	P.slots = slots;
@@ -245,6 +247,7 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 	A.N = N; A.Npad = Npad; A.W = h->W; A.blockY = r->block_y;
 	A.min_rr = r->min_bounces_for_rr;
 	A.exact = exact ? 1 : 0;
+	A.stage_lds = h->opt_stage_lds;
 	A.acc = exact ? h->trace_acc : P.st.lsum;
 	// persistent grid: as many workgroups as the LDS stack lets a CU hold (16-entry stack: 16 KB per
 	// workgroup -> 8 by LDS, VGPRs allow 7-8 waves/SIMD; 32-entry: 5)
@@ -443,7 +446,7 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 	HIP_TRY(h, hipStreamSynchronize(h->stream)); // host vectors in L die at return
 	h->bvh = BvhDev{pairs, (uint32_t)L.pairs.size(), leaves, tris, insts, L.root_ref};
 	h->scene = SceneDev{vertices, normals, uvs, mat_index, nodes, emissives, tex_meta, tex_data, sc->num_emissives,
-	                    sc->scene_diffuse_mat_index};
+	                    sc->scene_diffuse_mat_index, sc->num_material_nodes, sc->num_textures};
 	h->max_stack = L.max_stack;
 	h->have_scene = true;
 	return POLARIS_OK;
@@ -474,6 +477,7 @@ int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value
 	else if (k == "time_kernels") h->opt_time_kernels = value != 0;
 	else if (k == "traversal") h->opt_traversal = value != 0;
 	else if (k == "shade_sorted") h->opt_shade_sorted = value != 0;
+	else if (k == "stage_lds") h->opt_stage_lds = value != 0;
 	else if (k == "overlap") h->opt_overlap = (int)std::max<int64_t>(1, std::min<int64_t>(value, polaris_hip_tracer::kMaxPipes));
 	else if (k == "trace_wgs_per_cu") h->opt_trace_wgs_per_cu = (int)std::max<int64_t>(0, std::min<int64_t>(value, 64));
 	else return fail(h, POLARIS_E_BAD_ARGUMENT, "unknown option '%s'", key);

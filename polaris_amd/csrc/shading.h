@@ -57,6 +57,7 @@ struct SceneDev {
 	const uint8_t *tex_data;
 	uint32_t num_emissives;
 	int32_t bg_node;                    // scene_diffuse_mat_index or -1
+	uint32_t num_nodes, num_textures;   // table sizes (LDS staging in k_shade)
 };
 
 // ---- PRNG: samplers/random_sampler.cl:7-16 ---------------------------------------------
