@@ -647,172 +647,186 @@ struct ShadeArgs {
 	uint32_t bounce, min_rr;
 	int last_bounce;   // no closest-hit query follows (pipeline.go:203): do not emit indirect rays
 	int exact;         // accumulate into acc[pixelIndex] (trace accumulator) instead of lsum[path slot]
-	int stage_lds;     // k_shade: stage material nodes / lights / texture metadata in LDS when they fit
+	int stage_lds;     // stage material nodes / lights / texture metadata in LDS when they fit
 	float4 *acc;       // trace accumulator (exact) or lsum (batched)
 };
 
+struct ShadeOut {
+	bool emit_ind, emit_occ;
+	float4 ro, rd, thr, oo, od, oe; // new indirect ray (origin|maxDist, dir|path word, throughput), shadow ray, NEE radiance
+	uint32_t hit, miss, emit;       // event flags for the counters
+};
+
+// One ray through shadeHits / shade*RayMisses.  `gid_ref` is the ray's position in the reference's
+// compacted buffer (PRNG state, pt_integrator.cl:81), `sample` the sample the workgroup belongs to.
+__device__ __forceinline__ void shade_ray(const SceneDev &S, const ShadeArgs &A, uint32_t sample, uint32_t seed, uint32_t gid_ref,
+                                          float4 d4, float4 t4, float4 h4, ShadeOut &R) {
+	R.emit_ind = R.emit_occ = false;
+	R.hit = R.miss = R.emit = 0;
+	const uint32_t pword = (uint32_t)fbits(d4.w);
+	const uint32_t path_index = pword & 0xFFFFFFu;
+	uint32_t flags = pword >> 24;
+	const uint32_t pixel_index = A.blockY * A.W + path_index; // camera.cl:32-33
+	const uint32_t cell = A.exact ? pixel_index : (uint32_t)(sample * A.Npad + path_index);
+	f3 thr = xyz(t4);
+	const int tri = fbits(h4.w);
+	if (tri < 0) {
+		if (S.bg_node >= 0) { // pt_integrator.cl:214-275 (throughput is exactly 1 for primaries)
+			const PolarisMaterialNode *bg = S.nodes + S.bg_node;
+			f2 uv = latlong_uv(xyz(d4));
+			f3 kd = mat_color(uv, bg->k, bg->tex, S);
+			f3 add = A.bounce == 0 ? kd : thr * kd;
+			float4 a = A.acc[cell];
+			a.x += add.x; a.y += add.y; a.z += add.z;
+			A.acc[cell] = a;
+			R.miss = 1;
+		}
+		return;
+	}
+	R.hit = 1;
+	Rng rng = {seed, gid_ref}; // pt_integrator.cl:81-84
+	const f2 sample0 = rng_next(rng), sample1 = rng_next(rng), sample2 = rng_next(rng);
+	const f3 in_dir = -xyz(d4);
+	// surfaceInit, util/surface.cl:12-33
+	const float bu = h4.x, bv = h4.y, bw = 1.0f - (bu + bv); // intersect.cl:283-286
+	const uint32_t off = (uint32_t)tri * 3;
+	Surf sf;
+	{
+		float4 a = S.vertices[off], b = S.vertices[off + 1], c = S.vertices[off + 2];
+		sf.p = mk3(bw * a.x + bu * b.x + bv * c.x, bw * a.y + bu * b.y + bv * c.y, bw * a.z + bu * b.z + bv * c.z);
+		a = S.normals[off]; b = S.normals[off + 1]; c = S.normals[off + 2];
+		sf.n = normalize(mk3(bw * a.x + bu * b.x + bv * c.x, bw * a.y + bu * b.y + bv * c.y, bw * a.z + bu * b.z + bv * c.z));
+		float2 ua = S.uvs[off], ub = S.uvs[off + 1], uc = S.uvs[off + 2];
+		sf.uv = {bw * ua.x + bu * ub.x + bv * uc.x, bw * ua.y + bu * ub.y + bv * uc.y};
+	}
+	f3 tint = splat(1.0f);
+	const Mat m = select_material(S.mat_index[tri], sf, flags, tint, rng, S);
+	const float in_dot_n = dot(in_dir, sf.n);
+	if (m.type == POLARIS_BXDF_EMISSIVE) { // pt_integrator.cl:101-107 (indexed by pixel: SURVEY 5.8)
+		if (in_dot_n > 0.0f) {
+			f3 add = thr * m.nd->scale * mat_color(sf.uv, m.nd->k, m.nd->tex, S);
+			float4 a = A.acc[cell];
+			a.x += add.x; a.y += add.y; a.z += add.z;
+			A.acc[cell] = a;
+			R.emit = 1;
+		}
+		return;
+	}
+	bool reject = m.type == POLARIS_BXDF_INVALID;
+	if (A.bounce >= A.min_rr) { // Russian roulette, :113-125
+		float p = pm_max(pm_min(0.5f, 0.2126f * thr.x + 0.7152f * thr.y + 0.0722f * thr.z), 0.01f);
+		if (p < sample2.x) reject = true;
+		else thr = thr / p;
+	}
+	if (reject) return;
+	f3 out_dir = splat(0.0f);
+	float bxdf_pdf = 1.0f, bxdf_weight = 1.0f;
+	const f3 bxdf_val = bxdf_sample(sf, m, S, sample0, in_dir, out_dir, bxdf_pdf);
+	const float displace = pm_sign(dot(sf.n, out_dir));
+	const f3 ind_origin = sf.p + (sf.n * displace) * kEps;  // DISPLACE_BY_EPSILON, :134
+	const f3 occ_origin = sf.p + sf.n * kEps;               // :136
+	// light selection + sampling + MIS, :139-155
+	f3 e_dir = splat(0.0f), e_rad = splat(0.0f);
+	float e_pdf = 0.0f, sel_pdf = 0.0f, e_weight = 0.0f, e_dist = 0.0f;
+	const PolarisEmissive *em = nullptr;
+	if (S.num_emissives > 0) {
+		sel_pdf = pm_rcp((float)(int)S.num_emissives); // emissiveSelect, emissive_sampler.cl:226-237
+		const int ei = pm_clampi((int)(sample1.x * (int)S.num_emissives), 0, (int)S.num_emissives - 1);
+		em = S.emissives + ei;
+		const LightSample L = light_sample(sf, em, S, sample1);
+		e_dir = L.dir; e_rad = L.radiance; e_pdf = L.pdf; e_dist = L.dist;
+	}
+	const float n_dot_e = pm_max(0.0f, dot(sf.n, e_dir));
+	const bool want_nee = maxcomp(e_rad) > 0.0f && e_pdf > 0.0f && n_dot_e > 0.0f; // :158
+	if (em) {
+		float bxdf_e_pdf;
+		f3 bxdf_e_val;
+		bxdf_pdf_eval(sf, m, S, in_dir, e_dir, want_nee, bxdf_e_pdf, bxdf_e_val);
+		e_weight = (e_pdf * e_pdf) / (e_pdf * e_pdf + bxdf_e_pdf * bxdf_e_pdf);       // POWER_HEURISTIC, :149
+		const float e_bxdf_pdf = light_pdf(sf, em, S, out_dir);
+		bxdf_weight = (bxdf_pdf * bxdf_pdf) / (bxdf_pdf * bxdf_pdf + e_bxdf_pdf * e_bxdf_pdf); // :154
+		if (want_nee) {
+			e_rad = e_rad * (e_weight * bxdf_e_val * thr * n_dot_e / (e_pdf * sel_pdf)); // :160
+			if (maxcomp(e_rad) > 0.0f) {
+				R.emit_occ = true;
+				R.oo = make_float4(occ_origin.x, occ_origin.y, occ_origin.z, e_dist - kLightEps); // :203
+				R.od = make_float4(e_dir.x, e_dir.y, e_dir.z, ibits((int)cell));
+				R.oe = make_float4(e_rad.x, e_rad.y, e_rad.z, 0.0f);
+			}
+		}
+	}
+	if ((m.type & (POLARIS_BXDF_CONDUCTOR | POLARIS_BXDF_DIELECTRIC)) != 0) bxdf_weight = 1.0f; // :166-168
+	const f3 tp = bxdf_weight * bxdf_val * tint * pm_fabs(dot(sf.n, out_dir)); // :173
+	if (maxcomp(tp) > 0.0f && bxdf_pdf > 0.0f && !A.last_bounce) {
+		const f3 nt = thr * tp / bxdf_pdf; // :175
+		R.emit_ind = true;
+		R.ro = make_float4(ind_origin.x, ind_origin.y, ind_origin.z, kFltMax); // :209
+		R.rd = make_float4(out_dir.x, out_dir.y, out_dir.z, ibits((int)(path_index | (flags << 24))));
+		R.thr = make_float4(nt.x, nt.y, nt.z, 0.0f);
+	}
+}
+
 constexpr uint32_t kLdsMatNodes = 64, kLdsLights = 16, kLdsTextures = 16;
 
-__global__ __launch_bounds__(WG) void k_shade(Streams st, SceneDev Sg, ShadeArgs A, unsigned long long *stats) {
+// Material nodes, emissive records and texture metadata are tiny tables that EVERY ray walks
+// through dependent loads (tree node -> texture record -> texel; light -> its material).  When they
+// fit they are staged in LDS once per workgroup, which takes those round trips out of the wave's
+// latency chain: the shading kernels are bound by exactly that chain times their occupancy (PMC:
+// waves wait on memory 59 % of their life, 4.1 cycles per VALU instruction, 4 waves per SIMD).
+struct ShadeLds {
+	float4 nodes[kLdsMatNodes * 4];
+	float4 lights[kLdsLights * 5];
+	float4 texmeta[kLdsTextures];
+};
+__device__ __forceinline__ SceneDev stage_scene(const SceneDev &Sg, ShadeLds &L, int enabled) {
+	SceneDev S = Sg;
+	if (!enabled) return S;
+	const uint32_t tid = threadIdx.x;
+	if (Sg.num_nodes <= kLdsMatNodes) {
+		for (uint32_t i = tid; i < Sg.num_nodes * 4; i += WG) L.nodes[i] = reinterpret_cast<const float4 *>(Sg.nodes)[i];
+		S.nodes = reinterpret_cast<const PolarisMaterialNode *>(L.nodes);
+	}
+	if (Sg.num_emissives <= kLdsLights) {
+		for (uint32_t i = tid; i < Sg.num_emissives * 5; i += WG) L.lights[i] = reinterpret_cast<const float4 *>(Sg.emissives)[i];
+		S.emissives = reinterpret_cast<const PolarisEmissive *>(L.lights);
+	}
+	if (Sg.num_textures <= kLdsTextures) {
+		for (uint32_t i = tid; i < Sg.num_textures; i += WG) L.texmeta[i] = reinterpret_cast<const float4 *>(Sg.tex_meta)[i];
+		S.tex_meta = reinterpret_cast<const PolarisTextureMetadata *>(L.texmeta);
+	}
+	__syncthreads();
+	return S;
+}
+
+// k_shade: one workgroup per chunk, one lane per live ray, stable in-place compaction through LDS.
+__global__ __launch_bounds__(WG) void k_shade(Streams st, SceneDev Sg, ShadeArgs A) {
 	__shared__ uint32_t wave_ind[4], wave_occ[4];
 	__shared__ uint32_t blk_stats[3];
-	// material nodes, emissive records and texture metadata are tiny tables that EVERY ray walks
-	// through dependent loads (tree node -> texture record -> texel; light -> its material): when
-	// they fit they are staged in LDS once per workgroup, concurrently with the stream loads, which
-	// takes those round trips out of the wave's latency chain (the kernel is bound by exactly that
-	// chain times its occupancy: PMC shows waves waiting on memory 59 % of their life).
-	__shared__ float4 lds_nodes[kLdsMatNodes * 4];
-	__shared__ float4 lds_lights[kLdsLights * 5];
-	__shared__ float4 lds_texmeta[kLdsTextures];
+	__shared__ ShadeLds lds;
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const uint32_t cnt = st.cnt_ray[blockIdx.x];
 	if (cnt == 0) { // uniform exit: nothing live in this workgroup
 		if (tid == 0) { st.cnt_occ[blockIdx.x] = 0; st.wg_stat[blockIdx.x] = 0; }
 		return;
 	}
-	SceneDev S = Sg;
-	if (A.stage_lds) {
-		if (Sg.num_nodes <= kLdsMatNodes) {
-			for (uint32_t i = tid; i < Sg.num_nodes * 4; i += WG) lds_nodes[i] = reinterpret_cast<const float4 *>(Sg.nodes)[i];
-			S.nodes = reinterpret_cast<const PolarisMaterialNode *>(lds_nodes);
-		}
-		if (Sg.num_emissives <= kLdsLights) {
-			for (uint32_t i = tid; i < Sg.num_emissives * 5; i += WG) lds_lights[i] = reinterpret_cast<const float4 *>(Sg.emissives)[i];
-			S.emissives = reinterpret_cast<const PolarisEmissive *>(lds_lights);
-		}
-		if (Sg.num_textures <= kLdsTextures) {
-			for (uint32_t i = tid; i < Sg.num_textures; i += WG) lds_texmeta[i] = reinterpret_cast<const float4 *>(Sg.tex_meta)[i];
-			S.tex_meta = reinterpret_cast<const PolarisTextureMetadata *>(lds_texmeta);
-		}
-		__syncthreads();
-	}
+	const SceneDev S = stage_scene(Sg, lds, A.stage_lds);
 	if (tid < 3) blk_stats[tid] = 0;
-	const uint32_t wgs_per_sample = A.Npad / WG;
-	const uint32_t s = blockIdx.x / wgs_per_sample;
+	const uint32_t s = blockIdx.x / (A.Npad / WG);
 	const size_t base = (size_t)blockIdx.x * WG;
-	const size_t slot = base + tid;
-	const bool active = tid < cnt;
-
-	bool emit_ind = false, emit_occ = false;
-	float4 n_ro, n_rd, n_thr, n_oo, n_od, n_oe;
-	uint32_t n_hit = 0, n_miss = 0, n_emit = 0;
-
-	if (active) {
-		const float4 d4 = st.ray_d[slot];
-		const float4 t4 = st.thr[slot];
-		const float4 h4 = st.hit[slot];
-		const uint32_t pword = (uint32_t)fbits(d4.w);
-		const uint32_t path_index = pword & 0xFFFFFFu;
-		uint32_t flags = pword >> 24;
-		const uint32_t pixel_index = A.blockY * A.W + path_index; // camera.cl:32-33
-		const uint32_t cell = A.exact ? pixel_index : (uint32_t)(s * A.Npad + path_index);
-		f3 thr = xyz(t4);
-		const int tri = fbits(h4.w);
-		if (tri < 0) {
-			if (S.bg_node >= 0) { // pt_integrator.cl:214-275 (throughput is exactly 1 for primaries)
-				const PolarisMaterialNode *bg = S.nodes + S.bg_node;
-				f2 uv = latlong_uv(xyz(d4));
-				f3 kd = mat_color(uv, bg->k, bg->tex, S);
-				f3 add = A.bounce == 0 ? kd : thr * kd;
-				float4 a = A.acc[cell];
-				a.x += add.x; a.y += add.y; a.z += add.z;
-				A.acc[cell] = a;
-				n_miss = 1;
-			}
-		} else {
-			n_hit = 1;
-			// PRNG: (seed, position in the reference's compacted buffer), pt_integrator.cl:81-84
-			Rng rng = {A.seeds[(size_t)(A.first_sample + s) * A.seed_stride + 1 + A.bounce], st.pfx[blockIdx.x] + tid};
-			const f2 sample0 = rng_next(rng), sample1 = rng_next(rng), sample2 = rng_next(rng);
-			const f3 in_dir = -xyz(d4);
-			// surfaceInit, util/surface.cl:12-33
-			const float bu = h4.x, bv = h4.y, bw = 1.0f - (bu + bv); // intersect.cl:283-286
-			const uint32_t off = (uint32_t)tri * 3;
-			Surf sf;
-			{
-				float4 a = S.vertices[off], b = S.vertices[off + 1], c = S.vertices[off + 2];
-				sf.p = mk3(bw * a.x + bu * b.x + bv * c.x, bw * a.y + bu * b.y + bv * c.y, bw * a.z + bu * b.z + bv * c.z);
-				a = S.normals[off]; b = S.normals[off + 1]; c = S.normals[off + 2];
-				sf.n = normalize(mk3(bw * a.x + bu * b.x + bv * c.x, bw * a.y + bu * b.y + bv * c.y, bw * a.z + bu * b.z + bv * c.z));
-				float2 ua = S.uvs[off], ub = S.uvs[off + 1], uc = S.uvs[off + 2];
-				sf.uv = {bw * ua.x + bu * ub.x + bv * uc.x, bw * ua.y + bu * ub.y + bv * uc.y};
-			}
-			f3 tint = splat(1.0f);
-			const Mat m = select_material(S.mat_index[tri], sf, flags, tint, rng, S);
-			const float in_dot_n = dot(in_dir, sf.n);
-			if (m.type == POLARIS_BXDF_EMISSIVE) { // pt_integrator.cl:101-107 (indexed by pixel: SURVEY 5.8)
-				if (in_dot_n > 0.0f) {
-					f3 add = thr * m.nd->scale * mat_color(sf.uv, m.nd->k, m.nd->tex, S);
-					float4 a = A.acc[cell];
-					a.x += add.x; a.y += add.y; a.z += add.z;
-					A.acc[cell] = a;
-					n_emit = 1;
-				}
-			} else {
-				bool reject = m.type == POLARIS_BXDF_INVALID;
-				if (A.bounce >= A.min_rr) { // Russian roulette, :113-125
-					float p = pm_max(pm_min(0.5f, 0.2126f * thr.x + 0.7152f * thr.y + 0.0722f * thr.z), 0.01f);
-					if (p < sample2.x) reject = true;
-					else thr = thr / p;
-				}
-				if (!reject) {
-					f3 out_dir = splat(0.0f);
-					float bxdf_pdf = 1.0f, bxdf_weight = 1.0f;
-					const f3 bxdf_val = bxdf_sample(sf, m, S, sample0, in_dir, out_dir, bxdf_pdf);
-					const float displace = pm_sign(dot(sf.n, out_dir));
-					const f3 ind_origin = sf.p + (sf.n * displace) * kEps;  // DISPLACE_BY_EPSILON, :134
-					const f3 occ_origin = sf.p + sf.n * kEps;               // :136
-					// light selection + sampling + MIS, :139-155
-					f3 e_dir = splat(0.0f), e_rad = splat(0.0f);
-					float e_pdf = 0.0f, sel_pdf = 0.0f, e_weight = 0.0f, e_dist = 0.0f;
-					const PolarisEmissive *em = nullptr;
-					if (S.num_emissives > 0) {
-						sel_pdf = pm_rcp((float)(int)S.num_emissives); // emissiveSelect, emissive_sampler.cl:226-237
-						const int ei = pm_clampi((int)(sample1.x * (int)S.num_emissives), 0, (int)S.num_emissives - 1);
-						em = S.emissives + ei;
-						const LightSample L = light_sample(sf, em, S, sample1);
-						e_dir = L.dir; e_rad = L.radiance; e_pdf = L.pdf; e_dist = L.dist;
-					}
-					const float n_dot_e = pm_max(0.0f, dot(sf.n, e_dir));
-					const bool want_nee = maxcomp(e_rad) > 0.0f && e_pdf > 0.0f && n_dot_e > 0.0f; // :158
-					if (em) {
-						float bxdf_e_pdf;
-						f3 bxdf_e_val;
-						bxdf_pdf_eval(sf, m, S, in_dir, e_dir, want_nee, bxdf_e_pdf, bxdf_e_val);
-						e_weight = (e_pdf * e_pdf) / (e_pdf * e_pdf + bxdf_e_pdf * bxdf_e_pdf);       // POWER_HEURISTIC, :149
-						const float e_bxdf_pdf = light_pdf(sf, em, S, out_dir);
-						bxdf_weight = (bxdf_pdf * bxdf_pdf) / (bxdf_pdf * bxdf_pdf + e_bxdf_pdf * e_bxdf_pdf); // :154
-						if (want_nee) {
-							e_rad = e_rad * (e_weight * bxdf_e_val * thr * n_dot_e / (e_pdf * sel_pdf)); // :160
-							if (maxcomp(e_rad) > 0.0f) {
-								emit_occ = true;
-								n_oo = make_float4(occ_origin.x, occ_origin.y, occ_origin.z, e_dist - kLightEps); // :203
-								n_od = make_float4(e_dir.x, e_dir.y, e_dir.z, ibits((int)cell));
-								n_oe = make_float4(e_rad.x, e_rad.y, e_rad.z, 0.0f);
-							}
-						}
-					}
-					if ((m.type & (POLARIS_BXDF_CONDUCTOR | POLARIS_BXDF_DIELECTRIC)) != 0) bxdf_weight = 1.0f; // :166-168
-					const f3 tp = bxdf_weight * bxdf_val * tint * pm_fabs(dot(sf.n, out_dir)); // :173
-					if (maxcomp(tp) > 0.0f && bxdf_pdf > 0.0f && !A.last_bounce) {
-						const f3 nt = thr * tp / bxdf_pdf; // :175
-						emit_ind = true;
-						n_ro = make_float4(ind_origin.x, ind_origin.y, ind_origin.z, kFltMax); // :209
-						n_rd = make_float4(out_dir.x, out_dir.y, out_dir.z, ibits((int)(path_index | (flags << 24))));
-						n_thr = make_float4(nt.x, nt.y, nt.z, 0.0f);
-					}
-				}
-			}
-		}
+	ShadeOut R;
+	R.emit_ind = R.emit_occ = false;
+	R.hit = R.miss = R.emit = 0;
+	if (tid < cnt) {
+		const size_t slot = base + tid;
+		const uint32_t seed = A.seeds[(size_t)(A.first_sample + s) * A.seed_stride + 1 + A.bounce];
+		shade_ray(S, A, s, seed, st.pfx[blockIdx.x] + tid, st.ray_d[slot], st.thr[slot], st.hit[slot], R);
 	}
-
 	// ---- stable in-place compaction of the two output streams -----------------------------
-	const unsigned long long m_ind = __ballot(emit_ind), m_occ = __ballot(emit_occ);
+	const unsigned long long m_ind = __ballot(R.emit_ind), m_occ = __ballot(R.emit_occ);
 	const unsigned long long below = (1ull << lane) - 1ull;
 	const uint32_t r_ind = __popcll(m_ind & below), r_occ = __popcll(m_occ & below);
 	if (lane == 0) { wave_ind[wave] = __popcll(m_ind); wave_occ[wave] = __popcll(m_occ); }
-	// block statistics (one atomic per counter per workgroup)
-	const unsigned long long mh = __ballot(n_hit != 0), mm = __ballot(n_miss != 0), me = __ballot(n_emit != 0);
+	const unsigned long long mh = __ballot(R.hit != 0), mm = __ballot(R.miss != 0), me = __ballot(R.emit != 0);
 	__syncthreads(); // also orders every lane's stream loads before any lane's in-place stores
 	if (lane == 0) {
 		if (mh) atomicAdd(&blk_stats[0], (uint32_t)__popcll(mh));
@@ -825,275 +839,79 @@ __global__ __launch_bounds__(WG) void k_shade(Streams st, SceneDev Sg, ShadeArgs
 		if (w < (int)wave) { b_ind += wave_ind[w]; b_occ += wave_occ[w]; }
 		tot_ind += wave_ind[w]; tot_occ += wave_occ[w];
 	}
-	if (emit_ind) {
+	if (R.emit_ind) {
 		const size_t d = base + b_ind + r_ind;
-		st.ray_o[d] = n_ro; st.ray_d[d] = n_rd; st.thr[d] = n_thr;
+		st.ray_o[d] = R.ro; st.ray_d[d] = R.rd; st.thr[d] = R.thr;
 	}
-	if (emit_occ) {
+	if (R.emit_occ) {
 		const size_t d = base + b_occ + r_occ;
-		st.occ_o[d] = n_oo; st.occ_d[d] = n_od; st.occ_e[d] = n_oe;
+		st.occ_o[d] = R.oo; st.occ_d[d] = R.od; st.occ_e[d] = R.oe;
 	}
 	__syncthreads();
 	if (tid == 0) {
 		st.cnt_ray[blockIdx.x] = tot_ind;
 		st.cnt_occ[blockIdx.x] = tot_occ;
 		// no global atomics here: 32 Ki workgroups adding to three shared counters serialise at the
-		// memory side (~80 atomics/us on one address) and were, measured, the whole cost of this kernel
+		// memory side (~80 atomics/us on one address); k_scan sums these words instead
 		st.wg_stat[blockIdx.x] = blk_stats[0] | (blk_stats[1] << 10) | (blk_stats[2] << 20);
-		(void)stats;
 	}
 }
 
-// ------------------------------------------------------------------------------------------
-// k_shade_sorted: the same shading as k_shade, re-scheduled inside the workgroup.
-//
-// PMC counters put k_shade at ~31 % live lanes per VALU instruction.  The cause is not empty
-// slots but the 5-way BxDF switch: at bounce >= 1 the 64 rays of a wave land on walls, glass, the
-// metal/diffuse mix ... and the wave executes every family's sample + pdf + eval code in turn.
-// Here a workgroup shades in two phases with an LDS exchange in between:
-//   phase A (one lane per live ray, stream order): PRNG draws, surface interpolation, material
-//           tree walk, miss / emitter accumulation, Russian roulette.  Survivors are compacted
-//           (stable) to dense indices j and their state goes to LDS.
-//   sort    counting sort of the survivors by BxDF family (LDS atomics) -> k
-//   phase B (lane k): BxDF sample, light sample, MIS, NEE -- waves are now family-homogeneous.
-//   write   emit flags go back to LDS under the DENSE STREAM-ORDER index j, ranks are computed in
-//           j order (== original ray order, the compaction was stable) and lane k writes its rays
-//           at those ranks: the output streams are byte-identical to k_shade's.
-// ------------------------------------------------------------------------------------------
-constexpr int kShadeState = 27; // dwords of phase A -> phase B state per survivor
-
-__global__ __launch_bounds__(WG) void k_shade_sorted(Streams st, SceneDev S, ShadeArgs A, unsigned long long *stats) {
-	__shared__ uint32_t xs[kShadeState][WG];      // survivor state, one column per dense index j
-	__shared__ uint16_t s2j[WG];                  // sorted slot k -> dense index j
-	__shared__ uint16_t rank_ind[WG], rank_occ[WG];
-	__shared__ uint8_t flag_ind[WG], flag_occ[WG];
-	__shared__ uint32_t wave_a[4], wave_b[4], wave_c[4];
-	__shared__ uint32_t cls_count[8], cls_cursor[8];
-	__shared__ uint32_t blk_stats[3];
-	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const uint32_t cnt = st.cnt_ray[blockIdx.x];
-	if (cnt == 0) {
-		if (tid == 0) { st.cnt_occ[blockIdx.x] = 0; st.wg_stat[blockIdx.x] = 0; }
-		return;
-	}
-	if (tid < 3) blk_stats[tid] = 0;
-	if (tid < 8) { cls_count[tid] = 0; cls_cursor[tid] = 0; }
-	const uint32_t wgs_per_sample = A.Npad / WG;
-	const uint32_t s = blockIdx.x / wgs_per_sample;
-	const size_t base = (size_t)blockIdx.x * WG;
+// k_shade_wave: the same shading with a WAVE as the unit of work.  k_shade's launch time is
+// (#chunks / resident workgroups) x (latency chain of one workgroup) however few rays a chunk
+// still holds, so the sparse late bounces cost as much as the dense first one.  Here persistent
+// waves pull chunks (dealt round-robin to workgroups, LDS cursor inside) and walk a chunk's live
+// rays 64 at a time: a chunk with <= 64 survivors costs one pass of one wave instead of a
+// four-wave workgroup, and no __syncthreads is needed.  In-place safety: pass j reads slots
+// [64j, 64j+64) and writes at positions <= 64j + lane, i.e. only where this wave has already read.
+__global__ __launch_bounds__(WG) void k_shade_wave(Streams st, SceneDev Sg, ShadeArgs A, uint32_t num_chunks) {
+	__shared__ ShadeLds lds;
+	__shared__ uint32_t wg_cursor;
+	if (threadIdx.x == 0) wg_cursor = 0;
+	const SceneDev S = stage_scene(Sg, lds, 1); // (contains the __syncthreads that also publishes wg_cursor)
+	if (!A.stage_lds) __syncthreads();
+	const uint32_t lane = threadIdx.x & 63;
 	const unsigned long long below = (1ull << lane) - 1ull;
-	__syncthreads();
-
-	// ---------------------------------------------------------------- phase A
-	bool survive = false;
-	uint32_t cls = 0;
-	uint32_t n_hit = 0, n_miss = 0, n_emit = 0;
-	// survivor state (registers until the dense index is known)
-	f3 a_in = {0, 0, 0}, a_thr = {0, 0, 0}, a_tint = {1, 1, 1};
-	Surf a_sf = {{0, 0, 0}, {0, 0, 0}, {0, 0}};
-	f2 a_s0 = {0, 0}, a_s1 = {0, 0};
-	uint32_t a_node = 0, a_type = 0, a_pword = 0, a_cell = 0;
-	float a_iior = 0, a_eior = 0;
-	if (tid < cnt) {
-		const size_t slot = base + tid;
-		const float4 d4 = st.ray_d[slot];
-		const float4 t4 = st.thr[slot];
-		const float4 h4 = st.hit[slot];
-		const uint32_t pword = (uint32_t)fbits(d4.w);
-		const uint32_t path_index = pword & 0xFFFFFFu;
-		uint32_t flags = pword >> 24;
-		const uint32_t pixel_index = A.blockY * A.W + path_index;
-		const uint32_t cell = A.exact ? pixel_index : (uint32_t)(s * A.Npad + path_index);
-		f3 thr = xyz(t4);
-		const int tri = fbits(h4.w);
-		if (tri < 0) {
-			if (S.bg_node >= 0) {
-				const PolarisMaterialNode *bg = S.nodes + S.bg_node;
-				f2 uv = latlong_uv(xyz(d4));
-				f3 kd = mat_color(uv, bg->k, bg->tex, S);
-				f3 add = A.bounce == 0 ? kd : thr * kd;
-				float4 a = A.acc[cell];
-				a.x += add.x; a.y += add.y; a.z += add.z;
-				A.acc[cell] = a;
-				n_miss = 1;
-			}
-		} else {
-			n_hit = 1;
-			Rng rng = {A.seeds[(size_t)(A.first_sample + s) * A.seed_stride + 1 + A.bounce], st.pfx[blockIdx.x] + tid};
-			const f2 sample0 = rng_next(rng), sample1 = rng_next(rng), sample2 = rng_next(rng);
-			const f3 in_dir = -xyz(d4);
-			const float bu = h4.x, bv = h4.y, bw = 1.0f - (bu + bv);
-			const uint32_t off = (uint32_t)tri * 3;
-			Surf sf;
-			{
-				float4 a = S.vertices[off], b = S.vertices[off + 1], c = S.vertices[off + 2];
-				sf.p = mk3(bw * a.x + bu * b.x + bv * c.x, bw * a.y + bu * b.y + bv * c.y, bw * a.z + bu * b.z + bv * c.z);
-				a = S.normals[off]; b = S.normals[off + 1]; c = S.normals[off + 2];
-				sf.n = normalize(mk3(bw * a.x + bu * b.x + bv * c.x, bw * a.y + bu * b.y + bv * c.y, bw * a.z + bu * b.z + bv * c.z));
-				float2 ua = S.uvs[off], ub = S.uvs[off + 1], uc = S.uvs[off + 2];
-				sf.uv = {bw * ua.x + bu * ub.x + bv * uc.x, bw * ua.y + bu * ub.y + bv * uc.y};
-			}
-			f3 tint = splat(1.0f);
-			const Mat m = select_material(S.mat_index[tri], sf, flags, tint, rng, S);
-			const float in_dot_n = dot(in_dir, sf.n);
-			if (m.type == POLARIS_BXDF_EMISSIVE) {
-				if (in_dot_n > 0.0f) {
-					f3 add = thr * m.nd->scale * mat_color(sf.uv, m.nd->k, m.nd->tex, S);
-					float4 a = A.acc[cell];
-					a.x += add.x; a.y += add.y; a.z += add.z;
-					A.acc[cell] = a;
-					n_emit = 1;
+	const uint32_t wgs_per_sample = A.Npad / WG;
+	for (;;) {
+		uint32_t c = 0;
+		if (lane == 0) c = atomicAdd(&wg_cursor, 1u);
+		const uint32_t chunk = blockIdx.x + __builtin_amdgcn_readfirstlane(c) * gridDim.x;
+		if (chunk >= num_chunks) break;
+		const uint32_t cnt = st.cnt_ray[chunk];
+		uint32_t out_ind = 0, out_occ = 0, n_hit = 0, n_miss = 0, n_emit = 0;
+		if (cnt != 0) {
+			const uint32_t s = chunk / wgs_per_sample;
+			const uint32_t seed = A.seeds[(size_t)(A.first_sample + s) * A.seed_stride + 1 + A.bounce];
+			const uint32_t pfx = st.pfx[chunk];
+			const size_t base = (size_t)chunk * WG;
+			for (uint32_t j = 0; j < cnt; j += 64) {
+				const uint32_t idx = j + lane;
+				ShadeOut R;
+				R.emit_ind = R.emit_occ = false;
+				R.hit = R.miss = R.emit = 0;
+				if (idx < cnt) shade_ray(S, A, s, seed, pfx + idx, st.ray_d[base + idx], st.thr[base + idx], st.hit[base + idx], R);
+				const unsigned long long m_ind = __ballot(R.emit_ind), m_occ = __ballot(R.emit_occ);
+				if (R.emit_ind) {
+					const size_t d = base + out_ind + __popcll(m_ind & below);
+					st.ray_o[d] = R.ro; st.ray_d[d] = R.rd; st.thr[d] = R.thr;
 				}
-			} else {
-				bool reject = m.type == POLARIS_BXDF_INVALID;
-				if (A.bounce >= A.min_rr) {
-					float p = pm_max(pm_min(0.5f, 0.2126f * thr.x + 0.7152f * thr.y + 0.0722f * thr.z), 0.01f);
-					if (p < sample2.x) reject = true;
-					else thr = thr / p;
+				if (R.emit_occ) {
+					const size_t d = base + out_occ + __popcll(m_occ & below);
+					st.occ_o[d] = R.oo; st.occ_d[d] = R.od; st.occ_e[d] = R.oe;
 				}
-				if (!reject) {
-					survive = true;
-					cls = m.type == POLARIS_BXDF_DIFFUSE ? 0u : (m.type == POLARIS_BXDF_CONDUCTOR ? 1u : (m.type == POLARIS_BXDF_ROUGH_CONDUCTOR ? 2u : (m.type == POLARIS_BXDF_DIELECTRIC ? 3u : 4u)));
-					a_in = in_dir; a_thr = thr; a_tint = tint; a_sf = sf; a_s0 = sample0; a_s1 = sample1;
-					a_node = (uint32_t)(m.nd - S.nodes); a_type = m.type; a_iior = m.int_ior; a_eior = m.ext_ior;
-					a_pword = path_index | (flags << 24); a_cell = cell;
-				}
+				out_ind += __popcll(m_ind);
+				out_occ += __popcll(m_occ);
+				n_hit += __popcll(__ballot(R.hit != 0));
+				n_miss += __popcll(__ballot(R.miss != 0));
+				n_emit += __popcll(__ballot(R.emit != 0));
 			}
 		}
-	}
-	// stable compaction of the survivors -> dense stream-order index j
-	const unsigned long long m_sv = __ballot(survive);
-	if (lane == 0) wave_a[wave] = __popcll(m_sv);
-	const unsigned long long mh = __ballot(n_hit != 0), mm = __ballot(n_miss != 0), me = __ballot(n_emit != 0);
-	if (lane == 0) {
-		if (mh) atomicAdd(&blk_stats[0], (uint32_t)__popcll(mh));
-		if (mm) atomicAdd(&blk_stats[1], (uint32_t)__popcll(mm));
-		if (me) atomicAdd(&blk_stats[2], (uint32_t)__popcll(me));
-	}
-	__syncthreads(); // (also: every stream load of the workgroup is done before any in-place store below)
-	uint32_t jbase = 0, S_total = 0;
-#pragma unroll
-	for (int w = 0; w < 4; w++) { if (w < (int)wave) jbase += wave_a[w]; S_total += wave_a[w]; }
-	if (survive) {
-		const uint32_t j = jbase + __popcll(m_sv & below);
-		xs[0][j] = fbits(a_in.x); xs[1][j] = fbits(a_in.y); xs[2][j] = fbits(a_in.z);
-		xs[3][j] = fbits(a_thr.x); xs[4][j] = fbits(a_thr.y); xs[5][j] = fbits(a_thr.z);
-		xs[6][j] = fbits(a_sf.p.x); xs[7][j] = fbits(a_sf.p.y); xs[8][j] = fbits(a_sf.p.z);
-		xs[9][j] = fbits(a_sf.n.x); xs[10][j] = fbits(a_sf.n.y); xs[11][j] = fbits(a_sf.n.z);
-		xs[12][j] = fbits(a_sf.uv.x); xs[13][j] = fbits(a_sf.uv.y);
-		xs[14][j] = fbits(a_tint.x); xs[15][j] = fbits(a_tint.y); xs[16][j] = fbits(a_tint.z);
-		xs[17][j] = fbits(a_s0.x); xs[18][j] = fbits(a_s0.y); xs[19][j] = fbits(a_s1.x); xs[20][j] = fbits(a_s1.y);
-		xs[21][j] = a_node; xs[22][j] = a_type; xs[23][j] = fbits(a_iior); xs[24][j] = fbits(a_eior);
-		xs[25][j] = a_pword; xs[26][j] = a_cell;
-		atomicAdd(&cls_count[cls], 1u);
-		a_node = j; // keep j in a register for the scatter below
-	}
-	__syncthreads();
-	if (survive) { // counting sort by BxDF family (order inside a family is irrelevant)
-		uint32_t cb = 0;
-#pragma unroll
-		for (uint32_t c = 0; c < 5; c++) if (c < cls) cb += cls_count[c];
-		const uint32_t k = cb + atomicAdd(&cls_cursor[cls], 1u);
-		s2j[k] = (uint16_t)a_node;
-	}
-	__syncthreads();
-
-	// ---------------------------------------------------------------- phase B
-	bool emit_ind = false, emit_occ = false;
-	float4 n_ro, n_rd, n_thr, n_oo, n_od, n_oe;
-	uint32_t j = 0;
-	if (tid < S_total) {
-		j = s2j[tid];
-		const f3 in_dir = mk3(ibits(xs[0][j]), ibits(xs[1][j]), ibits(xs[2][j]));
-		const f3 thr = mk3(ibits(xs[3][j]), ibits(xs[4][j]), ibits(xs[5][j]));
-		Surf sf;
-		sf.p = mk3(ibits(xs[6][j]), ibits(xs[7][j]), ibits(xs[8][j]));
-		sf.n = mk3(ibits(xs[9][j]), ibits(xs[10][j]), ibits(xs[11][j]));
-		sf.uv = {ibits(xs[12][j]), ibits(xs[13][j])};
-		const f3 tint = mk3(ibits(xs[14][j]), ibits(xs[15][j]), ibits(xs[16][j]));
-		const f2 sample0 = {ibits(xs[17][j]), ibits(xs[18][j])}, sample1 = {ibits(xs[19][j]), ibits(xs[20][j])};
-		const Mat m = {S.nodes + xs[21][j], xs[22][j], ibits(xs[23][j]), ibits(xs[24][j])};
-		const uint32_t pword = xs[25][j], cell = xs[26][j];
-
-		f3 out_dir = splat(0.0f);
-		float bxdf_pdf = 1.0f, bxdf_weight = 1.0f;
-		const f3 bxdf_val = bxdf_sample(sf, m, S, sample0, in_dir, out_dir, bxdf_pdf);
-		const float displace = pm_sign(dot(sf.n, out_dir));
-		const f3 ind_origin = sf.p + (sf.n * displace) * kEps;
-		const f3 occ_origin = sf.p + sf.n * kEps;
-		f3 e_dir = splat(0.0f), e_rad = splat(0.0f);
-		float e_pdf = 0.0f, sel_pdf = 0.0f, e_weight = 0.0f, e_dist = 0.0f;
-		const PolarisEmissive *em = nullptr;
-		if (S.num_emissives > 0) {
-			sel_pdf = pm_rcp((float)(int)S.num_emissives);
-			const int ei = pm_clampi((int)(sample1.x * (int)S.num_emissives), 0, (int)S.num_emissives - 1);
-			em = S.emissives + ei;
-			const LightSample L = light_sample(sf, em, S, sample1);
-			e_dir = L.dir; e_rad = L.radiance; e_pdf = L.pdf; e_dist = L.dist;
+		if (lane == 0) {
+			st.cnt_ray[chunk] = out_ind;
+			st.cnt_occ[chunk] = out_occ;
+			st.wg_stat[chunk] = n_hit | (n_miss << 10) | (n_emit << 20);
 		}
-		const float n_dot_e = pm_max(0.0f, dot(sf.n, e_dir));
-		const bool want_nee = maxcomp(e_rad) > 0.0f && e_pdf > 0.0f && n_dot_e > 0.0f;
-		if (em) {
-			float bxdf_e_pdf;
-			f3 bxdf_e_val;
-			bxdf_pdf_eval(sf, m, S, in_dir, e_dir, want_nee, bxdf_e_pdf, bxdf_e_val);
-			e_weight = (e_pdf * e_pdf) / (e_pdf * e_pdf + bxdf_e_pdf * bxdf_e_pdf);
-			const float e_bxdf_pdf = light_pdf(sf, em, S, out_dir);
-			bxdf_weight = (bxdf_pdf * bxdf_pdf) / (bxdf_pdf * bxdf_pdf + e_bxdf_pdf * e_bxdf_pdf);
-			if (want_nee) {
-				e_rad = e_rad * (e_weight * bxdf_e_val * thr * n_dot_e / (e_pdf * sel_pdf));
-				if (maxcomp(e_rad) > 0.0f) {
-					emit_occ = true;
-					n_oo = make_float4(occ_origin.x, occ_origin.y, occ_origin.z, e_dist - kLightEps);
-					n_od = make_float4(e_dir.x, e_dir.y, e_dir.z, ibits((int)cell));
-					n_oe = make_float4(e_rad.x, e_rad.y, e_rad.z, 0.0f);
-				}
-			}
-		}
-		if ((m.type & (POLARIS_BXDF_CONDUCTOR | POLARIS_BXDF_DIELECTRIC)) != 0) bxdf_weight = 1.0f;
-		const f3 tp = bxdf_weight * bxdf_val * tint * pm_fabs(dot(sf.n, out_dir));
-		if (maxcomp(tp) > 0.0f && bxdf_pdf > 0.0f && !A.last_bounce) {
-			const f3 nt = thr * tp / bxdf_pdf;
-			emit_ind = true;
-			n_ro = make_float4(ind_origin.x, ind_origin.y, ind_origin.z, kFltMax);
-			n_rd = make_float4(out_dir.x, out_dir.y, out_dir.z, ibits((int)pword));
-			n_thr = make_float4(nt.x, nt.y, nt.z, 0.0f);
-		}
-		flag_ind[j] = emit_ind ? 1 : 0;
-		flag_occ[j] = emit_occ ? 1 : 0;
-	}
-	__syncthreads();
-	// ranks in dense stream order j (thread t plays j = t)
-	const bool fi = tid < S_total && flag_ind[tid] != 0, fo = tid < S_total && flag_occ[tid] != 0;
-	const unsigned long long m_ind = __ballot(fi), m_occ = __ballot(fo);
-	if (lane == 0) { wave_b[wave] = __popcll(m_ind); wave_c[wave] = __popcll(m_occ); }
-	__syncthreads();
-	uint32_t b_ind = 0, b_occ = 0, tot_ind = 0, tot_occ = 0;
-#pragma unroll
-	for (int w = 0; w < 4; w++) {
-		if (w < (int)wave) { b_ind += wave_b[w]; b_occ += wave_c[w]; }
-		tot_ind += wave_b[w]; tot_occ += wave_c[w];
-	}
-	if (tid < S_total) {
-		rank_ind[tid] = (uint16_t)(b_ind + __popcll(m_ind & below));
-		rank_occ[tid] = (uint16_t)(b_occ + __popcll(m_occ & below));
-	}
-	__syncthreads();
-	if (emit_ind) {
-		const size_t d = base + rank_ind[j];
-		st.ray_o[d] = n_ro; st.ray_d[d] = n_rd; st.thr[d] = n_thr;
-	}
-	if (emit_occ) {
-		const size_t d = base + rank_occ[j];
-		st.occ_o[d] = n_oo; st.occ_d[d] = n_od; st.occ_e[d] = n_oe;
-	}
-	if (tid == 0) {
-		st.cnt_ray[blockIdx.x] = tot_ind;
-		st.cnt_occ[blockIdx.x] = tot_occ;
-		// no global atomics here: 32 Ki workgroups adding to three shared counters serialise at the
-		// memory side (~80 atomics/us on one address) and were, measured, the whole cost of this kernel
-		st.wg_stat[blockIdx.x] = blk_stats[0] | (blk_stats[1] << 10) | (blk_stats[2] << 20);
-		(void)stats;
 	}
 }
 

@@ -86,7 +86,10 @@ struct polaris_hip_tracer {
 	int opt_time_kernels = 0;
 	int opt_trace_wgs_per_cu = 0; // 0 = auto (what the LDS stack admits)
 	int opt_stage_lds = 1;    // k_shade stages material nodes / lights / texture metadata in LDS when they fit
-	int opt_shade_sorted = 0; // 1 = two-phase shade with an LDS sort by BxDF family (measured: no gain), 0 = straight through
+	int opt_shade_wave = 1;   // 1 = persistent wave-per-chunk shading (k_shade_wave), 0 = one workgroup per chunk (k_shade)
+	int opt_shade_wgs_per_cu = 8;
+	int opt_shade_wave_from = -1; // first bounce shaded by k_shade_wave; -1 = where Russian roulette starts thinning the
+	                              // chunks (min_bounces_for_rr); earlier, denser bounces use k_shade
 	int opt_traversal = 1; // 1 = persistent waves with lane refill (k_trace), 0 = one ray per lane (k_intersect/k_occlusion)
 
 	// per-kernel timing (option time_kernels)
@@ -268,10 +271,12 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 		A.last_bounce = (b + 1 == B) ? 1 : 0;
 		{
 			Timed t(h, "shade", q);
-			if (h->opt_shade_sorted)
-				hipLaunchKernelGGL(k_shade_sorted, dim3(wgs), dim3(WG), 0, q, P.st, h->scene, A, h->d_stats);
-			else
-				hipLaunchKernelGGL(k_shade, dim3(wgs), dim3(WG), 0, q, P.st, h->scene, A, h->d_stats);
+			if (h->opt_shade_wave && (int)b >= (h->opt_shade_wave_from >= 0 ? h->opt_shade_wave_from : (int)r->min_bounces_for_rr)) {
+				const uint32_t grid = std::min<uint32_t>(wgs, (uint32_t)h->num_cus * (uint32_t)std::max(1, h->opt_shade_wgs_per_cu));
+				hipLaunchKernelGGL(k_shade_wave, dim3(grid), dim3(WG), 0, q, P.st, h->scene, A, wgs);
+			} else {
+				hipLaunchKernelGGL(k_shade, dim3(wgs), dim3(WG), 0, q, P.st, h->scene, A);
+			}
 		}
 		{
 			Timed t(h, "scan", q);
@@ -476,7 +481,9 @@ int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value
 	else if (k == "packet_shadow") h->opt_packet_shadow = (int)std::max<int64_t>(0, std::min<int64_t>(value, POLARIS_MAX_BOUNCES));
 	else if (k == "time_kernels") h->opt_time_kernels = value != 0;
 	else if (k == "traversal") h->opt_traversal = value != 0;
-	else if (k == "shade_sorted") h->opt_shade_sorted = value != 0;
+	else if (k == "shade_wave") h->opt_shade_wave = value != 0;
+	else if (k == "shade_wave_from") h->opt_shade_wave_from = (int)std::max<int64_t>(-1, std::min<int64_t>(value, POLARIS_MAX_BOUNCES));
+	else if (k == "shade_wgs_per_cu") h->opt_shade_wgs_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(value, 64));
 	else if (k == "stage_lds") h->opt_stage_lds = value != 0;
 	else if (k == "overlap") h->opt_overlap = (int)std::max<int64_t>(1, std::min<int64_t>(value, polaris_hip_tracer::kMaxPipes));
 	else if (k == "trace_wgs_per_cu") h->opt_trace_wgs_per_cu = (int)std::max<int64_t>(0, std::min<int64_t>(value, 64));

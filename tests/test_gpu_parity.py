@@ -70,7 +70,8 @@ def test_hip_vs_oracle_exact_and_batched(built, oracle, name):
                 ({"exact_accumulate": 1, "packet_primary": 0}, True), ({}, False),
                 ({"samples_per_batch": 4}, False), ({"samples_per_batch": 1, "overlap": 3}, False),
                 ({"samples_per_batch": 2, "overlap": 1, "traversal": 0}, False),
-                ({"exact_accumulate": 1, "shade_sorted": 1}, True), ({"shade_sorted": 1, "samples_per_batch": 3}, False))
+                ({"exact_accumulate": 1, "shade_wave": 0}, True), ({"exact_accumulate": 1, "shade_wave_from": 0}, True),
+                ({"shade_wave": 0, "stage_lds": 0, "samples_per_batch": 3}, False), ({"shade_wave_from": 1, "samples_per_batch": 2}, False))
     for opts, exact in variants:
         tr = make_hip_tracer(sc, W, H, **opts)
         try:
