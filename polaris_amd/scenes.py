@@ -567,6 +567,45 @@ def instanced_cubes(n_side=3, aspect=1.0, spacing=2.5) -> Scene:
     return sc
 
 
+def rotation_y(a):
+    c, s_ = math.cos(a), math.sin(a)
+    m = np.eye(4)
+    m[0, 0], m[0, 2], m[2, 0], m[2, 2] = c, s_, -s_, c
+    return m
+
+
+def scaling(sx, sy, sz):
+    return np.diag([sx, sy, sz, 1.0])
+
+
+def transformed_instances(aspect=1.0) -> Scene:
+    """Instances with rotation and NON-UNIFORM SCALE, one of them carrying an emissive triangle
+    pair: exercises the ray transform on instance entry / exit (intersect.cl:239-252, 330-335), the
+    comparison of hit distances across differently scaled instance spaces and reference quirk
+    a-9(4) (emissive normals and pdf edges go through the point transform of the INVERSE matrix)."""
+    mt = MaterialTable()
+    a = mt.diffuse((0.7, 0.5, 0.2))
+    b = mt.mix(mt.diffuse((0.2, 0.4, 0.7)), mt.conductor((0.9, 0.9, 0.9)), 0.5)
+    floor = mt.diffuse((0.6, 0.6, 0.6))
+    light = mt.emissive((6, 6, 5), 1.5)
+    bg = mt.diffuse((0.2, 0.25, 0.35))
+    cube = box((-0.5, -0.5, -0.5), (0.5, 0.5, 0.5), a)
+    ball = uv_sphere((0, 0, 0), 0.5, b, n_lat=8, n_lon=10)
+    panel = merge([quad((-0.5, 0, -0.5), (0.5, 0, -0.5), (0.5, 0, 0.5), (-0.5, 0, 0.5), light)])
+    ground = quad((-6, 0, -6), (-6, 0, 6), (6, 0, 6), (6, 0, -6), floor)
+    insts = [
+        (3, np.eye(4)),
+        (0, translation((-1.5, 0.8, 0)) @ rotation_y(0.6) @ scaling(1.0, 1.6, 0.7)),
+        (0, translation((1.4, 0.4, -0.8)) @ rotation_y(-1.1) @ scaling(0.8, 0.8, 0.8)),
+        (1, translation((0.1, 0.9, 0.6)) @ scaling(1.8, 0.9, 1.2)),
+        (1, translation((-0.4, 0.35, 2.0)) @ rotation_y(2.0) @ scaling(0.7, 0.7, 0.7)),
+        (2, translation((0.0, 3.5, 0.0)) @ rotation_y(0.4) @ scaling(2.5, 1.0, 1.5)),
+    ]
+    sc = compile_scene([cube, ball, panel, ground], insts, mt, scene_diffuse=bg, name="transformed-instances")
+    sc.set_camera(eye=(0, 2.4, 6.0), look=(0, 0.8, 0), fov=0.75, aspect=aspect)
+    return sc
+
+
 def textured_materials_scene(aspect=1.0) -> Scene:
     """A small scene touching every material operator and texture format (mix, mixMap, bumpMap,
     normalMap, disperse; L8, L32F, RGBA8, RGBA32F) -- parity coverage, not a benchmark."""
@@ -685,6 +724,7 @@ SCENES = {
     "sphere": sphere_scene,
     "cubes": lambda aspect=1.0: instanced_cubes(3, aspect),
     "materials": textured_materials_scene,
+    "transformed": transformed_instances,
     "instanced": lambda aspect=1.0: instanced_stress(32, aspect=aspect),
     "instanced-small": lambda aspect=1.0: instanced_stress(6, 9, 10, aspect=aspect),
     "terrain": lambda aspect=1.0: unique_stress(708, aspect),

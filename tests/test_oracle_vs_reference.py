@@ -11,7 +11,7 @@ import pytest
 from conftest import bits
 
 
-SCENES = ["cornell-diffuse", "cornell", "sphere", "cubes", "materials"]
+SCENES = ["cornell-diffuse", "cornell", "sphere", "cubes", "materials", "transformed"]
 
 
 @pytest.mark.parametrize("name", SCENES)

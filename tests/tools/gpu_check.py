@@ -8,7 +8,7 @@ from oracle import pybind as ob
 
 orc = ob.Oracle("oracle")
 W = H = int(os.environ.get("RES", "64")); spp = int(os.environ.get("SPP", "4")); B = 5
-for name in ["cornell-diffuse", "cornell", "sphere", "cubes", "materials"]:
+for name in ["cornell-diffuse", "cornell", "sphere", "cubes", "materials", "transformed"]:
     sc = scenes.SCENES[name]()
     seeds = scenes.make_seeds(spp, B)
     want, ws, wt = orc.trace(sc, ob.make_request(W, H, spp=spp, bounces=B), seeds, tap_sample=0)

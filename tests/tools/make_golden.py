@@ -26,7 +26,8 @@ CASES = [
     ("sphere_env_32", "sphere", 32, 32, 4, 5, 3, 0, 32),
     ("cubes_instanced_32", "cubes", 32, 32, 4, 5, 3, 0, 32),
     ("materials_32", "materials", 32, 32, 4, 5, 3, 0, 32),
-    ("materials_norr_1bounce", "materials", 24, 16, 3, 1, 2, 0, 16),  # rr disabled: minRR = bounces+1 (cmd/render.go:42-45)
+    ("materials_norr_1bounce", "materials", 24, 16, 3, 1, 2, 0, 16),
+    ("transformed_instances_32", "transformed", 32, 24, 4, 5, 3, 0, 24),  # rotated / non-uniformly scaled instances, instanced light  # rr disabled: minRR = bounces+1 (cmd/render.go:42-45)
 ]
 
 
