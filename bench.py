@@ -79,6 +79,8 @@ def main() -> None:
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--save-png", default="")
     ap.add_argument("--opt", action="append", default=[], help="tracer option key=value (polaris_hip_set_option)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to test the N>1 flow on one GPU)")
+    ap.add_argument("--same-device", action="store_true", help="testing aid: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--emulate-rank", default="", help="R/N: on ONE GPU, trace only the row block rank R of N would own "
                     "(tuning aid for the strong-scaling path; not a valid bench line)")
     args = ap.parse_args()
@@ -95,8 +97,13 @@ def main() -> None:
     if world > 1:
         import torch.distributed as dist
 
+        if args.same_device:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the tracer has no CPU fallback")
     dev = torch.device("cuda", local_rank)
@@ -151,7 +158,14 @@ def main() -> None:
             tr.MergeOutput(tr, make_req(block_y, block_h))  # primary merges its own block (default.go:191)
         else:
             tr.export_block(make_req(block_y, block_h), strip.data_ptr())
-            dist.gather(strip, gather_list, dst=0)  # the path's one exchange step
+            if args.backend == "nccl":
+                dist.gather(strip, gather_list, dst=0)  # the path's one exchange step
+            else:  # gloo test mode: stage through host memory
+                host = [torch.empty((rows[i] * W, 4), dtype=torch.float32) for i in range(world)] if rank == 0 else None
+                dist.gather(strip.cpu(), host, dst=0)
+                if rank == 0:
+                    for i in range(world):
+                        gather_list[i].copy_(host[i])
             if rank == 0:
                 torch.cuda.synchronize()
                 y = 0
@@ -185,8 +199,9 @@ def main() -> None:
             ms, n = tr.kernel_ms(name)
             kt[name] = (ms, n)
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    cnt = torch.tensor([totals[k] for k in sorted(totals)], dtype=torch.int64, device=dev)
+    rdev = dev if args.backend == "nccl" else torch.device("cpu")
+    el = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
+    cnt = torch.tensor([totals[k] for k in sorted(totals)], dtype=torch.int64, device=rdev)
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
@@ -224,7 +239,7 @@ def main() -> None:
         if kt:
             mine = {k: totals[k] // args.steps for k in totals}     # per-frame counters of rank 0
             tr.set_option("overlap", 1)
-            frame(False)
+            tr.Trace(make_req(block_y, block_h), seeds)   # local to rank 0: no collective in here
             iso = {name: tr.kernel_ms(name) for name in KERNELS[:-2]}
             alg = kernel_algorithmic_bytes(mine)
             dom = max(("generate", "intersect_packet", "intersect", "shade", "occlusion"), key=lambda k: iso[k][0])
