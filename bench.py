@@ -143,8 +143,11 @@ def main() -> None:
         r.exposure, r.seed, r.accumulated_samples = 1.2, 0, 0
         return r
 
-    strip = torch.empty((block_h * W, 4), dtype=torch.float32, device=dev)
-    gather_list = [torch.empty((rows[i] * W, 4), dtype=torch.float32, device=dev) for i in range(world)] if rank == 0 and world > 1 else None
+    # RCCL gather wants equally sized pieces: strips are padded to the tallest block (the naive
+    # scheduler gives the remainder rows to tracer 0, tracer/scheduler.go:101-103)
+    max_rows = max(rows)
+    strip = torch.zeros((max_rows * W, 4), dtype=torch.float32, device=dev)
+    gather_list = [torch.empty((max_rows * W, 4), dtype=torch.float32, device=dev) for i in range(world)] if rank == 0 and world > 1 else None
     totals = {k: 0 for k in ("primary_rays", "indirect_rays", "occlusion_rays", "shaded_hits", "shaded_misses", "emitter_hits", "unoccluded")}
 
     def frame(count: bool):
@@ -161,7 +164,7 @@ def main() -> None:
             if args.backend == "nccl":
                 dist.gather(strip, gather_list, dst=0)  # the path's one exchange step
             else:  # gloo test mode: stage through host memory
-                host = [torch.empty((rows[i] * W, 4), dtype=torch.float32) for i in range(world)] if rank == 0 else None
+                host = [torch.empty((max_rows * W, 4), dtype=torch.float32) for i in range(world)] if rank == 0 else None
                 dist.gather(strip.cpu(), host, dst=0)
                 if rank == 0:
                     for i in range(world):

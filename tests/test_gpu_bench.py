@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-SMALL = ["--width", "128", "--height", "96", "--spp", "8", "--steps", "2", "--warmup", "1"]
+SMALL = ["--width", "128", "--height", "97", "--spp", "8", "--steps", "2", "--warmup", "1"]  # 97 rows: uneven blocks [49, 48]
 
 
 def test_bench_single_gpu_line(built):
@@ -49,4 +49,4 @@ def test_bench_two_ranks_complete(built):
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
-    assert "row blocks [48, 48]" in d["config"]["workload"]
+    assert "row blocks [49, 48]" in d["config"]["workload"]
