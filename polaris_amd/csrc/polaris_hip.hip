@@ -67,7 +67,7 @@ struct polaris_hip_tracer {
 		std::vector<DevBuf> bufs;
 		hipEvent_t done = nullptr; // recorded after the pipe's last resolve
 	};
-	static constexpr int kMaxPipes = 4;
+	static constexpr int kMaxPipes = 8;
 	Pipe pipe[kMaxPipes];
 	int opt_overlap = 4; // number of pipelines used (1 = no overlap)
 	uint32_t *d_seeds = nullptr;
