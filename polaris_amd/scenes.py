@@ -475,7 +475,7 @@ def checker_rgba8(n=64, cells=8, a=(230, 230, 230), b=(60, 60, 70)):
     return img
 
 
-def cornell_box(variant="layered", aspect=1.0) -> Scene:
+def cornell_box(variant="layered", aspect=1.0, compiler="numpy") -> Scene:
     """Cornell box from the classic measured geometry (dimensions of the Cornell Program of
     Computer Graphics data set, scaled by 1/555 so the box spans ~[0,1]^3).
 
@@ -522,7 +522,14 @@ def cornell_box(variant="layered", aspect=1.0) -> Scene:
     else:
         parts.append(box((130 * s, 0, 65 * s), (130 * s + 165 * s, 165 * s, 65 * s + 165 * s), white, rot_y=0.29))
     mesh = merge(parts)
-    sc = compile_scene([mesh], [(0, np.eye(4))], mt, name=f"cornell-{variant}")
+    if compiler == "reference":
+        # the C++ restatement of the reference's own compiler (bvh_builder.go SAH on up to 1024
+        # candidate planes per axis, leaves of <= 10 triangles): the BVH `polaris render` would upload
+        from . import host_api
+
+        sc = host_api.compile_scene([mesh], [(0, np.eye(4))], mt, min_leaf=10, name=f"cornell-{variant}-refbvh")
+    else:
+        sc = compile_scene([mesh], [(0, np.eye(4))], mt, name=f"cornell-{variant}")
     sc.set_camera(eye=(278 * s, 273 * s, -800 * s), look=(278 * s, 273 * s, 0), fov=0.6911, aspect=aspect)
     return sc
 
@@ -721,6 +728,7 @@ def make_seeds(spp: int, bounces: int, base: int = 0xC0FFEE) -> np.ndarray:
 SCENES = {
     "cornell": lambda aspect=1.0: cornell_box("layered", aspect),
     "cornell-diffuse": lambda aspect=1.0: cornell_box("diffuse", aspect),
+    "cornell-refbvh": lambda aspect=1.0: cornell_box("layered", aspect, compiler="reference"),
     "sphere": sphere_scene,
     "cubes": lambda aspect=1.0: instanced_cubes(3, aspect),
     "materials": textured_materials_scene,
