@@ -126,15 +126,15 @@ def main() -> None:
 
     tr = HipTracer(f"hip-{rank}", local_rank)
     tr.Init()
-    tr.UpdateState(UpdateMode.Synchronous, ChangeType.FrameDimensions, (W, H))
-    tr.UpdateState(UpdateMode.Synchronous, ChangeType.SceneData, sc)
-    tr.UpdateState(UpdateMode.Synchronous, ChangeType.CameraData, sc)
     if args.samples_per_batch:
         tr.set_option("samples_per_batch", args.samples_per_batch)
     tr.set_option("time_kernels", 0 if args.no_kernel_timers else 1)
-    for kv in args.opt:
+    for kv in args.opt:  # before the upload: some options shape the scene layout
         k, v = kv.split("=")
         tr.set_option(k, int(v))
+    tr.UpdateState(UpdateMode.Synchronous, ChangeType.FrameDimensions, (W, H))
+    tr.UpdateState(UpdateMode.Synchronous, ChangeType.SceneData, sc)
+    tr.UpdateState(UpdateMode.Synchronous, ChangeType.CameraData, sc)
 
     def make_req(by, bh):
         r = T.BlockRequest()

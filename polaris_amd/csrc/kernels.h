@@ -33,7 +33,7 @@ constexpr int WG = 256;            // threads per workgroup (4 wave64)
 constexpr int kExitMarker = (int)0x80000000;
 
 struct PairNode { float4 lo0, hi0, lo1, hi1; };  // .w of lo0/lo1 carry the child refs (int bits)
-struct TriRec { float4 v0, e1, e2; };             // v0.w carries the DFS rank (uint bits)
+struct TriRec { float4 v0, e1, e2; };             // v0.w = DFS rank, e1.w = scene triangle index (uint bits)
 struct InstRec { float4 r0, r1, r2; int4 meta; }; // meta.x = root ref, meta.y = rank
 
 constexpr int kLdsTopNodes = 128; // pair records (8 KB) of the top of the tree staged in LDS per workgroup
@@ -185,7 +185,7 @@ __device__ __forceinline__ bool traverse(const BvhDev &B, f3 O, f3 D, float maxD
 					const uint32_t trank = (uint32_t)fbits(T.v0.w);
 					const bool closer = tt < best.t;
 					const bool tie = tt == best.t && best.tri >= 0 && (irank < best.irank || (irank == best.irank && trank < best.trank));
-					if (closer || tie) { best.t = tt; best.u = u; best.v = v; best.tri = t; best.inst = inst; best.irank = irank; best.trank = trank; }
+					if (closer || tie) { best.t = tt; best.u = u; best.v = v; best.tri = fbits(T.e1.w); best.inst = inst; best.irank = irank; best.trank = trank; }
 				}
 			}
 		}
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(WG) void k_trace(Streams st, BvhDev B, uint32_t num
 						const uint32_t trank = (uint32_t)fbits(T.v0.w);
 						const bool closer = tt < best.t;
 						const bool tie = tt == best.t && best.tri >= 0 && (irank < best.irank || (irank == best.irank && trank < best.trank));
-						if (closer || tie) { best.t = tt; best.u = u; best.v = v; best.tri = t; best.inst = inst; best.irank = irank; best.trank = trank; }
+						if (closer || tie) { best.t = tt; best.u = u; best.v = v; best.tri = fbits(T.e1.w); best.inst = inst; best.irank = irank; best.trank = trank; }
 					}
 				}
 				if (ANY_HIT && occluded) finish(true);
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(WG) void k_trace_packet(Streams st, BvhDev B, float
 										const uint32_t trank = (uint32_t)fbits(T.v0.w);
 										const bool closer = tt < best.t;
 										const bool tie = tt == best.t && best.tri >= 0 && (irank < best.irank || (irank == best.irank && trank < best.trank));
-										if (closer || tie) { best.t = tt; best.u = u; best.v = v; best.tri = t; best.inst = inst; best.irank = irank; best.trank = trank; }
+										if (closer || tie) { best.t = tt; best.u = u; best.v = v; best.tri = fbits(T.e1.w); best.inst = inst; best.irank = irank; best.trank = trank; }
 									}
 								}
 							}

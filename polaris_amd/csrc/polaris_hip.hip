@@ -85,6 +85,7 @@ struct polaris_hip_tracer {
 	int opt_packet_primary = 1; // wave-packet traversal (k_trace_packet) for bounce 0
 	int opt_time_kernels = 0;
 	int opt_trace_wgs_per_cu = 0; // 0 = auto (what the LDS stack admits)
+	int opt_max_leaf_tris = 2;    // subdivide bigger triangle leaves at upload (0 = keep the caller's leaves)
 	int opt_stage_lds = 1;    // k_shade stages material nodes / lights / texture metadata in LDS when they fit
 	int opt_shade_wave = 1;   // 1 = persistent wave-per-chunk shading (k_shade_wave), 0 = one workgroup per chunk (k_shade)
 	int opt_shade_wgs_per_cu = 8;
@@ -424,7 +425,11 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 	std::lock_guard<std::mutex> lk(h->mu);
 	if (!sc) return fail(h, POLARIS_E_BAD_ARGUMENT, "scene view is null");
 	SceneLayout L;
-	const std::string err = build_layout(*sc, L);
+	std::string err = build_layout(*sc, L, h->opt_max_leaf_tris);
+	if (err == "@retry-without-subdivision") { // the deeper tree would not fit the traversal stack
+		L = SceneLayout();
+		err = build_layout(*sc, L, 0);
+	}
 	if (!err.empty()) return fail(h, POLARIS_E_BAD_SCENE, "%s", err.c_str());
 	HIP_TRY(h, hipSetDevice(h->device));
 	HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -487,6 +492,7 @@ int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value
 	else if (k == "stage_lds") h->opt_stage_lds = value != 0;
 	else if (k == "overlap") h->opt_overlap = (int)std::max<int64_t>(1, std::min<int64_t>(value, polaris_hip_tracer::kMaxPipes));
 	else if (k == "trace_wgs_per_cu") h->opt_trace_wgs_per_cu = (int)std::max<int64_t>(0, std::min<int64_t>(value, 64));
+	else if (k == "max_leaf_tris") h->opt_max_leaf_tris = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20)); // next upload
 	else return fail(h, POLARIS_E_BAD_ARGUMENT, "unknown option '%s'", key);
 	return POLARIS_OK;
 }

@@ -12,7 +12,7 @@
 //     kernels/intersect.cl:296-298) plus a tagged reference per child:
 //         ref >= 0  -> inner node index          ref < 0 -> ~leaf node index
 //   * LeafInfo[node] = (ldata, rdata) of a leaf: 8 B fetch when a leaf is popped.
-//   * Tri[t] = {v0 | rank, e01 = v1 - v0, e02 = v2 - v0}: the two edge subtractions of
+//   * Tri[slot] = {v0 | rank, e01 = v1 - v0 | scene triangle index, e02 = v2 - v0}: the two edge subtractions of
 //     Moeller-Trumbore are hoisted to upload (one IEEE subtraction each, so bit-identical to
 //     intersect.cl:253-254).  rank = position of the triangle in the reference's left-first
 //     depth-first traversal order of its mesh BVH; the closest-hit kernel uses it to break exact
@@ -21,6 +21,8 @@
 //     read 3 float4), tagged root reference, and the instance's rank in top-level DFS order.
 #pragma once
 
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -32,10 +34,11 @@ namespace pol {
 
 struct PairNodeH { float lo0[3]; int32_t ref0; float hi0[3]; int32_t pad0; float lo1[3]; int32_t ref1; float hi1[3]; int32_t pad1; };
 struct LeafInfoH { int32_t ldata, rdata; };
-struct TriH { float v0[3]; uint32_t rank; float e1[3]; uint32_t pad1; float e2[3]; uint32_t pad2; };
+struct TriH { float v0[3]; uint32_t rank; float e1[3]; uint32_t orig; float e2[3]; uint32_t pad2; };
 struct InstH { float r0[4], r1[4], r2[4]; int32_t root_ref; uint32_t rank; uint32_t pad[2]; };
 static_assert(sizeof(PairNodeH) == 64 && sizeof(TriH) == 48 && sizeof(InstH) == 64, "layout");
 
+constexpr float kSplitCost = 1.0f;  // cost of one added pair-of-boxes step, in triangle tests (leaf subdivision)
 constexpr int kTraversalStack = 32; // entries per ray, == BVH_MAX_STACK_SIZE (intersect.cl:4)
 
 struct SceneLayout {
@@ -50,7 +53,16 @@ struct SceneLayout {
 inline bool is_leaf(const PolarisBvhNode &n) { return n.ldata <= 0; }
 
 // Returns "" on success, otherwise a description of the first inconsistency.
-inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out) {
+//
+// max_leaf_tris > 0: triangle leaves holding more triangles than that are subdivided at upload
+// (surface-area-heuristic splits of the leaf's own triangles, where a split pays).  The reference's boxes, down to and including its
+// leaves, are kept bit for bit, so a triangle is still only ever tested when the reference's
+// traversal would have reached its leaf; the ADDED boxes only cull inside such a leaf and are
+// inflated by 2^-15 of the scene's extent in the mesh's object space -- four orders of magnitude
+// above the rounding of the slab test for any ray starting within ~100 scene radii -- so they can
+// never hide a triangle the reference would have hit.  Results are unchanged (parity tests run
+// with and without); only the number of Moeller-Trumbore tests per ray drops.
+inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out, int max_leaf_tris = 0) {
 	const uint32_t NN = sc.num_bvh_nodes, NT = sc.num_triangles, NI = sc.num_mesh_instances;
 	if (!sc.bvh_nodes || NN == 0) return "scene has no BVH nodes";
 	if (!sc.mesh_instances || NI == 0) return "scene has no mesh instances";
@@ -101,19 +113,23 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out) {
 		return "scene diffuse material index out of range";
 
 	// ---- BVH: structure, ranks, stack depth ----------------------------------------------
-	out.pairs.assign(NN, PairNodeH{});
-	out.leaves.assign(NN, LeafInfoH{0, 0});
+	// Pass 1 walks the caller's tree: validation, DFS ranks, which leaves are reachable.
+	// Pass 2 walks the tree the kernels use (the same one, or the one with subdivided leaves)
+	// and emits pair/leaf records and the exact stack depth.
 	out.insts.assign(NI, InstH{});
-	out.tris.assign(NT, TriH{});
-	std::vector<uint8_t> seen(NN, 0);
-	auto ref_of = [&](int32_t idx) { return is_leaf(sc.bvh_nodes[idx]) ? ~idx : idx; };
+	std::vector<PolarisBvhNode> nodes(sc.bvh_nodes, sc.bvh_nodes + NN);
+	uint32_t n_nodes = NN, n_slots = NT;
+	std::vector<uint32_t> tri_rank(NT, 0xFFFFFFFFu);
+	std::vector<uint32_t> slot_src;          // triangle slot of the kernels -> scene triangle (pass 2)
+	std::vector<int32_t> leaf_root(NN, -1);  // reachable triangle leaf -> root of its mesh BVH
+	std::vector<uint8_t> seen;
+	auto ref_of = [&](int32_t idx) { return is_leaf(nodes[idx]) ? ~idx : idx; };
 
 	// iterative left-first DFS from `root`; level = 0 top tree, 1 bottom tree.  `need` tracks the
 	// number of stack entries a traversal can hold at a node (one pending sibling per level).
 	struct Item { int32_t node; int depth; };
 	uint32_t next_inst_rank = 0;
-	std::vector<uint32_t> tri_rank(NT, 0xFFFFFFFFu);
-	int top_max = 0;
+	int top_max = 0, pass = 1;
 	std::vector<int> inst_entry_depth(NI, 0);
 	std::string err;
 	auto walk = [&](int32_t root, int level, uint32_t &rank_counter, int &max_depth) -> bool {
@@ -122,14 +138,14 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out) {
 		while (!st.empty()) {
 			Item it = st.back();
 			st.pop_back();
-			if (it.node < 0 || (uint32_t)it.node >= NN) { err = "BVH child index out of range"; return false; }
+			if (it.node < 0 || (uint32_t)it.node >= n_nodes) { err = "BVH child index out of range"; return false; }
 			if (seen[it.node] && level == 0) { err = "BVH node " + std::to_string(it.node) + " reachable twice"; return false; }
 			seen[it.node] = 1;
 			if (it.depth > max_depth) max_depth = it.depth;
 			if (it.depth > 4 * kTraversalStack) { err = "BVH too deep"; return false; }
-			const PolarisBvhNode &n = sc.bvh_nodes[it.node];
+			const PolarisBvhNode &n = nodes[it.node];
 			if (is_leaf(n)) {
-				out.leaves[it.node] = {n.ldata, n.rdata};
+				if (pass == 2) out.leaves[it.node] = {n.ldata, n.rdata};
 				if (n.rdata == 0) {
 					if (level != 0) { err = "instance leaf inside a mesh BVH (node " + std::to_string(it.node) + ")"; return false; }
 					const uint32_t inst = (uint32_t)(-(int64_t)n.ldata);
@@ -140,17 +156,22 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out) {
 					if (level != 1) { err = "triangle leaf in the top-level BVH (node " + std::to_string(it.node) + ")"; return false; }
 					if (n.rdata < 0) { err = "negative triangle count"; return false; }
 					const uint64_t first = (uint64_t)(-(int64_t)n.ldata);
-					if (first + (uint64_t)n.rdata > NT) { err = "leaf triangle range out of bounds"; return false; }
-					for (uint64_t t = first; t < first + (uint64_t)n.rdata; t++)
-						if (tri_rank[t] == 0xFFFFFFFFu) tri_rank[t] = rank_counter++;
+					if (first + (uint64_t)n.rdata > n_slots) { err = "leaf triangle range out of bounds"; return false; }
+					if (pass == 1) {
+						if (leaf_root[it.node] < 0) leaf_root[it.node] = root;
+						for (uint64_t t = first; t < first + (uint64_t)n.rdata; t++)
+							if (tri_rank[t] == 0xFFFFFFFFu) tri_rank[t] = rank_counter++;
+					}
 				}
 			} else {
 				if (n.rdata <= 0) { err = "inner node " + std::to_string(it.node) + " has a non-positive right child"; return false; }
-				if ((uint32_t)n.ldata >= NN || (uint32_t)n.rdata >= NN) { err = "BVH child index out of range"; return false; }
-				PairNodeH &p = out.pairs[it.node];
-				const PolarisBvhNode &l = sc.bvh_nodes[n.ldata], &r = sc.bvh_nodes[n.rdata];
-				memcpy(p.lo0, l.min, 12); memcpy(p.hi0, l.max, 12); p.ref0 = ref_of(n.ldata);
-				memcpy(p.lo1, r.min, 12); memcpy(p.hi1, r.max, 12); p.ref1 = ref_of(n.rdata);
+				if ((uint32_t)n.ldata >= n_nodes || (uint32_t)n.rdata >= n_nodes) { err = "BVH child index out of range"; return false; }
+				if (pass == 2) {
+					PairNodeH &p = out.pairs[it.node];
+					const PolarisBvhNode &l = nodes[n.ldata], &r = nodes[n.rdata];
+					memcpy(p.lo0, l.min, 12); memcpy(p.hi0, l.max, 12); p.ref0 = ref_of(n.ldata);
+					memcpy(p.lo1, r.min, 12); memcpy(p.hi1, r.max, 12); p.ref1 = ref_of(n.rdata);
+				}
 				// right pushed first so the left subtree is visited first (reference order)
 				st.push_back({n.rdata, it.depth + 1});
 				st.push_back({n.ldata, it.depth + 1});
@@ -159,35 +180,180 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out) {
 		return true;
 	};
 
-	uint32_t dummy = 0;
-	if (!walk(0, 0, dummy, top_max)) return err;
+	std::vector<int> root_depth;
+	int need = 0;
+	auto walk_scene = [&]() -> std::string {
+		seen.assign(n_nodes, 0);
+		next_inst_rank = 0;
+		top_max = 0;
+		uint32_t dummy = 0;
+		if (!walk(0, 0, dummy, top_max)) return err;
+		// bottom trees: one walk per distinct root (meshes are shared by instances)
+		root_depth.assign(n_nodes, -1);
+		need = top_max;
+		for (uint32_t i = 0; i < NI; i++) {
+			const PolarisMeshInstance &mi = sc.mesh_instances[i];
+			if (mi.bvh_root >= NN) return "mesh instance " + std::to_string(i) + ": bvh root out of range";
+			if (mi.bvh_root == 0) return "mesh instance " + std::to_string(i) + ": bvh root is the scene root";
+			if (root_depth[mi.bvh_root] < 0) {
+				int md = 0;
+				uint32_t rank = 0;
+				std::fill(seen.begin(), seen.end(), 0);
+				if (!walk((int32_t)mi.bvh_root, 1, rank, md)) return err;
+				root_depth[mi.bvh_root] = md;
+			}
+			// stack use below an instance: pending top-level siblings + the exit marker + bottom depth
+			const int use = inst_entry_depth[i] + 1 + root_depth[mi.bvh_root];
+			if (use > need) need = use;
+		}
+		return "";
+	};
+	{
+		const std::string e = walk_scene();
+		if (!e.empty()) return e;
+	}
+	const int need_reference = need;
+
+	// ---- optional subdivision of big leaves ---------------------------------------------------
+	bool subdivided = false;
+	if (max_leaf_tris > 0) {
+		// extent of the scene in each mesh's object space -> padding of the added boxes
+		std::vector<float> root_pad(NN, 0.0f);
+		const PolarisBvhNode &world = sc.bvh_nodes[0];
+		for (uint32_t i = 0; i < NI; i++) {
+			const PolarisMeshInstance &mi = sc.mesh_instances[i];
+			const float *m = mi.inv_transform; // column major: m[4*c + r]
+			float ext = 0.0f;
+			for (int corner = 0; corner < 8; corner++) {
+				const float w[3] = {corner & 1 ? world.max[0] : world.min[0], corner & 2 ? world.max[1] : world.min[1],
+				                    corner & 4 ? world.max[2] : world.min[2]};
+				for (int r = 0; r < 3; r++) {
+					const float v = std::fabs(m[r] * w[0] + m[4 + r] * w[1] + m[8 + r] * w[2] + m[12 + r]);
+					if (!(v <= ext)) ext = v; // also takes NaN
+				}
+			}
+			const PolarisBvhNode &rb = sc.bvh_nodes[mi.bvh_root];
+			for (int k = 0; k < 3; k++) { ext = std::fmax(ext, std::fabs(rb.min[k])); ext = std::fmax(ext, std::fabs(rb.max[k])); }
+			float pad = ext * (1.0f / 32768.0f);
+			if (!(pad <= 1e30f)) pad = 1e30f;
+			if (pad > root_pad[mi.bvh_root]) root_pad[mi.bvh_root] = pad;
+		}
+		struct Range { int32_t node; uint32_t lo, hi; };
+		std::vector<Range> work;
+		for (uint32_t idx = 0; idx < NN; idx++) {
+			if (leaf_root[idx] < 0) continue;
+			const PolarisBvhNode src = sc.bvh_nodes[idx];
+			const uint32_t first = (uint32_t)(-(int64_t)src.ldata), count = (uint32_t)src.rdata;
+			const uint32_t lo = (uint32_t)slot_src.size();
+			if (slot_src.size() + (size_t)count > 4ull * NT + 64) return "triangle leaves overlap";
+			for (uint32_t t = first; t < first + count; t++) slot_src.push_back(t);
+			nodes[idx].ldata = -(int32_t)lo;
+			if (count <= (uint32_t)max_leaf_tris) continue;
+			subdivided = true;
+			const float pad = root_pad[leaf_root[idx]];
+			auto centroid = [&](uint32_t tri, int axis) {
+				const float *v = sc.vertices + 4 * (size_t)(3 * tri);
+				return v[axis] + v[4 + axis] + v[8 + axis];
+			};
+			work.clear();
+			work.push_back({(int32_t)idx, lo, lo + count});
+			while (!work.empty()) {
+				const Range rg = work.back();
+				work.pop_back();
+				const uint32_t cnt = rg.hi - rg.lo;
+				float bmin[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bmax[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+				float cmin[3] = {3.0e38f, 3.0e38f, 3.0e38f}, cmax[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+				for (uint32_t s = rg.lo; s < rg.hi; s++) {
+					const float *v = sc.vertices + 4 * (size_t)(3 * slot_src[s]);
+					for (int k = 0; k < 3; k++) {
+						bmin[k] = std::fmin(bmin[k], std::fmin(v[k], std::fmin(v[4 + k], v[8 + k])));
+						bmax[k] = std::fmax(bmax[k], std::fmax(v[k], std::fmax(v[4 + k], v[8 + k])));
+						const float c = centroid(slot_src[s], k);
+						cmin[k] = std::fmin(cmin[k], c);
+						cmax[k] = std::fmax(cmax[k], c);
+					}
+				}
+				PolarisBvhNode &nd = nodes[rg.node];
+				if (rg.node != (int32_t)idx) // the reference's own leaf keeps the reference's box
+					for (int k = 0; k < 3; k++) { nd.min[k] = bmin[k] - pad; nd.max[k] = bmax[k] + pad; }
+				// surface-area sweep over the three axes (triangles sorted by centroid): split where
+				// area(L)*|L| + area(R)*|R| is smallest, and only if that beats testing all of them
+				int best_axis = -1;
+				uint32_t best_at = 0;
+				float best_cost = 0.0f;
+				if (cnt > (uint32_t)max_leaf_tris) {
+					auto area = [](const float *lo, const float *hi) {
+						const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+						return dx * dy + dy * dz + dz * dx;
+					};
+					best_cost = (float)cnt * area(bmin, bmax) - kSplitCost * area(bmin, bmax);
+					std::vector<uint32_t> order(slot_src.begin() + rg.lo, slot_src.begin() + rg.hi);
+					std::vector<float> right_area(cnt + 1, 0.0f);
+					for (int axis = 0; axis < 3; axis++) {
+						std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return centroid(a, axis) < centroid(b, axis); });
+						float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+						auto grow = [&](uint32_t tri) {
+							const float *v = sc.vertices + 4 * (size_t)(3 * tri);
+							for (int k = 0; k < 3; k++) {
+								lo[k] = std::fmin(lo[k], std::fmin(v[k], std::fmin(v[4 + k], v[8 + k])));
+								hi[k] = std::fmax(hi[k], std::fmax(v[k], std::fmax(v[4 + k], v[8 + k])));
+							}
+						};
+						for (uint32_t i = cnt; i-- > 1;) { grow(order[i]); right_area[i] = area(lo, hi); }
+						for (int k = 0; k < 3; k++) { lo[k] = 3.0e38f; hi[k] = -3.0e38f; }
+						for (uint32_t i = 1; i < cnt; i++) {
+							grow(order[i - 1]);
+							const float c = area(lo, hi) * (float)i + right_area[i] * (float)(cnt - i);
+							if (c < best_cost) { best_cost = c; best_axis = axis; best_at = i; }
+						}
+					}
+				}
+				if (best_axis < 0) {
+					nd.ldata = -(int32_t)rg.lo;
+					nd.rdata = (int32_t)cnt;
+					continue;
+				}
+				std::stable_sort(slot_src.begin() + rg.lo, slot_src.begin() + rg.hi,
+				                 [&](uint32_t a, uint32_t b) { return centroid(a, best_axis) < centroid(b, best_axis); });
+				const uint32_t mid = rg.lo + best_at;
+				const int32_t l = (int32_t)nodes.size();
+				nodes.push_back(PolarisBvhNode{});
+				nodes.push_back(PolarisBvhNode{});
+				nodes[rg.node].ldata = l;
+				nodes[rg.node].rdata = l + 1;
+				work.push_back({l, rg.lo, mid});
+				work.push_back({l + 1, mid, rg.hi});
+			}
+		}
+		if (nodes.size() > 0x3FFFFFFFull) return "too many BVH nodes";
+	}
+	if (!subdivided) { // nothing to do: keep the caller's tree and triangle order
+		nodes.assign(sc.bvh_nodes, sc.bvh_nodes + NN);
+		slot_src.resize(NT);
+		for (uint32_t t = 0; t < NT; t++) slot_src[t] = t;
+	}
+	n_nodes = (uint32_t)nodes.size();
+	n_slots = (uint32_t)slot_src.size();
+	out.pairs.assign(n_nodes, PairNodeH{});
+	out.leaves.assign(n_nodes, LeafInfoH{0, 0});
+	pass = 2;
+	{
+		const std::string e = walk_scene();
+		if (!e.empty()) return e;
+	}
 	out.root_ref = ref_of(0);
-	// bottom trees: one walk per distinct root (meshes are shared by instances)
-	std::vector<int> root_depth(NN, -1);
-	int need = top_max;
 	for (uint32_t i = 0; i < NI; i++) {
 		const PolarisMeshInstance &mi = sc.mesh_instances[i];
-		if (mi.bvh_root >= NN) return "mesh instance " + std::to_string(i) + ": bvh root out of range";
-		if (mi.bvh_root == 0) return "mesh instance " + std::to_string(i) + ": bvh root is the scene root";
-		if (root_depth[mi.bvh_root] < 0) {
-			int md = 0;
-			uint32_t rank = 0;
-			std::fill(seen.begin(), seen.end(), 0);
-			if (!walk((int32_t)mi.bvh_root, 1, rank, md)) return err;
-			root_depth[mi.bvh_root] = md;
-		}
 		InstH &d = out.insts[i];
 		const float *m = mi.inv_transform; // column major: m[4*c + r]
 		for (int c = 0; c < 4; c++) { d.r0[c] = m[4 * c + 0]; d.r1[c] = m[4 * c + 1]; d.r2[c] = m[4 * c + 2]; }
 		d.root_ref = ref_of((int32_t)mi.bvh_root);
-		// stack use below an instance: pending top-level siblings + the exit marker + bottom depth
-		const int use = inst_entry_depth[i] + 1 + root_depth[mi.bvh_root];
-		if (use > need) need = use;
 	}
 	out.max_stack = need + 1;
-	if (out.max_stack > kTraversalStack)
-		return "BVH needs a traversal stack of " + std::to_string(out.max_stack) + " entries; the kernel (like the reference, "
+	if (need_reference + 1 > kTraversalStack)
+		return "BVH needs a traversal stack of " + std::to_string(need_reference + 1) + " entries; the kernel (like the reference, "
 		       "intersect.cl:4) has " + std::to_string(kTraversalStack);
+	if (out.max_stack > kTraversalStack) return "@retry-without-subdivision";
 
 	// ---- renumber inner nodes breadth-first ----------------------------------------------------
 	// The traversal kernels keep the first kLdsTopNodes pair records in LDS: every ray walks the top
@@ -195,24 +361,24 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out) {
 	// per-lane L1 gathers.  BFS continues through an instance leaf into the mesh BVH while the scene
 	// has few instances (a single-mesh scene's hot nodes are the top of that mesh's tree).
 	{
-		std::vector<int32_t> new_id(NN, -1);
+		std::vector<int32_t> new_id(n_nodes, -1);
 		std::vector<int32_t> order;
-		order.reserve(NN);
+		order.reserve(n_nodes);
 		auto visit = [&](int32_t root) {
 			size_t head = order.size();
-			if (is_leaf(sc.bvh_nodes[root]) || new_id[root] >= 0) return;
+			if (is_leaf(nodes[root]) || new_id[root] >= 0) return;
 			new_id[root] = (int32_t)order.size();
 			order.push_back(root);
 			while (head < order.size()) {
-				const PolarisBvhNode &n = sc.bvh_nodes[order[head++]];
+				const PolarisBvhNode &n = nodes[order[head++]];
 				const int32_t kids[2] = {n.ldata, n.rdata};
 				for (int32_t c : kids) {
-					const PolarisBvhNode &cn = sc.bvh_nodes[c];
+					const PolarisBvhNode &cn = nodes[c];
 					int32_t next = c;
 					if (is_leaf(cn)) {
 						if (cn.rdata != 0 || NI > 16) continue;
 						next = (int32_t)sc.mesh_instances[(uint32_t)(-(int64_t)cn.ldata)].bvh_root; // into the instance
-						if (is_leaf(sc.bvh_nodes[next])) continue;
+						if (is_leaf(nodes[next])) continue;
 					}
 					if (new_id[next] < 0) {
 						new_id[next] = (int32_t)order.size();
@@ -237,11 +403,14 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out) {
 		for (uint32_t i = 0; i < NI; i++) out.insts[i].root_ref = remap(out.insts[i].root_ref);
 	}
 
-	for (uint32_t t = 0; t < NT; t++) {
+	out.tris.assign(n_slots, TriH{});
+	for (uint32_t s = 0; s < n_slots; s++) {
+		const uint32_t t = slot_src[s];
 		const float *v0 = sc.vertices + 4 * (size_t)(3 * t), *v1 = v0 + 4, *v2 = v0 + 8;
-		TriH &d = out.tris[t];
+		TriH &d = out.tris[s];
 		for (int k = 0; k < 3; k++) { d.v0[k] = v0[k]; d.e1[k] = v1[k] - v0[k]; d.e2[k] = v2[k] - v0[k]; }
 		d.rank = tri_rank[t] == 0xFFFFFFFFu ? t : tri_rank[t];
+		d.orig = t;
 	}
 	return "";
 }

@@ -70,9 +70,9 @@ def make_hip_tracer(sc, W, H, device=0, **options):
 
     tr = HipTracer("test", device)
     tr.Init()
+    for k, v in options.items():  # before the upload: max_leaf_tris shapes the scene layout
+        tr.set_option(k, v)
     tr.UpdateState(UpdateMode.Synchronous, ChangeType.FrameDimensions, (W, H))
     tr.UpdateState(UpdateMode.Synchronous, ChangeType.SceneData, sc)
     tr.UpdateState(UpdateMode.Synchronous, ChangeType.CameraData, sc)
-    for k, v in options.items():
-        tr.set_option(k, v)
     return tr

@@ -89,6 +89,28 @@ def test_hip_vs_oracle_exact_and_batched(built, oracle, name):
             assert rmse(got, want, spp) <= 1e-6, name
 
 
+@pytest.mark.parametrize("max_leaf", [0, 1, 2, 5])
+def test_leaf_subdivision_is_invisible(built, oracle, max_leaf):
+    """The reference compiler's BVH (leaves of up to 10 triangles) traced with the leaves kept
+    (0) or subdivided at upload: bit-identical radiance and counters vs the CPU oracle."""
+    from oracle import pybind as ob
+    from polaris_amd import scenes
+
+    sc = scenes.cornell_box(compiler="reference")
+    W, H, spp, B = 64, 48, 3, 5
+    req = ob.make_request(W, H, spp=spp, bounces=B, rr=3)
+    seeds = scenes.make_seeds(5, spp, B)
+    want, wst, _ = oracle.trace(sc, req, seeds)
+    tr = make_hip_tracer(sc, W, H, exact_accumulate=1, max_leaf_tris=max_leaf)
+    try:
+        tr.Trace(req, seeds)
+        got, st = tr.read_accumulator(0), tr.last_trace_stats
+    finally:
+        tr.Close()
+    assert counters(st, B) == counters(wst, B)
+    assert np.array_equal(bits(got[..., :3]), bits(want[..., :3]))
+
+
 def test_row_blocks_merge_to_the_full_frame(built, oracle):
     """Two tracers on one GPU render row blocks [0,h0) and [h0,H) and merge into the primary
     (renderer/default.go:127-136,188-191): equals the oracle run block by block."""

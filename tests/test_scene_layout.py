@@ -1,0 +1,113 @@
+"""CPU tests of the upload-time scene re-layout (polaris_amd/csrc/scene_layout.h).
+
+The HIP backend subdivides big triangle leaves when a scene is uploaded (option max_leaf_tris).
+tests/tools/layout_check.cpp walks the resulting layout on the CPU with the kernels' traversal
+rules; here we check that
+
+* the hit record of every ray (triangle, instance, bits of t/u/v) is identical whatever the leaf
+  size -- the added boxes only cull inside a leaf the reference traversal had reached anyway;
+* primary hits agree with the CPU oracle's taps (reference traversal order) bit for bit;
+* the subdivision actually lowers the triangle tests per ray on a big-leaf BVH.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from polaris_amd import ctypes_api as T
+from polaris_amd import scenes
+
+BUILD = os.path.join(ROOT, "tests", "_build")
+SRC = os.path.join(ROOT, "tests", "tools", "layout_check.cpp")
+LIB = os.path.join(BUILD, "liblayout_check.so")
+
+
+@pytest.fixture(scope="module")
+def harness():
+    os.makedirs(BUILD, exist_ok=True)
+    deps = [SRC, os.path.join(ROOT, "polaris_amd", "csrc", "scene_layout.h"), os.path.join(ROOT, "include", "polaris_math.h")]
+    if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+                               "-I" + os.path.join(ROOT, "polaris_amd", "csrc"), SRC, "-o", LIB])
+    lib = C.CDLL(LIB)
+    lib.layout_check_traverse.argtypes = [C.POINTER(T.SceneView), C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p,
+                                          C.c_void_p, C.c_char_p, C.c_size_t]
+    return lib
+
+
+def traverse(lib, sc, rays, max_leaf, any_hit=False):
+    rays = np.ascontiguousarray(rays, dtype=np.float32)
+    hit = np.zeros((rays.shape[0], 6), np.int32)
+    cnt = np.zeros(6, np.uint64)
+    err = C.create_string_buffer(256)
+    view = T.scene_view(sc)
+    rc = lib.layout_check_traverse(C.byref(view), max_leaf, rays.ctypes.data, rays.shape[0], int(any_hit), hit.ctypes.data,
+                                   cnt.ctypes.data, err, 256)
+    assert rc == 0, err.value.decode()
+    return hit, cnt
+
+
+def camera_and_bounce_rays(oracle, sc, W=48, H=36, seed=7):
+    """Primary rays of one sample (from the oracle's tap) + random rays leaving the primary hit points."""
+    from oracle import pybind as ob
+
+    req = ob.make_request(W, H, spp=1, bounces=1, rr=2)
+    _, _, taps = oracle.trace(sc, req, scenes.make_seeds(seed, 1, 1), tap_sample=0)
+    prim = taps["primary_rays"].copy()
+    rng = np.random.default_rng(seed)
+    hitm = taps["primary_hit"] != 0
+    t = taps["primary_wuvt"][hitm, 3:4]
+    p = prim[hitm, 0:3] + prim[hitm, 4:7] * t
+    d = rng.normal(size=p.shape).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    sec = np.zeros((p.shape[0], 8), np.float32)
+    sec[:, 0:3] = p + d * np.float32(1e-3)
+    sec[:, 3] = np.float32(3.402823466e+38)
+    sec[:, 4:7] = d
+    # short shadow-like rays with a finite maxDist
+    sh = sec.copy()
+    sh[:, 3] = rng.uniform(0.05, 2.0, size=sh.shape[0]).astype(np.float32)
+    return prim, taps, np.concatenate([prim, sec, sh], axis=0)
+
+
+SCENE_MAKERS = {
+    "cornell-refbvh": lambda: scenes.cornell_box(compiler="reference"),
+    "cornell": lambda: scenes.cornell_box(),
+    "sphere": lambda: scenes.sphere_scene(),
+    "cubes": lambda: scenes.instanced_cubes(),
+    "transformed": lambda: scenes.transformed_instances(),
+    "terrain-small": lambda: scenes.SCENES["terrain-small"](),
+}
+
+
+@pytest.mark.parametrize("name", list(SCENE_MAKERS))
+def test_leaf_subdivision_never_changes_a_hit(harness, oracle, name):
+    sc = SCENE_MAKERS[name]()
+    prim, taps, rays = camera_and_bounce_rays(oracle, sc)
+    base, cnt0 = traverse(harness, sc, rays, 0)
+    base_any, _ = traverse(harness, sc, rays, 0, any_hit=True)
+    assert base[:, 5].sum() > 0
+    # primary hits against the oracle's reference-order traversal
+    n = prim.shape[0]
+    hm = taps["primary_hit"] != 0
+    assert np.array_equal(base[:n, 5] != 0, hm)
+    assert np.array_equal(base[:n][hm][:, [1, 0]], taps["primary_tri"][hm])
+    assert np.array_equal(base[:n][hm][:, 2], taps["primary_wuvt"][hm][:, 3].view(np.int32))
+    for max_leaf in (1, 2, 3, 4, 8):
+        got, cnt = traverse(harness, sc, rays, max_leaf)
+        assert np.array_equal(got, base), f"{name}: closest hits differ with max_leaf_tris={max_leaf}"
+        got_any, _ = traverse(harness, sc, rays, max_leaf, any_hit=True)
+        assert np.array_equal(got_any[:, 5], base_any[:, 5]), f"{name}: occlusion differs with max_leaf_tris={max_leaf}"
+        assert cnt[5] <= 32  # traversal stack
+
+
+def test_subdivision_cuts_triangle_tests_on_big_leaves(harness, oracle):
+    sc = scenes.cornell_box(compiler="reference")  # leaves of up to 10 triangles, as `polaris render` compiles them
+    _, _, rays = camera_and_bounce_rays(oracle, sc)
+    _, c0 = traverse(harness, sc, rays, 0)
+    _, c2 = traverse(harness, sc, rays, 2)
+    assert c2[1] < 0.8 * c0[1]
+    assert c2[4] == c0[4]  # same triangles, only regrouped
