@@ -76,6 +76,11 @@ typedef struct PolarisOracleTaps {
 	void prefix##_emissive_probe(const PolarisSceneView *scene, uint32_t emissive_index,      \
 	                             const float point[3], const float normal[3],                 \
 	                             const float sample[2], const float pdf_dir[3], float out[9]); \
+	/* rayIntersectionQuery (any_hit = 0, intersect.cl:184-347) or rayIntersectionTest (any_hit \
+	 * != 0, :26-180) over n arbitrary rays [n][8] = origin.xyz, maxDist, dir.xyz, unused:       \
+	 * hit[n]; for closest hits also wuvt[n][4] and inst_tri[n][2] (either may be NULL) */       \
+	int prefix##_intersect_probe(const PolarisSceneView *scene, const float *rays, uint32_t n,    \
+	                             int any_hit, int32_t *hit, float *wuvt, int32_t *inst_tri);      \
 	const char *prefix##_describe(void);
 
 POLARIS_ORACLE_DECL(polaris_oracle)

@@ -1165,6 +1165,27 @@ extern "C" void polaris_oracle_random(uint32_t state[2], float out[2]) {
 	out[1] = r.y;
 }
 
+extern "C" int polaris_oracle_intersect_probe(const PolarisSceneView *scene, const float *rays, uint32_t n, int any_hit,
+                                              int32_t *hit, float *wuvt, int32_t *inst_tri) {
+	bool overflow = false;
+#pragma omp parallel for schedule(dynamic, 256) reduction(|| : overflow)
+	for (long i = 0; i < (long)n; i++) {
+		Ray r;
+		memcpy(&r, rays + 8 * (size_t)i, sizeof r);
+		Intersection is;
+		memset(&is, 0, sizeof is);
+		bool ov = false;
+		const int h = any_hit ? traverse<true>(r, scene, nullptr, &ov) : traverse<false>(r, scene, &is, &ov);
+		overflow = overflow || ov;
+		hit[i] = h;
+		if (!any_hit && h) {
+			if (wuvt) memcpy(wuvt + 4 * (size_t)i, is.wuvt, 16);
+			if (inst_tri) { inst_tri[2 * (size_t)i] = (int32_t)is.meshInstance; inst_tri[2 * (size_t)i + 1] = (int32_t)is.triIndex; }
+		}
+	}
+	return overflow ? 1 : 0;
+}
+
 extern "C" void polaris_oracle_bxdf_probe(const PolarisMaterialNode *node, const PolarisTextureMetadata *tex_meta,
                                           const uint8_t *tex_data, const float normal[3], const float uv[2],
                                           const float in_dir[3], const float sample[2], const float eval_dir[3],

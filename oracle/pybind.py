@@ -68,6 +68,8 @@ class Oracle:
         f = lambda n: getattr(self.lib, f"{prefix}_{n}")
         self._trace, self._tonemap, self._random = f("trace"), f("tonemap"), f("random")
         self._bxdf, self._tex, self._emissive, self._describe = f("bxdf_probe"), f("tex_probe"), f("emissive_probe"), f("describe")
+        self._intersect = f("intersect_probe")
+        self._intersect.argtypes = [C.POINTER(T.SceneView), C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         vp = C.c_void_p
         self._trace.argtypes = [C.POINTER(T.SceneView), vp, vp, C.POINTER(T.BlockRequest), vp, C.c_size_t, vp,
                                 C.POINTER(T.TraceStats), C.POINTER(Taps), C.c_uint32]
@@ -122,6 +124,20 @@ class Oracle:
         return st, out
 
     # ---- function-level probes ---------------------------------------------------------
+    def intersect(self, scene, rays, any_hit=False):
+        """rayIntersectionQuery / rayIntersectionTest over arbitrary rays (n, 8) = origin, maxDist, dir, unused.
+        Returns (hit (n,) int32, wuvt (n,4) float32, inst_tri (n,2) int32); the last two only for closest hits."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = rays.shape[0]
+        hit = np.zeros(n, np.int32)
+        wuvt = np.zeros((n, 4), np.float32)
+        it = np.full((n, 2), -1, np.int32)
+        view = T.scene_view(scene)
+        rc = self._intersect(C.byref(view), rays.ctypes.data, n, int(any_hit), hit.ctypes.data, wuvt.ctypes.data, it.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"{self.kind}: traversal stack overflow")
+        return hit, wuvt, it
+
     def bxdf_probe(self, node, tex_meta, tex_data, normal, uv, in_dir, sample, eval_dir):
         f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
         node = np.ascontiguousarray(node)

@@ -246,6 +246,29 @@ extern "C" void polaris_ref_random(uint32_t state[2], float out[2]) {
 	out[1] = r.y;
 }
 
+extern "C" int polaris_ref_intersect_probe(const PolarisSceneView *sc, const float *rays, uint32_t n, int any_hit, int32_t *hit,
+                                           float *wuvt, int32_t *inst_tri) {
+	std::vector<Ray> r(n);
+	memcpy(r.data(), rays, (size_t)n * sizeof(Ray));
+	std::vector<int> flags(n, 0);
+	std::vector<Intersection> isects(any_hit ? 0 : n);
+	int count = (int)n;
+#pragma omp parallel for schedule(dynamic, 256)
+	for (long g = 0; g < (long)n; g++) {
+		polaris_ref_gid[0] = (size_t)g;
+		if (any_hit) rayIntersectionTest(r.data(), &count, sc->bvh_nodes, sc->mesh_instances, sc->vertices, flags.data());
+		else rayIntersectionQuery(r.data(), &count, sc->bvh_nodes, sc->mesh_instances, sc->vertices, flags.data(), isects.data());
+	}
+	for (uint32_t i = 0; i < n; i++) {
+		hit[i] = flags[i];
+		if (!any_hit && flags[i]) {
+			if (wuvt) memcpy(wuvt + 4 * (size_t)i, &isects[i], 16);
+			if (inst_tri) memcpy(inst_tri + 2 * (size_t)i, (const char *)&isects[i] + 16, 8);
+		}
+	}
+	return 0;
+}
+
 extern "C" void polaris_ref_bxdf_probe(const PolarisMaterialNode *node, const PolarisTextureMetadata *tex_meta,
                                        const uint8_t *tex_data, const float normal[3], const float uv[2],
                                        const float in_dir[3], const float sample[2], const float eval_dir[3],

@@ -133,10 +133,9 @@ __device__ __forceinline__ bool traverse(const BvhDev &B, f3 O, f3 D, float maxD
 			const PairNode P = B.pairs[cur];
 			float t0 = slab_entry(P.lo0, P.hi0, o, inv, maxDist);
 			float t1 = slab_entry(P.lo1, P.hi1, o, inv, maxDist);
-			if (!ANY_HIT) { // cull subtrees that start beyond the best hit (margin >> rounding of t)
-				const float lim = best.t * 1.001f;
-				if (t0 > lim) t0 = kFltMax;
-				if (t1 > lim) t1 = kFltMax;
+			if (!ANY_HIT) { // cull subtrees that start beyond the best hit (factor 1.001 >> rounding of t; +inf = box does not bound its subtree)
+				if (t0 > best.t * P.hi0.w) t0 = kFltMax;
+				if (t1 > best.t * P.hi1.w) t1 = kFltMax;
 			}
 			int c0 = fbits(P.lo0.w), c1 = fbits(P.lo1.w);
 			const bool h0 = t0 < kFltMax, h1 = t1 < kFltMax;
@@ -399,9 +398,8 @@ __global__ __launch_bounds__(WG) void k_trace(Streams st, BvhDev B, uint32_t num
 			float t0 = slab_entry_hw(P.lo0, P.hi0, o, inv, maxDist);
 			float t1 = slab_entry_hw(P.lo1, P.hi1, o, inv, maxDist);
 			if (!ANY_HIT) {
-				const float lim = best.t * 1.001f;
-				if (t0 > lim) t0 = kFltMax;
-				if (t1 > lim) t1 = kFltMax;
+				if (t0 > best.t * P.hi0.w) t0 = kFltMax;
+				if (t1 > best.t * P.hi1.w) t1 = kFltMax;
 			}
 			int c0 = fbits(P.lo0.w), c1 = fbits(P.lo1.w);
 			const bool h0 = t0 < kFltMax, h1 = t1 < kFltMax;
@@ -535,8 +533,8 @@ __global__ __launch_bounds__(WG) void k_trace_packet(Streams st, BvhDev B, float
 			const PairNode P = B.pairs[ucur]; // uniform address: scalar loads
 			float t0 = slab_entry_hw(P.lo0, P.hi0, o, inv, maxDist);
 			float t1 = slab_entry_hw(P.lo1, P.hi1, o, inv, maxDist);
-			const float lim = ANY_HIT ? kFltMax : best.t * 1.001f;
-			const bool w0 = active && t0 < kFltMax && !(t0 > lim), w1 = active && t1 < kFltMax && !(t1 > lim);
+			const float lim0 = ANY_HIT ? kFltMax : best.t * P.hi0.w, lim1 = ANY_HIT ? kFltMax : best.t * P.hi1.w;
+			const bool w0 = active && t0 < kFltMax && !(t0 > lim0), w1 = active && t1 < kFltMax && !(t1 > lim1);
 			const unsigned long long m0 = __ballot(w0), m1 = __ballot(w1);
 			const int c0 = fbits(P.lo0.w), c1 = fbits(P.lo1.w);
 			if (m0 != 0ull && m1 != 0ull) {

@@ -11,6 +11,7 @@
 //     fetch per traversal step instead of the reference's two dependent 32 B fetches,
 //     kernels/intersect.cl:296-298) plus a tagged reference per child:
 //         ref >= 0  -> inner node index          ref < 0 -> ~leaf node index
+//     and a cull factor per child (1.001, or +inf when the box does not bound its subtree).
 //   * LeafInfo[node] = (ldata, rdata) of a leaf: 8 B fetch when a leaf is popped.
 //   * Tri[slot] = {v0 | rank, e01 = v1 - v0 | scene triangle index, e02 = v2 - v0}: the two edge subtractions of
 //     Moeller-Trumbore are hoisted to upload (one IEEE subtraction each, so bit-identical to
@@ -25,7 +26,9 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <limits>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "polaris_types.h"
@@ -38,6 +41,7 @@ struct TriH { float v0[3]; uint32_t rank; float e1[3]; uint32_t orig; float e2[3
 struct InstH { float r0[4], r1[4], r2[4]; int32_t root_ref; uint32_t rank; uint32_t pad[2]; };
 static_assert(sizeof(PairNodeH) == 64 && sizeof(TriH) == 48 && sizeof(InstH) == 64, "layout");
 
+constexpr float kCullMargin = 1.001f; // a subtree is skipped when its box starts beyond kCullMargin x the best hit distance
 constexpr float kSplitCost = 1.0f;  // cost of one added pair-of-boxes step, in triangle tests (leaf subdivision)
 constexpr int kTraversalStack = 32; // entries per ray, == BVH_MAX_STACK_SIZE (intersect.cl:4)
 
@@ -48,6 +52,7 @@ struct SceneLayout {
 	std::vector<InstH> insts;
 	int32_t root_ref = 0;
 	int max_stack = 0;
+	uint32_t unbounded_boxes = 0;   // inner nodes with a child whose box does not contain its subtree (never culled by distance)
 };
 
 inline bool is_leaf(const PolarisBvhNode &n) { return n.ldata <= 0; }
@@ -354,6 +359,110 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out, in
 		return "BVH needs a traversal stack of " + std::to_string(need_reference + 1) + " entries; the kernel (like the reference, "
 		       "intersect.cl:4) has " + std::to_string(kTraversalStack);
 	if (out.max_stack > kTraversalStack) return "@retry-without-subdivision";
+
+	// ---- which boxes really bound their contents? ----------------------------------------------
+	// The closest-hit kernels skip a child whose box starts beyond the best hit so far.  That is
+	// only the reference's answer if the box bounds everything below it -- and the reference's own
+	// scene reader breaks this: an `instance` with a rotation or a scale gets the mesh box moved by
+	// the translation alone (asset/scene/reader/wavefront.go:514-519), and the top-level boxes are
+	// unions of those.  The reference still finds hits inside such an instance whenever the ray
+	// touches the (wrong) box, however far away the box starts, because it never culls by distance
+	// (intersect.cl:309 compares with the ray's max distance only).  So: the real extent of every
+	// subtree is computed here, and a child whose box does not contain it gets an infinite cull
+	// limit (PairNode.hi?.w is the factor applied to the best distance).
+	{
+		struct Box { float lo[3], hi[3]; };
+		const Box empty = {{3.0e38f, 3.0e38f, 3.0e38f}, {-3.0e38f, -3.0e38f, -3.0e38f}};
+		std::vector<Box> content(n_nodes, empty);
+		std::vector<uint8_t> done(n_nodes, 0);
+		auto grow = [](Box &b, const float *p) { for (int k = 0; k < 3; k++) { b.lo[k] = std::fmin(b.lo[k], p[k]); b.hi[k] = std::fmax(b.hi[k], p[k]); } };
+		auto merge = [&](Box &b, const Box &c) { grow(b, c.lo); grow(b, c.hi); };
+		// forward (object -> world) matrices, in double: the stored ones are the inverses
+		auto invert = [](const float *a, double *o) {
+			double m[4][8];
+			for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) { m[r][c] = a[4 * c + r]; m[r][4 + c] = r == c; }
+			for (int c = 0; c < 4; c++) {
+				int piv = c;
+				for (int r = c + 1; r < 4; r++) if (std::fabs(m[r][c]) > std::fabs(m[piv][c])) piv = r;
+				if (!(std::fabs(m[piv][c]) > 0.0)) return false;
+				for (int k = 0; k < 8; k++) std::swap(m[c][k], m[piv][k]);
+				const double d = m[c][c];
+				for (int k = 0; k < 8; k++) m[c][k] /= d;
+				for (int r = 0; r < 4; r++) if (r != c) { const double f = m[r][c]; for (int k = 0; k < 8; k++) m[r][k] -= f * m[c][k]; }
+			}
+			for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) o[4 * r + c] = m[r][4 + c]; // row major
+			return true;
+		};
+		// post-order over a tree; instance leaves pull in the (already computed) box of their mesh
+		std::vector<std::pair<int32_t, int>> st;
+		auto bound_tree = [&](int32_t root) {
+			st.clear();
+			st.push_back({root, 0});
+			while (!st.empty()) {
+				const int32_t idx = st.back().first;
+				const int phase = st.back().second;
+				const PolarisBvhNode &n = nodes[idx];
+				if (done[idx]) { st.pop_back(); continue; }
+				if (is_leaf(n)) {
+					Box b = empty;
+					if (n.rdata == 0) {
+						const uint32_t inst = (uint32_t)(-(int64_t)n.ldata);
+						const Box &mb = content[sc.mesh_instances[inst].bvh_root];
+						double fwd[16];
+						if (invert(sc.mesh_instances[inst].inv_transform, fwd) && mb.lo[0] <= mb.hi[0]) {
+							for (int corner = 0; corner < 8; corner++) {
+								const double p[3] = {corner & 1 ? mb.hi[0] : mb.lo[0], corner & 2 ? mb.hi[1] : mb.lo[1], corner & 4 ? mb.hi[2] : mb.lo[2]};
+								float w[3];
+								for (int r = 0; r < 3; r++) w[r] = (float)(fwd[4 * r] * p[0] + fwd[4 * r + 1] * p[1] + fwd[4 * r + 2] * p[2] + fwd[4 * r + 3]);
+								grow(b, w);
+							}
+						} else { // singular matrix: nothing can be promised about this instance
+							for (int k = 0; k < 3; k++) { b.lo[k] = -3.0e38f; b.hi[k] = 3.0e38f; }
+						}
+					} else {
+						const uint32_t first = (uint32_t)(-(int64_t)n.ldata);
+						for (uint32_t s = first; s < first + (uint32_t)n.rdata; s++) {
+							const float *v = sc.vertices + 4 * (size_t)(3 * slot_src[s]);
+							grow(b, v); grow(b, v + 4); grow(b, v + 8);
+						}
+					}
+					content[idx] = b;
+					done[idx] = 1;
+					st.pop_back();
+				} else if (phase == 0) {
+					st.back().second = 1;
+					st.push_back({n.ldata, 0});
+					st.push_back({n.rdata, 0});
+				} else {
+					Box b = content[n.ldata];
+					merge(b, content[n.rdata]);
+					content[idx] = b;
+					done[idx] = 1;
+					st.pop_back();
+				}
+			}
+		};
+		for (uint32_t i = 0; i < NI; i++) bound_tree((int32_t)sc.mesh_instances[i].bvh_root);
+		bound_tree(0);
+		auto cull_factor = [&](int32_t child) {
+			const PolarisBvhNode &n = nodes[child];
+			const Box &c = content[child];
+			bool inside = true;
+			for (int k = 0; k < 3; k++) {
+				const float tol = 1e-4f * std::fmax(std::fmax(std::fabs(c.lo[k]), std::fabs(c.hi[k])), c.hi[k] - c.lo[k]) + 1e-30f;
+				if (!(n.min[k] - tol <= c.lo[k] && c.hi[k] <= n.max[k] + tol)) inside = false;
+			}
+			return inside ? kCullMargin : std::numeric_limits<float>::infinity();
+		};
+		for (uint32_t idx = 0; idx < n_nodes; idx++) {
+			if (!done[idx] || is_leaf(nodes[idx])) continue;
+			PairNodeH &p = out.pairs[idx];
+			const float f0 = cull_factor(nodes[idx].ldata), f1 = cull_factor(nodes[idx].rdata);
+			memcpy(&p.pad0, &f0, 4);
+			memcpy(&p.pad1, &f1, 4);
+			if (!(f0 == kCullMargin && f1 == kCullMargin)) out.unbounded_boxes++;
+		}
+	}
 
 	// ---- renumber inner nodes breadth-first ----------------------------------------------------
 	// The traversal kernels keep the first kLdsTopNodes pair records in LDS: every ray walks the top

@@ -4,8 +4,11 @@
 #include <cstring>
 #include <random>
 
+#include "material_expr.hpp"
 #include "renderer.hpp"
 #include "scene_compiler.hpp"
+#include "texture.hpp"
+#include "wavefront_reader.hpp"
 
 using namespace polaris;
 
@@ -186,5 +189,110 @@ void *polaris_host_compile_scene(const float *prim_vertices, const float *prim_n
 }
 const PolarisSceneView *polaris_host_compiled_view(void *h) { return &static_cast<CompiledBox *>(h)->view; }
 void polaris_host_compiled_free(void *h) { delete static_cast<CompiledBox *>(h); }
+
+// ---- scene front-end (wavefront_reader.cpp, material_expr.cpp, texture.cpp) ---------------------
+// Returns 0 = parsed and valid, 1 = parse error, 2 = parsed but semantically invalid.
+int polaris_host_material_check(const char *expr, char err[512]) {
+	std::unique_ptr<material::Expr> e;
+	if (Error pe = material::ParseExpression(expr, &e)) { if (err) snprintf(err, 512, "%s", pe.msg.c_str()); return 1; }
+	if (Error ve = e->Validate()) { if (err) snprintf(err, 512, "%s", ve.msg.c_str()); return 2; }
+	return 0;
+}
+int polaris_host_material_ior(const char *name, float *out) { return material::IOR(name, out) ? 1 : 0; }
+
+// ReadScene (path != NULL) or the same from an in-memory .obj (content != NULL, name = its label).
+// The handle is a CompiledBox: polaris_host_compiled_view/_free apply.
+void *polaris_host_read_scene(const char *path, const char *name, const char *content, int min_leaf, char err[1024]) {
+	auto *box = new CompiledBox();
+	reader::WavefrontSceneReader r;
+	if (min_leaf > 0) r.rawScene.minPrimitivesPerLeaf = min_leaf;
+	Error e;
+	if (path) {
+		const std::string p(path);
+		if (p.size() >= 4 && p.compare(p.size() - 4, 4, ".obj") == 0) e = r.Read(p, &box->out);
+		else e = reader::ReadScene(p, &box->out);
+	} else {
+		e = r.ReadString(name ? name : "embedded", content ? content : "", &box->out);
+	}
+	if (e) {
+		if (err) snprintf(err, 1024, "%s", e.msg.c_str());
+		delete box;
+		return nullptr;
+	}
+	box->view = box->out.View();
+	return box;
+}
+// Camera of a compiled scene: fov/eye/look/up as parsed, and the CameraData (eye + frustum corner
+// rays) for a frame of the given aspect (cmd/render.go:58 SetupProjection).
+void polaris_host_compiled_camera(void *h, float aspect, int invert_y, float params[10], float eye[3], float frustum[16]) {
+	scene::Camera cam = static_cast<CompiledBox *>(h)->out.camera;
+	if (params) {
+		params[0] = cam.FOV;
+		params[1] = cam.Position.x; params[2] = cam.Position.y; params[3] = cam.Position.z;
+		params[4] = cam.LookAt.x; params[5] = cam.LookAt.y; params[6] = cam.LookAt.z;
+		params[7] = cam.Up.x; params[8] = cam.Up.y; params[9] = cam.Up.z;
+	}
+	cam.InvertY = invert_y != 0;
+	cam.SetupProjection(aspect);
+	const tracer::CameraData d = cam.Data();
+	if (eye) memcpy(eye, d.eye, sizeof d.eye);
+	if (frustum) memcpy(frustum, d.frustum, sizeof d.frustum);
+}
+// warnings joined by '\n' (missing textures, ...); returns the length needed
+size_t polaris_host_compiled_warnings(void *h, char *buf, size_t cap) {
+	std::string all;
+	for (const std::string &w : static_cast<CompiledBox *>(h)->out.warnings) all += w + "\n";
+	if (buf && cap) snprintf(buf, cap, "%s", all.c_str());
+	return all.size() + 1;
+}
+// Parse-level probes for the reader tests: counts and the instance matrices of a parsed .obj.
+// out_counts = {meshes, instances, materials(after pruning order), primitives of mesh 0}
+int polaris_host_parse_obj(const char *content, uint32_t out_counts[4], float *inst_transforms, float *inst_boxes, uint32_t cap,
+                           char *mat_exprs, size_t mat_cap, char err[1024]) {
+	reader::WavefrontSceneReader r;
+	if (Error e = r.Parse("embedded", content)) { if (err) snprintf(err, 1024, "%s", e.msg.c_str()); return 1; }
+	if (r.rawScene.instances.empty()) r.CreateDefaultMeshInstances();
+	r.ProcessMaterials();
+	out_counts[0] = uint32_t(r.rawScene.meshes.size());
+	out_counts[1] = uint32_t(r.rawScene.instances.size());
+	out_counts[2] = uint32_t(r.rawScene.materials.size());
+	out_counts[3] = r.rawScene.meshes.empty() ? 0 : uint32_t(r.rawScene.meshes[0].primitives.size());
+	for (uint32_t i = 0; i < r.rawScene.instances.size() && i < cap; i++) {
+		const compiler::MeshInstance &mi = r.rawScene.instances[i];
+		if (inst_transforms) memcpy(inst_transforms + 16 * i, mi.transform, 64);
+		if (inst_boxes) {
+			float *b = inst_boxes + 9 * i;
+			b[0] = mi.bbox[0].x; b[1] = mi.bbox[0].y; b[2] = mi.bbox[0].z; b[3] = mi.bbox[1].x; b[4] = mi.bbox[1].y; b[5] = mi.bbox[1].z;
+			b[6] = mi.center.x; b[7] = mi.center.y; b[8] = mi.center.z;
+		}
+	}
+	if (mat_exprs && mat_cap) {
+		std::string all;
+		for (const compiler::Material &m : r.rawScene.materials) all += m.name + "\t" + (m.used ? "1" : "0") + "\t" + m.expression + "\n";
+		snprintf(mat_exprs, mat_cap, "%s", all.c_str());
+	}
+	return 0;
+}
+int polaris_host_parse_mtl(const char *content, char *mat_exprs, size_t mat_cap, char err[1024]) {
+	reader::WavefrontSceneReader r;
+	if (Error e = r.ParseMaterials("embedded", content)) { if (err) snprintf(err, 1024, "%s", e.msg.c_str()); return 1; }
+	std::string all;
+	for (const reader::WavefrontMaterial &m : r.materials) all += m.Name + "\t" + m.GetExpression() + "\n";
+	if (mat_exprs && mat_cap) snprintf(mat_exprs, mat_cap, "%s", all.c_str());
+	return 0;
+}
+int polaris_host_select_face_index(const char *token, int list_len, int rel_offset, int *out, char err[256]) {
+	if (Error e = reader::SelectFaceCoordIndex(token, list_len, rel_offset, out)) { if (err) snprintf(err, 256, "%s", e.msg.c_str()); return 1; }
+	return 0;
+}
+// Decode an image file into the tracer's texture representation.  Returns 0 and fills
+// meta = {format, width, height, bytes}; data (capacity cap) receives the texels.
+int polaris_host_texture_load(const char *path, uint32_t meta[4], uint8_t *data, size_t cap, char err[512]) {
+	texture::Texture t;
+	if (Error e = texture::Load(path, &t)) { if (err) snprintf(err, 512, "%s", e.msg.c_str()); return 1; }
+	meta[0] = t.format; meta[1] = t.width; meta[2] = t.height; meta[3] = uint32_t(t.data.size());
+	if (data && cap >= t.data.size()) memcpy(data, t.data.data(), t.data.size());
+	return 0;
+}
 
 } // extern "C"

@@ -3,6 +3,10 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <map>
+
+#include "material_expr.hpp"
+#include "texture.hpp"
 
 namespace polaris {
 namespace compiler {
@@ -136,30 +140,13 @@ int32_t FindMaterialNodeByBxdf(const std::vector<PolarisMaterialNode> &nodes, ui
 }
 
 // 4x4 inverse (general), column major
-static bool invert4(const float m[16], float out[16]) {
-	double a[16], inv[16];
-	for (int i = 0; i < 16; i++) a[i] = m[i];
-	inv[0] = a[5] * a[10] * a[15] - a[5] * a[11] * a[14] - a[9] * a[6] * a[15] + a[9] * a[7] * a[14] + a[13] * a[6] * a[11] - a[13] * a[7] * a[10];
-	inv[4] = -a[4] * a[10] * a[15] + a[4] * a[11] * a[14] + a[8] * a[6] * a[15] - a[8] * a[7] * a[14] - a[12] * a[6] * a[11] + a[12] * a[7] * a[10];
-	inv[8] = a[4] * a[9] * a[15] - a[4] * a[11] * a[13] - a[8] * a[5] * a[15] + a[8] * a[7] * a[13] + a[12] * a[5] * a[11] - a[12] * a[7] * a[9];
-	inv[12] = -a[4] * a[9] * a[14] + a[4] * a[10] * a[13] + a[8] * a[5] * a[14] - a[8] * a[6] * a[13] - a[12] * a[5] * a[10] + a[12] * a[6] * a[9];
-	inv[1] = -a[1] * a[10] * a[15] + a[1] * a[11] * a[14] + a[9] * a[2] * a[15] - a[9] * a[3] * a[14] - a[13] * a[2] * a[11] + a[13] * a[3] * a[10];
-	inv[5] = a[0] * a[10] * a[15] - a[0] * a[11] * a[14] - a[8] * a[2] * a[15] + a[8] * a[3] * a[14] + a[12] * a[2] * a[11] - a[12] * a[3] * a[10];
-	inv[9] = -a[0] * a[9] * a[15] + a[0] * a[11] * a[13] + a[8] * a[1] * a[15] - a[8] * a[3] * a[13] - a[12] * a[1] * a[11] + a[12] * a[3] * a[9];
-	inv[13] = a[0] * a[9] * a[14] - a[0] * a[10] * a[13] - a[8] * a[1] * a[14] + a[8] * a[2] * a[13] + a[12] * a[1] * a[10] - a[12] * a[2] * a[9];
-	inv[2] = a[1] * a[6] * a[15] - a[1] * a[7] * a[14] - a[5] * a[2] * a[15] + a[5] * a[3] * a[14] + a[13] * a[2] * a[7] - a[13] * a[3] * a[6];
-	inv[6] = -a[0] * a[6] * a[15] + a[0] * a[7] * a[14] + a[4] * a[2] * a[15] - a[4] * a[3] * a[14] - a[12] * a[2] * a[7] + a[12] * a[3] * a[6];
-	inv[10] = a[0] * a[5] * a[15] - a[0] * a[7] * a[13] - a[4] * a[1] * a[15] + a[4] * a[3] * a[13] + a[12] * a[1] * a[7] - a[12] * a[3] * a[5];
-	inv[14] = -a[0] * a[5] * a[14] + a[0] * a[6] * a[13] + a[4] * a[1] * a[14] - a[4] * a[2] * a[13] - a[12] * a[1] * a[6] + a[12] * a[2] * a[5];
-	inv[3] = -a[1] * a[6] * a[11] + a[1] * a[7] * a[10] + a[5] * a[2] * a[11] - a[5] * a[3] * a[10] - a[9] * a[2] * a[7] + a[9] * a[3] * a[6];
-	inv[7] = a[0] * a[6] * a[11] - a[0] * a[7] * a[10] - a[4] * a[2] * a[11] + a[4] * a[3] * a[10] + a[8] * a[2] * a[7] - a[8] * a[3] * a[6];
-	inv[11] = -a[0] * a[5] * a[11] + a[0] * a[7] * a[9] + a[4] * a[1] * a[11] - a[4] * a[3] * a[9] - a[8] * a[1] * a[7] + a[8] * a[3] * a[5];
-	inv[15] = a[0] * a[5] * a[10] - a[0] * a[6] * a[9] - a[4] * a[1] * a[10] + a[4] * a[2] * a[9] + a[8] * a[1] * a[6] - a[8] * a[2] * a[5];
-	double det = a[0] * inv[0] + a[1] * inv[4] + a[2] * inv[8] + a[3] * inv[12];
-	if (det == 0.0) return false;
-	det = 1.0 / det;
-	for (int i = 0; i < 16; i++) out[i] = float(inv[i] * det);
-	return true;
+static bool invert4(const float a[16], float out[16]) { // Mat4.Inv, types/matrix.go:108-138 (float32, same order)
+	types::Mat4 m;
+	memcpy(m.m, a, sizeof m.m);
+	bool singular = false;
+	const types::Mat4 inv = m.Inv(&singular);
+	memcpy(out, inv.m, sizeof inv.m);
+	return !singular;
 }
 
 static Vec3 xform(const float m[16], Vec3 v) {
@@ -188,6 +175,7 @@ Error Compile(const Input &in, Output *out) { // compiler.go:81-231
 	for (size_t i = 0; i < in.instances.size(); i++) {
 		const MeshInstance &mi = in.instances[i];
 		if (mi.meshIndex >= in.meshes.size()) return Error{POLARIS_E_BAD_SCENE, "mesh instance references a missing mesh"};
+		if (mi.hasBounds) { instVols[i] = {{mi.bbox[0], mi.bbox[1]}, mi.center}; continue; }
 		Vec3 lo{FLT_MAX, FLT_MAX, FLT_MAX}, hi{-FLT_MAX, -FLT_MAX, -FLT_MAX};
 		const Vec3 a = meshLo[mi.meshIndex], b = meshHi[mi.meshIndex];
 		for (int c = 0; c < 8; c++) {
@@ -219,6 +207,7 @@ Error Compile(const Input &in, Output *out) { // compiler.go:81-231
 		std::vector<bvh::BoundedVolume> vols(pm.primitives.size());
 		for (size_t i = 0; i < vols.size(); i++) {
 			const Primitive &p = pm.primitives[i];
+			if (p.hasBounds) { vols[i] = {{p.bbox[0], p.bbox[1]}, p.center}; continue; }
 			Vec3 lo = vmin(vmin(p.vertices[0], p.vertices[1]), p.vertices[2]), hi = vmax(vmax(p.vertices[0], p.vertices[1]), p.vertices[2]);
 			vols[i] = {{lo, hi}, {0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)}};
 		}
@@ -288,6 +277,197 @@ Error Compile(const Input &in, Output *out) { // compiler.go:81-231
 			out->emissives.push_back(e);
 		}
 	}
+	return Error::Nil();
+}
+
+// ---- material expressions -> layered material trees (compiler.go:271-552) -----------------------
+namespace {
+
+struct MaterialCompiler {
+	const ParsedScene &in;
+	Output &out;
+	std::map<int, int32_t> matIndexToMatRoot;        // compiler.go:29
+	std::map<std::string, int32_t> texIndexCache;    // compiler.go:33
+	std::vector<std::string> matRefList;             // compiler.go:39
+
+	static std::string dirOf(const std::string &path) {
+		const size_t slash = path.find_last_of('/');
+		return slash == std::string::npos ? std::string(".") : (slash == 0 ? std::string("/") : path.substr(0, slash));
+	}
+
+	// bakeTexture, compiler.go:496-552
+	Error bakeTexture(const Material &mat, const std::string &texName, int32_t *index) {
+		std::string rel = texName;
+		for (char &c : rel) if (c == '\\') c = '/'; // asset.NewResource, resource.go:48
+		*index = -1;
+		if (rel.find("://") != std::string::npos) {
+			out.warnings.push_back("\"" + mat.name + "\": skipping remote texture \"" + texName + "\" (no network in this build)");
+			return Error::Nil();
+		}
+		const std::string path = mat.assetRelPath.empty() ? rel : dirOf(mat.assetRelPath) + "/" + rel;
+		const auto cached = texIndexCache.find(path);
+		if (cached != texIndexCache.end()) { *index = cached->second; return Error::Nil(); }
+		FILE *probe = fopen(path.c_str(), "rb");
+		if (!probe) { // a texture that cannot be opened is skipped with a warning, compiler.go:499-502
+			out.warnings.push_back("\"" + mat.name + "\": skipping missing texture \"" + texName + "\"");
+			return Error::Nil();
+		}
+		fclose(probe);
+		texture::Texture tex;
+		if (Error e = texture::Load(path, &tex)) return Error{e.code, "\"" + mat.name + "\": " + e.msg};
+		PolarisTextureMetadata md{};
+		md.format = tex.format; md.width = tex.width; md.height = tex.height;
+		md.data_offset = uint32_t(out.textureData.size());
+		out.textureData.insert(out.textureData.end(), tex.data.begin(), tex.data.end());
+		while (out.textureData.size() % 4) out.textureData.push_back(0); // align4, compiler.go:555-562
+		out.textureMeta.push_back(md);
+		*index = int32_t(out.textureMeta.size() - 1);
+		texIndexCache[path] = *index;
+		return Error::Nil();
+	}
+
+	// setMaterialNodeParameter, compiler.go:441-492
+	Error setParameter(const Material &mat, PolarisMaterialNode *node, const material::Param &p) {
+		using material::Param;
+		if (p.name == material::ParamReflectance || p.name == material::ParamSpecularity || p.name == material::ParamRadiance) {
+			if (p.kind == Param::Vec3) { node->k[0] = p.v[0]; node->k[1] = p.v[1]; node->k[2] = p.v[2]; node->k[3] = 0.0f; }
+			else if (p.kind == Param::Texture) return bakeTexture(mat, p.s, &node->tex);
+		} else if (p.name == material::ParamTransmittance) {
+			if (p.kind == Param::Vec3) { node->t[0] = p.v[0]; node->t[1] = p.v[1]; node->t[2] = p.v[2]; node->t[3] = 0.0f; }
+			else if (p.kind == Param::Texture) return bakeTexture(mat, p.s, &node->right_child);
+		} else if (p.name == material::ParamIntIOR || p.name == material::ParamExtIOR) {
+			float *dst = p.name == material::ParamExtIOR ? &node->ext_ior : &node->int_ior;
+			if (p.kind == Param::Float) *dst = p.f;
+			else if (p.kind == Param::MaterialName) return material::IOR(p.s, dst);
+		} else if (p.name == material::ParamScale) {
+			node->scale = p.f;
+		} else if (p.name == material::ParamRoughness) {
+			if (p.kind == Param::Float) node->scale = p.f;
+			else if (p.kind == Param::Texture) return bakeTexture(mat, p.s, &node->roughness_tex);
+		}
+		return Error::Nil();
+	}
+
+	// generateMaterial, compiler.go:313-327
+	Error generateMaterial(const Material &mat, int32_t *root) {
+		std::unique_ptr<material::Expr> expr;
+		if (Error e = material::ParseExpression(mat.expression, &expr)) return Error{e.code, "material \"" + mat.name + "\": " + e.msg};
+		if (Error e = expr->Validate()) return Error{e.code, "material \"" + mat.name + "\": " + e.msg};
+		matRefList.push_back(mat.name);
+		return generateTree(mat, *expr, root);
+	}
+
+	// generateMaterialTree, compiler.go:331-438: children first, then the node itself
+	Error generateTree(const Material &mat, const material::Expr &e, int32_t *index) {
+		using material::Expr;
+		PolarisMaterialNode node{};
+		node.left_child = uint32_t(-1); node.right_child = -1; node.tex = -1; node.roughness_tex = -1; // Union1 {0,-1,-1,-1}, Union5 {-1}
+		node.int_ior = material::DefaultIntIOR;
+		node.ext_ior = material::DefaultExtIOR;
+		auto child = [&](const std::unique_ptr<Expr> &c, int32_t *dst) -> Error { return generateTree(mat, *c, dst); };
+		auto set4 = [](float *dst, const float *src) { memcpy(dst, src, 16); };
+		int32_t tmp = -1;
+		switch (e.kind) {
+		case Expr::MaterialRef: {
+			for (const std::string &seen : matRefList)
+				if (seen == e.ref) {
+					std::string chain;
+					for (size_t i = 0; i < matRefList.size(); i++) chain += (i ? " -> " : "") + matRefList[i];
+					return Error{POLARIS_E_BAD_SCENE, "detected circular dependency loop while processing \"" + matRefList[0] + "\"; " + chain + " => " + e.ref};
+				}
+			for (const Material &m : in.materials)
+				if (m.name == e.ref) return generateMaterial(m, index);
+			return Error{POLARIS_E_BAD_SCENE, "material \"" + mat.name + "\" references undefined material \"" + e.ref + "\""};
+		}
+		case Expr::Bxdf:
+			node.type = e.bxdfType;
+			switch (e.bxdfType) { // defaults, compiler.go:363-387
+			case POLARIS_BXDF_DIFFUSE: set4(node.k, material::DefaultReflectance); break;
+			case POLARIS_BXDF_CONDUCTOR: set4(node.k, material::DefaultSpecularity); break;
+			case POLARIS_BXDF_DIELECTRIC: set4(node.k, material::DefaultSpecularity); set4(node.t, material::DefaultTransmittance); break;
+			case POLARIS_BXDF_ROUGH_CONDUCTOR: set4(node.k, material::DefaultSpecularity); node.scale = material::DefaultRoughness; break;
+			case POLARIS_BXDF_ROUGH_DIELECTRIC:
+				set4(node.k, material::DefaultSpecularity); set4(node.t, material::DefaultTransmittance); node.scale = material::DefaultRoughness;
+				break;
+			case POLARIS_BXDF_EMISSIVE: set4(node.k, material::DefaultRadiance); node.scale = material::DefaultRadianceScaler; break;
+			}
+			for (const material::Param &p : e.params)
+				if (Error err = setParameter(mat, &node, p)) return err;
+			break;
+		case Expr::Mix:
+		case Expr::MixMap:
+			node.type = e.kind == Expr::Mix ? POLARIS_MAT_OP_MIX : POLARIS_MAT_OP_MIX_MAP;
+			if (Error err = child(e.left, &tmp)) return err;
+			node.left_child = uint32_t(tmp);
+			if (Error err = child(e.right, &node.right_child)) return err;
+			if (e.kind == Expr::Mix) node.k[0] = e.weight;
+			else if (Error err = bakeTexture(mat, e.texture, &node.tex)) return err;
+			break;
+		case Expr::BumpMap:
+		case Expr::NormalMap:
+			node.type = e.kind == Expr::BumpMap ? POLARIS_MAT_OP_BUMP_MAP : POLARIS_MAT_OP_NORMAL_MAP;
+			if (Error err = child(e.left, &tmp)) return err;
+			node.left_child = uint32_t(tmp);
+			if (Error err = bakeTexture(mat, e.texture, &node.tex)) return err;
+			break;
+		case Expr::Disperse:
+			node.type = POLARIS_MAT_OP_DISPERSE;
+			if (Error err = child(e.left, &tmp)) return err;
+			node.left_child = uint32_t(tmp);
+			for (int k = 0; k < 3; k++) { node.k[k] = e.intIOR[k]; node.t[k] = e.extIOR[k]; }
+			break;
+		}
+		out.materialNodes.push_back(node);
+		*index = int32_t(out.materialNodes.size() - 1);
+		return Error::Nil();
+	}
+
+	// createLayeredMaterialTrees, compiler.go:271-309
+	Error run() {
+		for (size_t i = 0; i < in.materials.size(); i++) {
+			const Material &mat = in.materials[i];
+			if (!mat.used) continue; // reached lazily through material references
+			matRefList.clear();
+			int32_t root = -1;
+			if (Error e = generateMaterial(mat, &root)) return e;
+			matIndexToMatRoot[int(i)] = root;
+			if (mat.name == SceneDiffuseMaterialName) out.sceneDiffuseMatIndex = root;
+			else if (mat.name == SceneEmissiveMaterialName) out.sceneEmissiveMatIndex = root;
+		}
+		return Error::Nil();
+	}
+};
+
+} // namespace
+
+Error CompileScene(const ParsedScene &in, Output *out) { // compiler.Compile, compiler.go:44-75
+	if (!out) return Error{POLARIS_E_BAD_ARGUMENT, "output is null"};
+	Output mats;
+	MaterialCompiler mc{in, mats, {}, {}, {}};
+	if (Error e = mc.run()) return e;
+
+	Input geo;
+	geo.meshes = in.meshes;
+	geo.instances = in.instances;
+	geo.materialNodes = mats.materialNodes;
+	geo.textureMeta = mats.textureMeta;
+	geo.textureData = mats.textureData;
+	geo.sceneDiffuseMatIndex = mats.sceneDiffuseMatIndex;
+	geo.sceneEmissiveMatIndex = mats.sceneEmissiveMatIndex;
+	geo.minPrimitivesPerLeaf = in.minPrimitivesPerLeaf;
+	geo.materialRoots.assign(in.materials.size(), -1);
+	for (const auto &kv : mc.matIndexToMatRoot) geo.materialRoots[size_t(kv.first)] = kv.second;
+	for (const Mesh &m : in.meshes)
+		for (const Primitive &p : m.primitives)
+			if (p.materialIndex < 0 || size_t(p.materialIndex) >= geo.materialRoots.size() || geo.materialRoots[size_t(p.materialIndex)] < 0)
+				return Error{POLARIS_E_BAD_SCENE, "mesh \"" + m.name + "\": a primitive references a material that was not compiled"};
+	if (Error e = Compile(geo, out)) return e;
+	out->warnings = mats.warnings;
+
+	out->camera = scene::Camera(in.camera.fov); // setupCamera, compiler.go:233-241
+	out->camera.Position = in.camera.eye;
+	out->camera.LookAt = in.camera.look;
+	out->camera.Up = in.camera.up;
 	return Error::Nil();
 }
 

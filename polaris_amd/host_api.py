@@ -45,6 +45,18 @@ def load() -> C.CDLL:
         lib.polaris_host_compiled_view.argtypes = [vp]
         lib.polaris_host_compiled_free.argtypes = [vp]
         lib.polaris_host_compiled_free.restype = None
+        lib.polaris_host_material_check.argtypes = [C.c_char_p, C.c_char_p]
+        lib.polaris_host_material_ior.argtypes = [C.c_char_p, C.POINTER(C.c_float)]
+        lib.polaris_host_read_scene.restype = vp
+        lib.polaris_host_read_scene.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p]
+        lib.polaris_host_compiled_camera.argtypes = [vp, C.c_float, C.c_int, vp, vp, vp]
+        lib.polaris_host_compiled_camera.restype = None
+        lib.polaris_host_compiled_warnings.argtypes = [vp, C.c_char_p, C.c_size_t]
+        lib.polaris_host_compiled_warnings.restype = C.c_size_t
+        lib.polaris_host_parse_obj.argtypes = [C.c_char_p, vp, vp, vp, C.c_uint32, C.c_char_p, C.c_size_t, C.c_char_p]
+        lib.polaris_host_parse_mtl.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.c_char_p]
+        lib.polaris_host_select_face_index.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_char_p]
+        lib.polaris_host_texture_load.argtypes = [C.c_char_p, vp, vp, C.c_size_t, C.c_char_p]
         _lib = lib
     return _lib
 
@@ -132,6 +144,28 @@ def bvh_build(boxes, min_leaf: int):
     return nodes[:n].copy(), [int(v) for v in sizes[: nl.value]]
 
 
+def _scene_from_handle(lib, h, name):
+    """Copy the arrays of a compiled scene (CompiledBox handle) into a polaris_amd.scenes.Scene."""
+    from .scenes import Scene
+
+    v = lib.polaris_host_compiled_view(h).contents
+
+    def grab(ptr, count, dtype):
+        if not ptr or count == 0:
+            return np.zeros(0, dtype=dtype)
+        nbytes = count * np.dtype(dtype).itemsize
+        return np.frombuffer(C.string_at(ptr, nbytes), dtype=dtype).copy()
+
+    nt = v.num_triangles
+    return Scene(
+        bvh_nodes=grab(v.bvh_nodes, v.num_bvh_nodes, T.BVH_NODE), mesh_instances=grab(v.mesh_instances, v.num_mesh_instances, T.MESH_INSTANCE),
+        material_nodes=grab(v.material_nodes, v.num_material_nodes, T.MATERIAL_NODE), emissives=grab(v.emissives, v.num_emissives, T.EMISSIVE),
+        texture_data=grab(v.texture_data, v.texture_data_bytes, np.uint8), texture_meta=grab(v.texture_meta, v.num_textures, T.TEXTURE_META),
+        vertices=grab(v.vertices, nt * 12, np.float32).reshape(-1, 4), normals=grab(v.normals, nt * 12, np.float32).reshape(-1, 4),
+        uvs=grab(v.uvs, nt * 6, np.float32).reshape(-1, 2), material_index=grab(v.material_index, nt, np.uint32),
+        scene_diffuse_mat_index=int(v.scene_diffuse_mat_index), scene_emissive_mat_index=int(v.scene_emissive_mat_index), name=name)
+
+
 def compile_scene(meshes, instances, mats, *, scene_diffuse=-1, scene_emissive=-1, min_leaf=10, name="compiled"):
     """The C++ scene compiler (polaris_amd/host/scene_compiler.cpp = compiler.go partitionGeometry) on
     the same inputs polaris_amd.scenes.compile_scene takes: list[scenes.Mesh], list[(mesh index, 4x4
@@ -161,22 +195,91 @@ def compile_scene(meshes, instances, mats, *, scene_diffuse=-1, scene_emissive=-
     if not h:
         raise RuntimeError(f"compile_scene: {err.value.decode()}")
     try:
-        v = lib.polaris_host_compiled_view(h).contents
-
-        def grab(ptr, count, dtype):
-            if not ptr or count == 0:
-                return np.zeros(0, dtype=dtype)
-            nbytes = count * np.dtype(dtype).itemsize
-            return np.frombuffer(C.string_at(ptr, nbytes), dtype=dtype).copy()
-
-        nt = v.num_triangles
-        sc = Scene(
-            bvh_nodes=grab(v.bvh_nodes, v.num_bvh_nodes, T.BVH_NODE), mesh_instances=grab(v.mesh_instances, v.num_mesh_instances, T.MESH_INSTANCE),
-            material_nodes=grab(v.material_nodes, v.num_material_nodes, T.MATERIAL_NODE), emissives=grab(v.emissives, v.num_emissives, T.EMISSIVE),
-            texture_data=grab(v.texture_data, v.texture_data_bytes, np.uint8), texture_meta=grab(v.texture_meta, v.num_textures, T.TEXTURE_META),
-            vertices=grab(v.vertices, nt * 12, np.float32).reshape(-1, 4), normals=grab(v.normals, nt * 12, np.float32).reshape(-1, 4),
-            uvs=grab(v.uvs, nt * 6, np.float32).reshape(-1, 2), material_index=grab(v.material_index, nt, np.uint32),
-            scene_diffuse_mat_index=int(v.scene_diffuse_mat_index), scene_emissive_mat_index=int(v.scene_emissive_mat_index), name=name)
+        sc = _scene_from_handle(lib, h, name)
     finally:
         lib.polaris_host_compiled_free(h)
     return sc
+
+
+# ---- scene front-end: Wavefront OBJ/MTL reader, material expressions, textures ------------------
+def material_check(expr: str):
+    """(status, message): 0 valid, 1 parse error, 2 semantic error (material.ParseExpression + Validate)."""
+    err = C.create_string_buffer(512)
+    rc = load().polaris_host_material_check(expr.encode(), err)
+    return rc, err.value.decode()
+
+
+def material_ior(name: str):
+    out = C.c_float()
+    return None if load().polaris_host_material_ior(name.encode(), C.byref(out)) else float(out.value)
+
+
+def read_scene(path=None, *, content=None, name="embedded", aspect=1.0, invert_y=False, min_leaf=0):
+    """reader.ReadScene: parse a Wavefront .obj (+ .mtl, textures) and compile it.  Returns a
+    polaris_amd.scenes.Scene whose eye/frustum come from the file's camera_* statements for a frame of
+    the given aspect; `.camera` = dict(fov, eye, look, up), `.warnings` = list of strings."""
+    lib = load()
+    err = C.create_string_buffer(1024)
+    h = lib.polaris_host_read_scene(path.encode() if path is not None else None, name.encode(),
+                                    content.encode() if content is not None else None, min_leaf, err)
+    if not h:
+        raise RuntimeError(err.value.decode())
+    try:
+        sc = _scene_from_handle(lib, h, os.path.basename(path) if path else name)
+        params = np.zeros(10, np.float32)
+        eye = np.zeros(3, np.float32)
+        fr = np.zeros((4, 4), np.float32)
+        lib.polaris_host_compiled_camera(h, float(aspect), int(invert_y), params.ctypes.data, eye.ctypes.data, fr.ctypes.data)
+        sc.eye, sc.frustum = eye, fr
+        sc.camera = {"fov": float(params[0]), "eye": params[1:4].copy(), "look": params[4:7].copy(), "up": params[7:10].copy()}
+        n = lib.polaris_host_compiled_warnings(h, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        lib.polaris_host_compiled_warnings(h, buf, n + 1)
+        sc.warnings = [w for w in buf.value.decode().split("\n") if w]
+    finally:
+        lib.polaris_host_compiled_free(h)
+    return sc
+
+
+def parse_obj(content: str, max_instances=64):
+    """Parse-level view of an .obj: dict(counts, transforms [n][4][4] (row = matrix row), boxes, materials)."""
+    counts = np.zeros(4, np.uint32)
+    xf = np.zeros((max_instances, 16), np.float32)
+    boxes = np.zeros((max_instances, 9), np.float32)
+    mats = C.create_string_buffer(1 << 16)
+    err = C.create_string_buffer(1024)
+    if load().polaris_host_parse_obj(content.encode(), counts.ctypes.data, xf.ctypes.data, boxes.ctypes.data, max_instances, mats, len(mats), err):
+        raise RuntimeError(err.value.decode())
+    n = int(counts[1])
+    materials = [tuple(l.split("\t")) for l in mats.value.decode().split("\n") if l]
+    return {"meshes": int(counts[0]), "instances": n, "materials": materials, "mesh0_primitives": int(counts[3]),
+            "transforms": xf[:n].reshape(n, 4, 4).transpose(0, 2, 1).copy(), "bbox": boxes[:n, :6].reshape(n, 2, 3).copy(), "center": boxes[:n, 6:].copy()}
+
+
+def parse_mtl(content: str):
+    """[(name, generated material expression)] of a material library (parseMaterials + GetExpression)."""
+    mats = C.create_string_buffer(1 << 16)
+    err = C.create_string_buffer(1024)
+    if load().polaris_host_parse_mtl(content.encode(), mats, len(mats), err):
+        raise RuntimeError(err.value.decode())
+    return [tuple(l.split("\t")) for l in mats.value.decode().split("\n") if l]
+
+
+def select_face_index(token: str, list_len: int, rel_offset: int = 0):
+    out = C.c_int(-1)
+    err = C.create_string_buffer(256)
+    if load().polaris_host_select_face_index(token.encode(), list_len, rel_offset, C.byref(out), err):
+        raise ValueError(err.value.decode())
+    return out.value
+
+
+def texture_load(path: str):
+    """(format, width, height, texel bytes) of an image file as the scene compiler bakes it."""
+    meta = np.zeros(4, np.uint32)
+    err = C.create_string_buffer(512)
+    lib = load()
+    if lib.polaris_host_texture_load(path.encode(), meta.ctypes.data, None, 0, err):
+        raise RuntimeError(err.value.decode())
+    data = np.zeros(int(meta[3]), np.uint8)
+    lib.polaris_host_texture_load(path.encode(), meta.ctypes.data, data.ctypes.data, data.size, err)
+    return int(meta[0]), int(meta[1]), int(meta[2]), data

@@ -41,7 +41,7 @@ def harness():
 def traverse(lib, sc, rays, max_leaf, any_hit=False):
     rays = np.ascontiguousarray(rays, dtype=np.float32)
     hit = np.zeros((rays.shape[0], 6), np.int32)
-    cnt = np.zeros(6, np.uint64)
+    cnt = np.zeros(7, np.uint64)
     err = C.create_string_buffer(256)
     view = T.scene_view(sc)
     rc = lib.layout_check_traverse(C.byref(view), max_leaf, rays.ctypes.data, rays.shape[0], int(any_hit), hit.ctypes.data,
@@ -55,7 +55,7 @@ def camera_and_bounce_rays(oracle, sc, W=48, H=36, seed=7):
     from oracle import pybind as ob
 
     req = ob.make_request(W, H, spp=1, bounces=1, rr=2)
-    _, _, taps = oracle.trace(sc, req, scenes.make_seeds(seed, 1, 1), tap_sample=0)
+    _, _, taps = oracle.trace(sc, req, scenes.make_seeds(1, 1, base=seed), tap_sample=0)
     prim = taps["primary_rays"].copy()
     rng = np.random.default_rng(seed)
     hitm = taps["primary_hit"] != 0
@@ -102,6 +102,70 @@ def test_leaf_subdivision_never_changes_a_hit(harness, oracle, name):
         got_any, _ = traverse(harness, sc, rays, max_leaf, any_hit=True)
         assert np.array_equal(got_any[:, 5], base_any[:, 5]), f"{name}: occlusion differs with max_leaf_tris={max_leaf}"
         assert cnt[5] <= 32  # traversal stack
+
+
+def _obj_room(tmp):
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import obj_fixtures
+    from polaris_amd import host_api
+
+    return host_api.read_scene(obj_fixtures.write_cornell(str(tmp)), aspect=4 / 3)
+
+
+RANDOM_RAY_SCENES = {
+    "obj-room": _obj_room,  # rotated + scaled instances: the reader's instance boxes do NOT bound them (wavefront.go:514-519)
+    "transformed": lambda tmp: scenes.transformed_instances(),
+    "cubes": lambda tmp: scenes.instanced_cubes(),
+    "cornell-refbvh": lambda tmp: scenes.cornell_box(compiler="reference"),
+    "materials": lambda tmp: scenes.textured_materials_scene(),
+}
+
+
+@pytest.mark.parametrize("name", list(RANDOM_RAY_SCENES))
+def test_layout_traversal_equals_the_reference_query_on_random_rays(harness, oracle, name, tmp_path, request):
+    """The kernels' traversal rules (near child first, distance culling where a box really bounds
+    its subtree, DFS-rank tie break) over the uploaded layout vs rayIntersectionQuery /
+    rayIntersectionTest of the oracle -- and of the compiled reference where it exists -- on
+    rays the camera never produces: hit flags, instance, triangle and the bits of t, u, v."""
+    from oracle import pybind as ob
+
+    sc = RANDOM_RAY_SCENES[name](tmp_path)
+    box_lo = np.minimum(sc.vertices[:, :3].min(axis=0), -1.0) - 0.5
+    box_hi = np.maximum(sc.vertices[:, :3].max(axis=0), 1.0) + 0.5
+    rng = np.random.default_rng(5)
+    n = 60000
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 0:3] = rng.uniform(box_lo, box_hi, size=(n, 3))
+    d = rng.normal(size=(n, 3))
+    rays[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays[:, 3] = np.float32(3.402823466e+38)
+    rays[: n // 8, 4 + (np.arange(n // 8) % 3)] = 0.0  # axis-parallel components: infinities in the slab test
+    shadow = rays.copy()
+    shadow[:, 3] = rng.uniform(0.05, 4.0, size=n)
+    ref = ob.Oracle("ref_pm") if ob.available("ref_pm") else None
+    h, wuvt, it = oracle.intersect(sc, rays)
+    ha, _, _ = oracle.intersect(sc, shadow, any_hit=True)
+    assert 0 < h.sum() < n
+    if ref is not None:
+        rh, rw, rit = ref.intersect(sc, rays)
+        rha, _, _ = ref.intersect(sc, shadow, any_hit=True)
+        assert np.array_equal(rh, h) and np.array_equal(rha, ha)
+        assert np.array_equal(rw.view(np.uint32)[h != 0], wuvt.view(np.uint32)[h != 0]) and np.array_equal(rit[h != 0], it[h != 0])
+    hm = h != 0
+    for max_leaf in (0, 2):
+        got, cnt = traverse(harness, sc, rays, max_leaf)
+        assert np.array_equal(got[:, 5] != 0, hm), f"{name}: hit flags differ (max_leaf_tris={max_leaf})"
+        assert np.array_equal(got[hm][:, [1, 0]], it[hm])
+        assert np.array_equal(got[hm][:, 2], wuvt[hm][:, 3].view(np.int32))
+        assert np.array_equal(got[hm][:, 3:5], wuvt[hm][:, 1:3].view(np.int32))
+        got_any, _ = traverse(harness, sc, shadow, max_leaf, any_hit=True)
+        assert np.array_equal(got_any[:, 5] != 0, ha != 0)
+        if name == "obj-room":
+            assert cnt[6] > 0  # the non-bounding instance boxes were detected (and are never culled by distance)
+        if name == "cornell-refbvh":
+            assert cnt[6] == 0
 
 
 def test_subdivision_cuts_triangle_tests_on_big_leaves(harness, oracle):

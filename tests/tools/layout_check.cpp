@@ -38,7 +38,8 @@ inline float slab(const float *lo, const float *hi, V3 o, V3 inv, float maxDist)
 extern "C" {
 
 // rays: [n][8] = origin.xyz, maxDist, dir.xyz, unused.  hit: [n][6] = tri, inst, bits(t), bits(u), bits(v), found.
-// counters: [0] pair steps, [1] triangle tests, [2] leaf visits, [3] pair records, [4] triangle slots, [5] stack need.
+// counters: [0] pair steps, [1] triangle tests, [2] leaf visits, [3] pair records, [4] triangle slots, [5] stack need,
+//           [6] inner nodes holding a box that does not bound its subtree.
 // any_hit != 0: first-found semantics is order dependent, so only `found` is meaningful.
 int layout_check_traverse(const PolarisSceneView *sc, int max_leaf_tris, const float *rays, uint32_t n, int any_hit,
                           int32_t *hit, uint64_t *counters, char *err, size_t err_len) {
@@ -66,9 +67,10 @@ int layout_check_traverse(const PolarisSceneView *sc, int max_leaf_tris, const f
 				steps++;
 				float t0 = slab(P.lo0, P.hi0, o, inv, maxDist), t1 = slab(P.lo1, P.hi1, o, inv, maxDist);
 				if (!any_hit) {
-					const float lim = bt * 1.001f;
-					if (t0 > lim) t0 = kFltMax;
-					if (t1 > lim) t1 = kFltMax;
+					float f0, f1;
+					memcpy(&f0, &P.pad0, 4); memcpy(&f1, &P.pad1, 4);
+					if (t0 > bt * f0) t0 = kFltMax;
+					if (t1 > bt * f1) t1 = kFltMax;
 				}
 				int c0 = P.ref0, c1 = P.ref1;
 				const bool h0 = t0 < kFltMax, h1 = t1 < kFltMax;
@@ -142,7 +144,7 @@ int layout_check_traverse(const PolarisSceneView *sc, int max_leaf_tris, const f
 	}
 	if (counters) {
 		counters[0] = steps; counters[1] = tests; counters[2] = visits;
-		counters[3] = L.pairs.size(); counters[4] = L.tris.size(); counters[5] = (uint64_t)L.max_stack;
+		counters[3] = L.pairs.size(); counters[4] = L.tris.size(); counters[5] = (uint64_t)L.max_stack; counters[6] = L.unbounded_boxes;
 	}
 	return 0;
 }
