@@ -6,7 +6,7 @@ compiled scene arrays, request, seeds) and the outputs of the reference's own Op
 on the host: the trace accumulator, the ray counters, and the primary-ray taps.  Fixtures are
 data; no reference source is stored.
 
-    python tests/tools/make_golden.py
+    python tests/tools/make_golden.py [fixture names]
 """
 import os
 import sys
@@ -28,7 +28,22 @@ CASES = [
     ("materials_32", "materials", 32, 32, 4, 5, 3, 0, 32),
     ("materials_norr_1bounce", "materials", 24, 16, 3, 1, 2, 0, 16),
     ("transformed_instances_32", "transformed", 32, 24, 4, 5, 3, 0, 24),  # rotated / non-uniformly scaled instances, instanced light  # rr disabled: minRR = bounces+1 (cmd/render.go:42-45)
+    # a Wavefront scene through the C++ reader + compiler: `instance` statements with rotation and scale (whose boxes the
+    # reference's reader computes from the translation alone), mat_expr trees, PNM + PNG textures, a refractive prism
+    ("obj_room_40", "obj-room", 40, 30, 4, 5, 3, 0, 30),
 ]
+
+
+def build_scene(key, aspect):
+    if key == "obj-room":
+        import tempfile
+
+        sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+        import obj_fixtures
+        from polaris_amd import host_api
+
+        return host_api.read_scene(obj_fixtures.write_cornell(tempfile.mkdtemp()), aspect=aspect)
+    return scenes.SCENES[key](aspect)
 
 
 def main():
@@ -36,8 +51,11 @@ def main():
     ref = ob.Oracle("ref_pm")
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
+    only = set(sys.argv[1:])  # optional: fixture names to (re)generate
     for name, key, W, H, spp, B, rr, by, bh in CASES:
-        sc = scenes.SCENES[key](W / H)
+        if only and name not in only:
+            continue
+        sc = build_scene(key, W / H)
         seeds = scenes.make_seeds(spp, B, base=0xC0FFEE + len(name))
         req = ob.make_request(W, H, spp=spp, bounces=B, rr=rr, block_y=by, block_h=bh)
         acc, st, taps = ref.trace(sc, req, seeds, tap_sample=0)
