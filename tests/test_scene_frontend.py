@@ -299,6 +299,14 @@ def test_texture_decoders(tmp_path):
     px = data.view(np.float32).reshape(3, 2, 4)
     assert fmt == T.TEX_RGBA32F and np.array_equal(px[..., :3], c16.astype(np.float32) / np.float32(65535)) and np.all(px[..., 3] == 1.0)
 
+    # asset/texure/texture_test.go:14-66: a 1x1 8-bit RGBA PNG -> Rgba8, 4 bytes; a 1x1 16-bit RGBA PNG -> Rgba32F, 16 bytes
+    F.write_png(str(tmp_path / "one8.png"), np.zeros((1, 1, 4), np.uint8))
+    F.write_png(str(tmp_path / "one16.png"), np.zeros((1, 1, 4), np.uint16), bit_depth=16)
+    fmt, w, h, data = H.texture_load(str(tmp_path / "one8.png"))
+    assert (fmt, w, h, data.size) == (T.TEX_RGBA8, 1, 1, 4)
+    fmt, w, h, data = H.texture_load(str(tmp_path / "one16.png"))
+    assert (fmt, w, h, data.size) == (T.TEX_RGBA32F, 1, 1, 16)
+
     rgbe = np.array([[[128, 64, 32, 129], [255, 0, 0, 128], [0, 0, 0, 0]]], np.uint8)
     F.write_hdr(str(tmp_path / "e.hdr"), rgbe)
     fmt, w, h, data = H.texture_load(str(tmp_path / "e.hdr"))
