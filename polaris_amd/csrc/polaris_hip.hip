@@ -82,10 +82,11 @@ struct polaris_hip_tracer {
 	int64_t opt_samples_per_batch = 0; // 0 = auto
 	int opt_exact = 0;
 	int opt_packet_shadow = 0;  // shadow rays of the first N bounces go through the packet kernel too
-	int opt_packet_primary = 1; // wave-packet traversal (k_trace_packet) for bounce 0
+	int opt_packet_primary = -1; // wave-packet traversal (k_trace_packet) for bounce 0: 1/0, -1 = by scene size (packet_primary below)
+	bool packet_primary = true;  // resolved at upload
 	int opt_time_kernels = 0;
 	int opt_trace_wgs_per_cu = 0; // 0 = auto (what the LDS stack admits)
-	int opt_max_leaf_tris = 2;    // subdivide bigger triangle leaves at upload (0 = keep the caller's leaves)
+	int opt_max_leaf_tris = -1;   // subdivide bigger triangle leaves at upload (0 = keep the caller's leaves, -1 = by scene size)
 	int opt_stage_lds = 1;    // k_shade stages material nodes / lights / texture metadata in LDS when they fit
 	int opt_shade_wave = 1;   // 1 = persistent wave-per-chunk shading (k_shade_wave), 0 = one workgroup per chunk (k_shade)
 	int opt_shade_wgs_per_cu = 8;
@@ -260,8 +261,8 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 	const uint32_t persistent = std::min<uint32_t>(wgs, (uint32_t)h->num_cus * per_cu);
 	for (uint32_t b = 0; b < B; b++) {
 		{
-			Timed t(h, (b == 0 && h->opt_packet_primary) ? "intersect_packet" : "intersect", q);
-			if (b == 0 && h->opt_packet_primary)
+			Timed t(h, (b == 0 && h->packet_primary) ? "intersect_packet" : "intersect", q);
+			if (b == 0 && h->packet_primary)
 				hipLaunchKernelGGL(k_trace_packet<false>, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, (float4 *)nullptr, h->d_stats);
 			else if (h->opt_traversal)
 				launch_trace<false>(h, P, persistent, wgs, nullptr);
@@ -425,7 +426,11 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 	std::lock_guard<std::mutex> lk(h->mu);
 	if (!sc) return fail(h, POLARIS_E_BAD_ARGUMENT, "scene view is null");
 	SceneLayout L;
-	std::string err = build_layout(*sc, L, h->opt_max_leaf_tris);
+	// Defaults by scene size (measured): small scenes live in L2/LDS and are bound by
+	// instruction issue -> small leaves and packet traversal of camera rays pay; scenes far larger than
+	// the caches are bound by node fetches -> fewer, fuller leaves and one ray per lane.
+	const int max_leaf = h->opt_max_leaf_tris >= 0 ? h->opt_max_leaf_tris : (sc->num_triangles <= 32768u ? 2 : 4);
+	std::string err = build_layout(*sc, L, max_leaf);
 	if (err == "@retry-without-subdivision") { // the deeper tree would not fit the traversal stack
 		L = SceneLayout();
 		err = build_layout(*sc, L, 0);
@@ -458,6 +463,7 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 	h->scene = SceneDev{vertices, normals, uvs, mat_index, nodes, emissives, tex_meta, tex_data, sc->num_emissives,
 	                    sc->scene_diffuse_mat_index, sc->num_material_nodes, sc->num_textures};
 	h->max_stack = L.max_stack;
+	if (h->opt_packet_primary < 0) h->packet_primary = sc->num_triangles <= 262144u;
 	h->have_scene = true;
 	return POLARIS_OK;
 }
@@ -482,7 +488,7 @@ int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value
 	const std::string k(key);
 	if (k == "samples_per_batch") h->opt_samples_per_batch = value < 0 ? 0 : value;
 	else if (k == "exact_accumulate") h->opt_exact = value != 0;
-	else if (k == "packet_primary") h->opt_packet_primary = value != 0;
+	else if (k == "packet_primary") { h->opt_packet_primary = value < 0 ? -1 : (value != 0); if (value >= 0) h->packet_primary = value != 0; }
 	else if (k == "packet_shadow") h->opt_packet_shadow = (int)std::max<int64_t>(0, std::min<int64_t>(value, POLARIS_MAX_BOUNCES));
 	else if (k == "time_kernels") h->opt_time_kernels = value != 0;
 	else if (k == "traversal") h->opt_traversal = value != 0;
@@ -492,7 +498,7 @@ int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value
 	else if (k == "stage_lds") h->opt_stage_lds = value != 0;
 	else if (k == "overlap") h->opt_overlap = (int)std::max<int64_t>(1, std::min<int64_t>(value, polaris_hip_tracer::kMaxPipes));
 	else if (k == "trace_wgs_per_cu") h->opt_trace_wgs_per_cu = (int)std::max<int64_t>(0, std::min<int64_t>(value, 64));
-	else if (k == "max_leaf_tris") h->opt_max_leaf_tris = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20)); // next upload
+	else if (k == "max_leaf_tris") h->opt_max_leaf_tris = (int)std::max<int64_t>(-1, std::min<int64_t>(value, 1 << 20)); // next upload
 	else return fail(h, POLARIS_E_BAD_ARGUMENT, "unknown option '%s'", key);
 	return POLARIS_OK;
 }
@@ -717,7 +723,7 @@ int polaris_hip_tap_primary(polaris_hip_tracer *h, const PolarisBlockRequest *r,
 	hipStream_t q = h->stream;
 	HIP_TRY(h, hipMemcpyAsync(h->d_seeds, &seed, sizeof seed, hipMemcpyHostToDevice, q));
 	hipLaunchKernelGGL(k_generate, dim3(Npad / WG), dim3(WG), 0, q, st0, h->cam, h->d_seeds, 1u, 0u, N, Npad, h->W, r->block_y, 1);
-	if (h->opt_packet_primary) hipLaunchKernelGGL(k_trace_packet<false>, dim3(Npad / WG), dim3(WG), 0, q, st0, h->bvh, (float4 *)nullptr, h->d_stats);
+	if (h->packet_primary) hipLaunchKernelGGL(k_trace_packet<false>, dim3(Npad / WG), dim3(WG), 0, q, st0, h->bvh, (float4 *)nullptr, h->d_stats);
 	else hipLaunchKernelGGL(k_intersect, dim3(Npad / WG), dim3(WG), 0, q, st0, h->bvh);
 	HIP_TRY(h, hipGetLastError());
 	std::vector<float4> ro(N), rd(N), ht(N);

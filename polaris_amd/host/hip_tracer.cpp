@@ -46,11 +46,14 @@ void HipTracer::Close() {
 }
 
 Error HipTracer::UpdateState(UpdateMode mode, ChangeType type, const void *data, Duration *took) {
-	switch (type) {
-	case ChangeType::FrameDimensions: dims_ = *static_cast<const FrameDims *>(data); has_dims_ = true; break;
-	case ChangeType::SceneData: scene_ = static_cast<const PolarisSceneView *>(data); has_scene_ = true; break;
-	case ChangeType::CameraData: cam_ = *static_cast<const CameraData *>(data); has_cam_ = true; break;
-	default: return Error{POLARIS_E_BAD_ARGUMENT, "unsupported change type"};
+	{
+		std::lock_guard<std::mutex> lk(change_mu_);
+		switch (type) {
+		case ChangeType::FrameDimensions: dims_ = *static_cast<const FrameDims *>(data); has_dims_ = true; break;
+		case ChangeType::SceneData: scene_ = static_cast<const PolarisSceneView *>(data); has_scene_ = true; break;
+		case ChangeType::CameraData: cam_ = *static_cast<const CameraData *>(data); has_cam_ = true; break;
+		default: return Error{POLARIS_E_BAD_ARGUMENT, "unsupported change type"};
+		}
 	}
 	if (mode == UpdateMode::Synchronous) return commitChanges(took);
 	if (took) *took = Duration{0};
@@ -59,6 +62,7 @@ Error HipTracer::UpdateState(UpdateMode mode, ChangeType type, const void *data,
 
 Error HipTracer::commitChanges(Duration *took) { // tracer/opencl/tracer.go:161-192
 	const auto start = clock_::now();
+	std::lock_guard<std::mutex> lk(change_mu_);
 	Error err;
 	if (has_dims_ && !err) { err = check(polaris_hip_resize(h_, dims_.w, dims_.h)); has_dims_ = false; }
 	if (has_scene_ && !err) { err = check(polaris_hip_upload_scene(h_, scene_)); has_scene_ = false; scene_ = nullptr; }

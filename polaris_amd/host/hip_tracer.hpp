@@ -54,6 +54,7 @@ private:
 	Stats stats_;
 	PolarisTraceStats last_{};
 	std::mutex mu_;
+	std::mutex change_mu_; // the change buffer: the interactive renderer queues camera updates from another thread (opengl.go:298-300)
 	// change buffer: latest update of each type wins (tracer/opencl/tracer.go:150-158)
 	bool has_dims_ = false, has_scene_ = false, has_cam_ = false;
 	FrameDims dims_{};

@@ -653,6 +653,45 @@ def textured_materials_scene(aspect=1.0) -> Scene:
     return sc
 
 
+def material_ball(aspect=1.0, detail=1.0) -> Scene:
+    """Stand-in for BASELINE.json configs[3] ("Mitsuba scene", 1920x1080, 512 spp): the Mitsuba material
+    preview ball is not redistributable and there is no network, so this is a procedural scene of the same
+    character -- ~60 k triangles in one mesh (a finely tessellated coated ball on a pedestal, a rough glass
+    ball, a polished ring of small spheres), layered materials (mix of rough conductor over textured diffuse,
+    bump map, rough dielectric), a checker floor, two area lights and an environment light."""
+    mt = MaterialTable()
+    chk = mt.texture(T.TEX_RGBA8, checker_rgba8(64, 8, (235, 235, 225), (70, 75, 90)))
+    rng = np.random.default_rng(11)
+    yy, xx = np.mgrid[0:32, 0:32]
+    bump = mt.texture(T.TEX_L8, (127 + 90 * np.sin(xx * 0.7) * np.sin(yy * 0.7) + rng.integers(-8, 8, (32, 32))).clip(0, 255).astype(np.uint8))
+    coat = mt.mix(mt.rough_conductor((0.95, 0.78, 0.45), roughness=0.2), mt.diffuse((0.55, 0.12, 0.1)), 0.35)
+    ball_mat = mt.bump_map(coat, bump)
+    glass = mt.rough_dielectric((1, 1, 1), (0.92, 0.97, 0.95), roughness=0.15, int_ior=1.5)
+    steel = mt.rough_conductor((0.8, 0.82, 0.85), roughness=0.3)
+    floor = mt.diffuse(tex=chk)
+    stand = mt.diffuse((0.25, 0.25, 0.28))
+    key = mt.emissive((14, 13, 11), 1.0)
+    fill = mt.emissive((3, 4, 6), 1.0)
+    bg = mt.diffuse((0.35, 0.4, 0.5))
+    env = mt.emissive((0.5, 0.6, 0.8), 0.6)
+    lat, lon = max(6, int(120 * detail)), max(8, int(200 * detail))
+    parts = [
+        uv_sphere((0, 1.35, 0), 1.0, ball_mat, n_lat=lat, n_lon=lon),                                   # 48 k triangles at detail 1
+        uv_sphere((1.9, 0.55, 0.9), 0.55, glass, n_lat=max(5, int(50 * detail)), n_lon=max(6, int(60 * detail))),  # 6 k
+        box((-0.45, 0, -0.45), (0.45, 0.4, 0.45), stand),
+        quad((-8, 0, -8), (-8, 0, 8), (8, 0, 8), (8, 0, -8), floor, uv=((0, 0), (6, 0), (6, 6), (0, 6))),
+        quad((-2.5, 4.5, 1.0), (-0.5, 4.5, 1.0), (-0.5, 4.5, 3.0), (-2.5, 4.5, 3.0), key),
+        quad((3.5, 0.5, -2.0), (3.5, 2.5, -2.0), (3.5, 2.5, 0.0), (3.5, 0.5, 0.0), fill),
+    ]
+    n_ring = max(4, int(24 * detail))
+    for i in range(n_ring):  # 24 small spheres of 10x12x2 = 240 triangles
+        a = 2 * math.pi * i / n_ring
+        parts.append(uv_sphere((1.45 * math.cos(a), 0.16, 1.45 * math.sin(a)), 0.16, steel, n_lat=max(4, int(10 * detail)), n_lon=max(5, int(12 * detail))))
+    sc = compile_scene([merge(parts)], [(0, np.eye(4))], mt, scene_diffuse=bg, scene_emissive=env, name="material-ball")
+    sc.set_camera(eye=(2.2, 2.6, 5.2), look=(0.2, 1.0, 0), fov=0.62, aspect=aspect)
+    return sc
+
+
 def displaced_grid(n=64, size=10.0, amp=0.6, mat=0, seed=3):
     """(n x n) quads = 2 n^2 triangles of a smooth random height field (flat normals)."""
     rng = np.random.default_rng(seed)
@@ -735,6 +774,8 @@ SCENES = {
     "transformed": transformed_instances,
     "instanced": lambda aspect=1.0: instanced_stress(32, aspect=aspect),
     "instanced-small": lambda aspect=1.0: instanced_stress(6, 9, 10, aspect=aspect),
+    "material-ball": material_ball,
+    "material-ball-small": lambda aspect=1.0: material_ball(aspect, detail=0.12),
     "terrain": lambda aspect=1.0: unique_stress(708, aspect),
     "terrain-small": lambda aspect=1.0: unique_stress(48, aspect),
 }

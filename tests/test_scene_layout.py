@@ -120,6 +120,7 @@ RANDOM_RAY_SCENES = {
     "cubes": lambda tmp: scenes.instanced_cubes(),
     "cornell-refbvh": lambda tmp: scenes.cornell_box(compiler="reference"),
     "materials": lambda tmp: scenes.textured_materials_scene(),
+    "material-ball-small": lambda tmp: scenes.SCENES["material-ball-small"](),
 }
 
 
