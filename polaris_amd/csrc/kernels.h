@@ -118,6 +118,16 @@ __device__ __forceinline__ float slab_entry(float4 lo, float4 hi, f3 o, f3 inv, 
 
 struct HitRec { float t, u, v; int tri; int inst; uint32_t irank, trank; };
 
+// A leaf reference is ~code.  code & 15 = triangle count (1..15) and code >> 4 = first triangle slot:
+// the common case costs no fetch.  code & 15 == 0: look the leaf up by node id (code >> 4) --
+// instance leaves (count 0) and leaves of more than 15 triangles.  Returns (-first | -instance, count).
+__device__ __forceinline__ int2 leaf_of(const BvhDev &B, int ref) {
+	const uint32_t code = (uint32_t)~ref;
+	const uint32_t cnt = code & 15u;
+	if (cnt) return make_int2(-(int)(code >> 4), (int)cnt);
+	return B.leaves[code >> 4];
+}
+
 template <bool ANY_HIT>
 __device__ __forceinline__ bool traverse(const BvhDev &B, f3 O, f3 D, float maxDist, int (*stk)[WG], HitRec &best) {
 	const int lane = threadIdx.x;
@@ -147,7 +157,7 @@ __device__ __forceinline__ bool traverse(const BvhDev &B, f3 O, f3 D, float maxD
 			}
 			if (h0 || h1) { cur = h0 ? c0 : c1; continue; }
 		} else { // leaf (cur = ~node)
-			const int2 li = B.leaves[~cur];
+			const int2 li = leaf_of(B, cur);
 			if (li.y == 0) { // top-level leaf: enter the mesh instance (intersect.cl:239-252)
 				inst = -li.x;
 				const InstRec I = B.insts[inst];
@@ -416,7 +426,7 @@ __global__ __launch_bounds__(WG) void k_trace(Streams st, BvhDev B, uint32_t num
 		// ---- phase 2: leaves ---------------------------------------------------------------------
 		if (has && cur < 0) {
 			TC(c_leaf++; if (lane == __ffsll((long long)__ballot(true)) - 1) c_iter2++;)
-			const int2 li = B.leaves[~cur];
+			const int2 li = leaf_of(B, cur);
 			if (li.y == 0) { // top-level leaf: enter the instance
 				inst = -li.x;
 				const InstRec I = B.insts[inst];
@@ -551,7 +561,7 @@ __global__ __launch_bounds__(WG) void k_trace_packet(Streams st, BvhDev B, float
 			else need_pop = true;
 		} else {
 			const int unode = __builtin_amdgcn_readfirstlane(~cur);
-			const int2 li = B.leaves[unode];
+			const int2 li = leaf_of(B, ~unode);
 			if (li.y == 0) { // enter the instance (all lanes transform; only active ones matter)
 				inst = -li.x;
 				const InstRec I = B.insts[inst];

@@ -10,7 +10,9 @@
 //   * PairNode[node]: for every INNER node, the boxes of BOTH children side by side (64 B, one
 //     fetch per traversal step instead of the reference's two dependent 32 B fetches,
 //     kernels/intersect.cl:296-298) plus a tagged reference per child:
-//         ref >= 0  -> inner node index          ref < 0 -> ~leaf node index
+//         ref >= 0  -> inner node index          ref < 0 -> ~code of a leaf:
+//         code = first triangle slot << 4 | triangle count (1..15): no fetch needed to start testing;
+//         code = node index << 4 | 0: LeafInfo[node] has the details (instance leaves, leaves of > 15 triangles)
 //     and a cull factor per child (1.001, or +inf when the box does not bound its subtree).
 //   * LeafInfo[node] = (ldata, rdata) of a leaf: 8 B fetch when a leaf is popped.
 //   * Tri[slot] = {v0 | rank, e01 = v1 - v0 | scene triangle index, e02 = v2 - v0}: the two edge subtractions of
@@ -73,6 +75,7 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out, in
 	if (!sc.mesh_instances || NI == 0) return "scene has no mesh instances";
 	if (NT == 0 || !sc.vertices || !sc.normals || !sc.uvs || !sc.material_index) return "scene has no triangles";
 	if (NT > (1u << 30)) return "too many triangles";
+	if (NN >= (1u << 27)) return "too many BVH nodes";
 	if (sc.num_material_nodes == 0 || !sc.material_nodes) return "scene has no material nodes";
 	if (sc.num_emissives && !sc.emissives) return "emissive list pointer is null";
 	if (sc.num_textures && (!sc.texture_meta || !sc.texture_data)) return "texture pointers are null";
@@ -128,7 +131,14 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out, in
 	std::vector<uint32_t> slot_src;          // triangle slot of the kernels -> scene triangle (pass 2)
 	std::vector<int32_t> leaf_root(NN, -1);  // reachable triangle leaf -> root of its mesh BVH
 	std::vector<uint8_t> seen;
-	auto ref_of = [&](int32_t idx) { return is_leaf(nodes[idx]) ? ~idx : idx; };
+	// tagged child reference: inner node -> its index; leaf -> ~code, see the header comment
+	auto ref_of = [&](int32_t idx) -> int32_t {
+		const PolarisBvhNode &n = nodes[idx];
+		if (!is_leaf(n)) return idx;
+		const uint32_t first = (uint32_t)(-(int64_t)n.ldata);
+		if (n.rdata >= 1 && n.rdata <= 15 && first < (1u << 27) - 1u) return ~(int32_t)((first << 4) | (uint32_t)n.rdata);
+		return ~(int32_t)((uint32_t)idx << 4);
+	};
 
 	// iterative left-first DFS from `root`; level = 0 top tree, 1 bottom tree.  `need` tracks the
 	// number of stack entries a traversal can hold at a node (one pending sibling per level).
@@ -330,7 +340,7 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out, in
 				work.push_back({l + 1, mid, rg.hi});
 			}
 		}
-		if (nodes.size() > 0x3FFFFFFFull) return "too many BVH nodes";
+		if (nodes.size() >= (1ull << 27)) return "too many BVH nodes";
 	}
 	if (!subdivided) { // nothing to do: keep the caller's tree and triangle order
 		nodes.assign(sc.bvh_nodes, sc.bvh_nodes + NN);
