@@ -203,6 +203,7 @@ __device__ __forceinline__ bool traverse(const BvhDev &B, f3 O, f3 D, float maxD
 			if (sp == 0) return best.tri >= 0;
 			cur = stk[--sp][lane];
 			if (cur != kExitMarker) break;
+			if (sp == 0) return best.tri >= 0; // nothing pending above the instance: done, skip the restore
 			o = O; d = D; // leaving the instance: restore the world-space ray (intersect.cl:330-335)
 			inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)};
 		}
@@ -283,14 +284,19 @@ __device__ __forceinline__ float slab_entry_hw(float4 lo, float4 hi, f3 o, f3 in
 // ticket counter was measured first: it saturates at ~88 dequeues/us (MI355X_MICROARCH.md,
 // "dequeue"), a ~190 us floor under every launch of a 16 Ki-chunk batch.
 
-template <bool ANY_HIT, int STACK>
+template <bool ANY_HIT, int STACK, bool LDS_TOP>
 __global__ __launch_bounds__(WG) void k_trace(Streams st, BvhDev B, uint32_t num_chunks, uint32_t *ticket, float4 *acc,
                                               unsigned long long *stats) {
 	__shared__ int stk[STACK][WG]; // STACK = smallest of {16, 24, 32} that fits the scene: LDS per wave sets the occupancy
 	__shared__ uint32_t wg_cursor;
-	__shared__ float4 top[kLdsTopNodes * 4]; // first kLdsTopNodes PairNodes (breadth-first = the hot top of the tree)
 	if (threadIdx.x == 0) wg_cursor = 0;
-	{
+	// LDS_TOP (small scenes only): the first kLdsTopNodes PairNodes (breadth-first = the hot top of the
+	// tree) are staged in LDS.  The compiler turns the two-way fetch below into one FLAT load through a
+	// selected pointer; that is a win while a large share of the tree is in LDS (Cornell: -2 %) and a
+	// loss on big trees, where nearly every fetch is global and pays the FLAT path (-11 % / -18 % frame
+	// time on the 59 K / 1 M triangle scenes without it), so the host picks the variant by tree size.
+	__shared__ float4 top[LDS_TOP ? kLdsTopNodes * 4 : 1];
+	if (LDS_TOP) {
 		const uint32_t n4 = min((uint32_t)kLdsTopNodes, B.num_pairs) * 4;
 		const float4 *src = reinterpret_cast<const float4 *>(B.pairs);
 		for (uint32_t i = threadIdx.x; i < n4; i += WG) top[i] = src[i];
@@ -338,6 +344,7 @@ __global__ __launch_bounds__(WG) void k_trace(Streams st, BvhDev B, uint32_t num
 			if (sp == 0) { finish(false); return; }
 			cur = stk[--sp][tid];
 			if (cur != kExitMarker) return;
+			if (sp == 0) { finish(false); return; } // nothing pending above the instance: no need to restore the ray
 			const float4 o4 = src_o[slot], d4 = src_d[slot]; // leaving the instance: back to the world-space ray
 			o = xyz(o4); d = xyz(d4);
 			inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)};
@@ -403,7 +410,7 @@ __global__ __launch_bounds__(WG) void k_trace(Streams st, BvhDev B, uint32_t num
 			if (!descending) continue;
 			TC(c_node++; if (lane == __ffsll((long long)__ballot(true)) - 1) c_iter1++;)
 			PairNode P;
-			if (cur < kLdsTopNodes) { P.lo0 = top[4 * cur]; P.hi0 = top[4 * cur + 1]; P.lo1 = top[4 * cur + 2]; P.hi1 = top[4 * cur + 3]; }
+			if (LDS_TOP && cur < kLdsTopNodes) { P.lo0 = top[4 * cur]; P.hi0 = top[4 * cur + 1]; P.lo1 = top[4 * cur + 2]; P.hi1 = top[4 * cur + 3]; }
 			else P = B.pairs[cur];
 			float t0 = slab_entry_hw(P.lo0, P.hi0, o, inv, maxDist);
 			float t1 = slab_entry_hw(P.lo1, P.hi1, o, inv, maxDist);

@@ -224,15 +224,22 @@ int check_request(polaris_hip_tracer *h, const PolarisBlockRequest *r) {
 
 inline uint32_t grid_for(size_t n) { return (uint32_t)((n + WG - 1) / WG); }
 
-template <bool ANY_HIT>
-void launch_trace(polaris_hip_tracer *h, polaris_hip_tracer::Pipe &P, uint32_t grid, uint32_t chunks, float4 *acc) {
+template <bool ANY_HIT, bool LDS_TOP>
+void launch_trace_v(polaris_hip_tracer *h, polaris_hip_tracer::Pipe &P, uint32_t grid, uint32_t chunks, float4 *acc) {
 	hipStream_t q = P.q;
 	if (h->max_stack <= 16)
-		hipLaunchKernelGGL((k_trace<ANY_HIT, 16>), dim3(grid), dim3(WG), 0, q, P.st, h->bvh, chunks, h->d_tickets, acc, h->d_stats);
+		hipLaunchKernelGGL((k_trace<ANY_HIT, 16, LDS_TOP>), dim3(grid), dim3(WG), 0, q, P.st, h->bvh, chunks, h->d_tickets, acc, h->d_stats);
 	else if (h->max_stack <= 24)
-		hipLaunchKernelGGL((k_trace<ANY_HIT, 24>), dim3(grid), dim3(WG), 0, q, P.st, h->bvh, chunks, h->d_tickets, acc, h->d_stats);
+		hipLaunchKernelGGL((k_trace<ANY_HIT, 24, LDS_TOP>), dim3(grid), dim3(WG), 0, q, P.st, h->bvh, chunks, h->d_tickets, acc, h->d_stats);
 	else
-		hipLaunchKernelGGL((k_trace<ANY_HIT, 32>), dim3(grid), dim3(WG), 0, q, P.st, h->bvh, chunks, h->d_tickets, acc, h->d_stats);
+		hipLaunchKernelGGL((k_trace<ANY_HIT, 32, LDS_TOP>), dim3(grid), dim3(WG), 0, q, P.st, h->bvh, chunks, h->d_tickets, acc, h->d_stats);
+}
+
+template <bool ANY_HIT>
+void launch_trace(polaris_hip_tracer *h, polaris_hip_tracer::Pipe &P, uint32_t grid, uint32_t chunks, float4 *acc) {
+	// top of the tree in LDS only while that is a large share of the tree (kernels.h, k_trace)
+	if (h->bvh.num_pairs <= 8u * kLdsTopNodes) launch_trace_v<ANY_HIT, true>(h, P, grid, chunks, acc);
+	else launch_trace_v<ANY_HIT, false>(h, P, grid, chunks, acc);
 }
 
 // One wavefront batch: K samples starting at sample s0, on pipeline p.
