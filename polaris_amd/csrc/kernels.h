@@ -662,7 +662,6 @@ struct ShadeArgs {
 	uint32_t bounce, min_rr;
 	int last_bounce;   // no closest-hit query follows (pipeline.go:203): do not emit indirect rays
 	int exact;         // accumulate into acc[pixelIndex] (trace accumulator) instead of lsum[path slot]
-	int stage_lds;     // stage material nodes / lights / texture metadata in LDS when they fit
 	float4 *acc;       // trace accumulator (exact) or lsum (batched)
 };
 
@@ -674,7 +673,8 @@ struct ShadeOut {
 
 // One ray through shadeHits / shade*RayMisses.  `gid_ref` is the ray's position in the reference's
 // compacted buffer (PRNG state, pt_integrator.cl:81), `sample` the sample the workgroup belongs to.
-__device__ __forceinline__ void shade_ray(const SceneDev &S, const ShadeArgs &A, uint32_t sample, uint32_t seed, uint32_t gid_ref,
+template <bool LDS>
+__device__ __forceinline__ void shade_ray(const SceneT<LDS> &S, const ShadeArgs &A, uint32_t sample, uint32_t seed, uint32_t gid_ref,
                                           float4 d4, float4 t4, float4 h4, ShadeOut &R) {
 	R.emit_ind = R.emit_occ = false;
 	R.hit = R.miss = R.emit = 0;
@@ -687,7 +687,7 @@ __device__ __forceinline__ void shade_ray(const SceneDev &S, const ShadeArgs &A,
 	const int tri = fbits(h4.w);
 	if (tri < 0) {
 		if (S.bg_node >= 0) { // pt_integrator.cl:214-275 (throughput is exactly 1 for primaries)
-			const PolarisMaterialNode *bg = S.nodes + S.bg_node;
+			typename Tbl<LDS>::Node bg = S.nodes + S.bg_node;
 			f2 uv = latlong_uv(xyz(d4));
 			f3 kd = mat_color(uv, bg->k, bg->tex, S);
 			f3 add = A.bounce == 0 ? kd : thr * kd;
@@ -715,7 +715,7 @@ __device__ __forceinline__ void shade_ray(const SceneDev &S, const ShadeArgs &A,
 		sf.uv = {bw * ua.x + bu * ub.x + bv * uc.x, bw * ua.y + bu * ub.y + bv * uc.y};
 	}
 	f3 tint = splat(1.0f);
-	const Mat m = select_material(S.mat_index[tri], sf, flags, tint, rng, S);
+	const MatT<LDS> m = select_material(S.mat_index[tri], sf, flags, tint, rng, S);
 	const float in_dot_n = dot(in_dir, sf.n);
 	if (m.type == POLARIS_BXDF_EMISSIVE) { // pt_integrator.cl:101-107 (indexed by pixel: SURVEY 5.8)
 		if (in_dot_n > 0.0f) {
@@ -743,7 +743,7 @@ __device__ __forceinline__ void shade_ray(const SceneDev &S, const ShadeArgs &A,
 	// light selection + sampling + MIS, :139-155
 	f3 e_dir = splat(0.0f), e_rad = splat(0.0f);
 	float e_pdf = 0.0f, sel_pdf = 0.0f, e_weight = 0.0f, e_dist = 0.0f;
-	const PolarisEmissive *em = nullptr;
+	typename Tbl<LDS>::Light em = nullptr;
 	if (S.num_emissives > 0) {
 		sel_pdf = pm_rcp((float)(int)S.num_emissives); // emissiveSelect, emissive_sampler.cl:226-237
 		const int ei = pm_clampi((int)(sample1.x * (int)S.num_emissives), 0, (int)S.num_emissives - 1);
@@ -785,35 +785,38 @@ constexpr uint32_t kLdsMatNodes = 64, kLdsLights = 16, kLdsTextures = 16;
 
 // Material nodes, emissive records and texture metadata are tiny tables that EVERY ray walks
 // through dependent loads (tree node -> texture record -> texel; light -> its material).  When they
-// fit they are staged in LDS once per workgroup, which takes those round trips out of the wave's
-// latency chain: the shading kernels are bound by exactly that chain times their occupancy (PMC:
-// waves wait on memory 59 % of their life, 4.1 cycles per VALU instruction, 4 waves per SIMD).
+// all fit they are staged in LDS once per workgroup (kernel variant LDS = true, chosen by the host),
+// which takes those round trips out of the wave's latency chain: the shading kernels are bound by
+// exactly that chain times their occupancy (PMC: waves wait on memory 59 % of their life, 4.1 cycles
+// per VALU instruction, 4 waves per SIMD).
 struct ShadeLds {
 	float4 nodes[kLdsMatNodes * 4];
 	float4 lights[kLdsLights * 5];
 	float4 texmeta[kLdsTextures];
 };
-__device__ __forceinline__ SceneDev stage_scene(const SceneDev &Sg, ShadeLds &L, int enabled) {
-	SceneDev S = Sg;
-	if (!enabled) return S;
-	const uint32_t tid = threadIdx.x;
-	if (Sg.num_nodes <= kLdsMatNodes) {
+// Ends in a __syncthreads() in both variants (k_shade_wave relies on it to publish its cursor).
+template <bool LDS>
+__device__ __forceinline__ SceneT<LDS> stage_scene(const SceneDev &Sg, ShadeLds &L) {
+	SceneT<LDS> S;
+	S.vertices = Sg.vertices; S.normals = Sg.normals; S.uvs = Sg.uvs; S.mat_index = Sg.mat_index; S.tex_data = Sg.tex_data;
+	S.num_emissives = Sg.num_emissives; S.bg_node = Sg.bg_node; S.num_nodes = Sg.num_nodes; S.num_textures = Sg.num_textures;
+	if constexpr (LDS) { // the host launches this variant only when all three tables fit
+		const uint32_t tid = threadIdx.x;
 		for (uint32_t i = tid; i < Sg.num_nodes * 4; i += WG) L.nodes[i] = reinterpret_cast<const float4 *>(Sg.nodes)[i];
-		S.nodes = reinterpret_cast<const PolarisMaterialNode *>(L.nodes);
-	}
-	if (Sg.num_emissives <= kLdsLights) {
 		for (uint32_t i = tid; i < Sg.num_emissives * 5; i += WG) L.lights[i] = reinterpret_cast<const float4 *>(Sg.emissives)[i];
-		S.emissives = reinterpret_cast<const PolarisEmissive *>(L.lights);
-	}
-	if (Sg.num_textures <= kLdsTextures) {
 		for (uint32_t i = tid; i < Sg.num_textures; i += WG) L.texmeta[i] = reinterpret_cast<const float4 *>(Sg.tex_meta)[i];
-		S.tex_meta = reinterpret_cast<const PolarisTextureMetadata *>(L.texmeta);
+		S.nodes = (typename Tbl<true>::Node)(L.nodes);
+		S.emissives = (typename Tbl<true>::Light)(L.lights);
+		S.tex_meta = (typename Tbl<true>::TexMeta)(L.texmeta);
+	} else {
+		S.nodes = Sg.nodes; S.emissives = Sg.emissives; S.tex_meta = Sg.tex_meta;
 	}
 	__syncthreads();
 	return S;
 }
 
 // k_shade: one workgroup per chunk, one lane per live ray, stable in-place compaction through LDS.
+template <bool LDS>
 __global__ __launch_bounds__(WG) void k_shade(Streams st, SceneDev Sg, ShadeArgs A) {
 	__shared__ uint32_t wave_ind[4], wave_occ[4];
 	__shared__ uint32_t blk_stats[3];
@@ -824,7 +827,7 @@ __global__ __launch_bounds__(WG) void k_shade(Streams st, SceneDev Sg, ShadeArgs
 		if (tid == 0) { st.cnt_occ[blockIdx.x] = 0; st.wg_stat[blockIdx.x] = 0; }
 		return;
 	}
-	const SceneDev S = stage_scene(Sg, lds, A.stage_lds);
+	const SceneT<LDS> S = stage_scene<LDS>(Sg, lds);
 	if (tid < 3) blk_stats[tid] = 0;
 	const uint32_t s = blockIdx.x / (A.Npad / WG);
 	const size_t base = (size_t)blockIdx.x * WG;
@@ -879,12 +882,12 @@ __global__ __launch_bounds__(WG) void k_shade(Streams st, SceneDev Sg, ShadeArgs
 // rays 64 at a time: a chunk with <= 64 survivors costs one pass of one wave instead of a
 // four-wave workgroup, and no __syncthreads is needed.  In-place safety: pass j reads slots
 // [64j, 64j+64) and writes at positions <= 64j + lane, i.e. only where this wave has already read.
+template <bool LDS>
 __global__ __launch_bounds__(WG) void k_shade_wave(Streams st, SceneDev Sg, ShadeArgs A, uint32_t num_chunks) {
 	__shared__ ShadeLds lds;
 	__shared__ uint32_t wg_cursor;
 	if (threadIdx.x == 0) wg_cursor = 0;
-	const SceneDev S = stage_scene(Sg, lds, 1); // (contains the __syncthreads that also publishes wg_cursor)
-	if (!A.stage_lds) __syncthreads();
+	const SceneT<LDS> S = stage_scene<LDS>(Sg, lds); // (ends in the __syncthreads that also publishes wg_cursor)
 	const uint32_t lane = threadIdx.x & 63;
 	const unsigned long long below = (1ull << lane) - 1ull;
 	const uint32_t wgs_per_sample = A.Npad / WG;

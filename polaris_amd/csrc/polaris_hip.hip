@@ -259,7 +259,9 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 	A.N = N; A.Npad = Npad; A.W = h->W; A.blockY = r->block_y;
 	A.min_rr = r->min_bounces_for_rr;
 	A.exact = exact ? 1 : 0;
-	A.stage_lds = h->opt_stage_lds;
+	// LDS-table variant of the shade kernels: only when all three tables fit (kernels.h, stage_scene)
+	const bool staged = h->opt_stage_lds && h->scene.num_nodes <= kLdsMatNodes && h->scene.num_emissives <= kLdsLights &&
+	                    h->scene.num_textures <= kLdsTextures;
 	A.acc = exact ? h->trace_acc : P.st.lsum;
 	// persistent grid: as many workgroups as the LDS stack lets a CU hold (16-entry stack: 16 KB per
 	// workgroup -> 8 by LDS, VGPRs allow 7-8 waves/SIMD; 32-entry: 5)
@@ -282,9 +284,11 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 			Timed t(h, "shade", q);
 			if (h->opt_shade_wave && (int)b >= (h->opt_shade_wave_from >= 0 ? h->opt_shade_wave_from : (int)r->min_bounces_for_rr)) {
 				const uint32_t grid = std::min<uint32_t>(wgs, (uint32_t)h->num_cus * (uint32_t)std::max(1, h->opt_shade_wgs_per_cu));
-				hipLaunchKernelGGL(k_shade_wave, dim3(grid), dim3(WG), 0, q, P.st, h->scene, A, wgs);
+				if (staged) hipLaunchKernelGGL(k_shade_wave<true>, dim3(grid), dim3(WG), 0, q, P.st, h->scene, A, wgs);
+				else hipLaunchKernelGGL(k_shade_wave<false>, dim3(grid), dim3(WG), 0, q, P.st, h->scene, A, wgs);
 			} else {
-				hipLaunchKernelGGL(k_shade, dim3(wgs), dim3(WG), 0, q, P.st, h->scene, A);
+				if (staged) hipLaunchKernelGGL(k_shade<true>, dim3(wgs), dim3(WG), 0, q, P.st, h->scene, A);
+				else hipLaunchKernelGGL(k_shade<false>, dim3(wgs), dim3(WG), 0, q, P.st, h->scene, A);
 			}
 		}
 		{

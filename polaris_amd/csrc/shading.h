@@ -45,20 +45,40 @@ constexpr float kLightEps = kEps * 1e3f;               // constants.cl:24
 constexpr float kMinRoughness = 0.1f;                  // constants.cl:27
 constexpr float kFltMax = 3.402823466e+38f;
 
+// The three small tables every shaded ray walks through dependent loads -- material nodes, emissive
+// records, texture metadata -- are read either from global memory or, when they all fit, from the
+// copy the shade kernels stage in LDS.  The address space is part of the pointer TYPE (LDS = true:
+// address_space(3), so the accesses compile to ds_read; generic pointers would compile to FLAT loads,
+// measured 10 % slower shading), hence the template parameter on everything that touches a table.
+template <bool LDS> struct Tbl;
+template <> struct Tbl<false> {
+	typedef const PolarisMaterialNode *Node;
+	typedef const PolarisEmissive *Light;
+	typedef const PolarisTextureMetadata *TexMeta;
+	typedef const float *F;
+};
+template <> struct Tbl<true> {
+	typedef const __attribute__((address_space(3))) PolarisMaterialNode *Node;
+	typedef const __attribute__((address_space(3))) PolarisEmissive *Light;
+	typedef const __attribute__((address_space(3))) PolarisTextureMetadata *TexMeta;
+	typedef const __attribute__((address_space(3))) float *F;
+};
+
 // Scene tables as the shade kernel sees them (device pointers).
-struct SceneDev {
+template <bool LDS> struct SceneT {
 	const float4 *vertices;             // [3T] original vertices (surface interpolation)
 	const float4 *normals;              // [3T]
 	const float2 *uvs;                  // [3T]
 	const uint32_t *mat_index;          // [T]
-	const PolarisMaterialNode *nodes;
-	const PolarisEmissive *emissives;
-	const PolarisTextureMetadata *tex_meta;
+	typename Tbl<LDS>::Node nodes;
+	typename Tbl<LDS>::Light emissives;
+	typename Tbl<LDS>::TexMeta tex_meta;
 	const uint8_t *tex_data;
 	uint32_t num_emissives;
 	int32_t bg_node;                    // scene_diffuse_mat_index or -1
 	uint32_t num_nodes, num_textures;   // table sizes (LDS staging in k_shade)
 };
+typedef SceneT<false> SceneDev; // what the host fills in
 
 // ---- PRNG: samplers/random_sampler.cl:7-16 ---------------------------------------------
 struct Rng { uint32_t sx, sy; };
@@ -73,7 +93,7 @@ PD f2 rng_next(Rng &r) {
 }
 
 // ---- util/transform.cl ----------------------------------------------------------------
-PD f3 xform_point(f3 v, const float *m) { // mul4x1, transform.cl:9-16 (column-major 4x4)
+template <class FP> PD f3 xform_point(f3 v, FP m) { // mul4x1, transform.cl:9-16 (column-major 4x4)
 	return {m[0] * v.x + m[4] * v.y + m[8] * v.z + m[12], m[1] * v.x + m[5] * v.y + m[9] * v.z + m[13],
 	        m[2] * v.x + m[6] * v.y + m[10] * v.z + m[14]};
 }
@@ -102,8 +122,9 @@ struct TexFetch {
 	uint32_t fmt, w, i00, i10, i01, i11; // element indices of TL, TR(bx,ty), BL(tx,by), BR
 	float cx, cy;
 };
-PD TexFetch tex_setup(f2 uv, int tex, const SceneDev &S) { // texture_sampler.cl:15-38 (shared prologue)
-	const PolarisTextureMetadata m = S.tex_meta[tex];
+template <bool LDS> PD TexFetch tex_setup(f2 uv, int tex, const SceneT<LDS> &S) { // texture_sampler.cl:15-38 (shared prologue)
+	PolarisTextureMetadata m; // field by field: the record may live in LDS
+	m.format = S.tex_meta[tex].format; m.width = S.tex_meta[tex].width; m.height = S.tex_meta[tex].height; m.data_offset = S.tex_meta[tex].data_offset;
 	TexFetch t;
 	float sx = (uv.x - pm_floor(uv.x)) * (float)m.width;
 	float sy = (uv.y - pm_floor(uv.y)) * (float)m.height;
@@ -128,7 +149,7 @@ PD float tex_chan(const TexFetch &t, uint32_t i, uint32_t c) { // one channel of
 	default: return ((const float *)t.base)[i];
 	}
 }
-PD f3 tex_sample3(f2 uv, int tex, const SceneDev &S) { // texGetSample3f, texture_sampler.cl:14-110
+template <bool LDS> PD f3 tex_sample3(f2 uv, int tex, const SceneT<LDS> &S) { // texGetSample3f, texture_sampler.cl:14-110
 	TexFetch t = tex_setup(uv, tex, S);
 	if (t.fmt > POLARIS_TEX_RGBA32F) return splat(0.0f);
 	bool rgba = t.fmt == POLARIS_TEX_RGBA8 || t.fmt == POLARIS_TEX_RGBA32F;
@@ -145,38 +166,38 @@ PD f3 tex_sample3(f2 uv, int tex, const SceneDev &S) { // texGetSample3f, textur
 	}
 	return r;
 }
-PD float tex_sample1(f2 uv, int tex, const SceneDev &S) { // texGetSample1f, texture_sampler.cl:114-184 (red channel)
+template <bool LDS> PD float tex_sample1(f2 uv, int tex, const SceneT<LDS> &S) { // texGetSample1f, texture_sampler.cl:114-184 (red channel)
 	TexFetch t = tex_setup(uv, tex, S);
 	if (t.fmt > POLARIS_TEX_RGBA32F) return 0.0f;
 	float r = bilerp(tex_chan(t, t.i00, 0), tex_chan(t, t.i10, 0), tex_chan(t, t.i01, 0), tex_chan(t, t.i11, 0), t.cx, t.cy);
 	return (t.fmt == POLARIS_TEX_RGBA8 || t.fmt == POLARIS_TEX_L8) ? r / 255.0f : r;
 }
-PD f3 tex_bump3(f2 uv, int tex, const SceneDev &S) { // texGetBumpSample3f, texture_sampler.cl:187-252
+template <bool LDS> PD f3 tex_bump3(f2 uv, int tex, const SceneT<LDS> &S) { // texGetBumpSample3f, texture_sampler.cl:187-252
 	TexFetch t = tex_setup(uv, tex, S);
 	if (t.fmt > POLARIS_TEX_RGBA32F) return splat(0.0f);
 	float s0 = tex_chan(t, t.i00, 0), s1 = tex_chan(t, t.i10, 0), s2 = tex_chan(t, t.i01, 0);
 	if (t.fmt == POLARIS_TEX_RGBA8 || t.fmt == POLARIS_TEX_L8) { s0 = s0 / 255.0f; s1 = s1 / 255.0f; s2 = s2 / 255.0f; }
 	return splat(0.5f) + 0.5f * normalize(mk3(s1 - s0, s2 - s0, 1.0f));
 }
-PD f3 mat_color(f2 uv, const float *def, int tex, const SceneDev &S) { // matGetSample3f, material_sampler.cl:97-104
+template <bool LDS> PD f3 mat_color(f2 uv, typename Tbl<LDS>::F def, int tex, const SceneT<LDS> &S) { // matGetSample3f, material_sampler.cl:97-104
 	return tex == -1 ? mk3(def[0], def[1], def[2]) : tex_sample3(uv, tex, S);
 }
-PD float mat_scalar(f2 uv, float def, int tex, const SceneDev &S) { // matGetSample1f, material_sampler.cl:108-114
+template <bool LDS> PD float mat_scalar(f2 uv, float def, int tex, const SceneT<LDS> &S) { // matGetSample1f, material_sampler.cl:108-114
 	return tex == -1 ? def : tex_sample1(uv, tex, S);
 }
 
 // ---- surface + selected material -----------------------------------------------------
 struct Surf { f3 p, n; f2 uv; };
-struct Mat {                       // the leaf selected by the material-tree walk
-	const PolarisMaterialNode *nd; // read in place
+template <bool LDS> struct MatT {  // the leaf selected by the material-tree walk
+	typename Tbl<LDS>::Node nd;    // read in place
 	uint32_t type;
 	float int_ior, ext_ior;        // after the dispersion override (material_sampler.cl:92-94)
 };
 
 // matSelectNode, samplers/material_sampler.cl:21-95.  `flags` are the path's dispersion
 // flags (PATH_FLAG_DISPERSE_R/G/B = 1/2/4, util/path.cl:4-6), updated in place.
-PD Mat select_material(uint32_t root, Surf &sf, uint32_t &flags, f3 &tint, Rng &rng, const SceneDev &S) {
-	const PolarisMaterialNode *nd = S.nodes + root;
+template <bool LDS> PD MatT<LDS> select_material(uint32_t root, Surf &sf, uint32_t &flags, f3 &tint, Rng &rng, const SceneT<LDS> &S) {
+	typename Tbl<LDS>::Node nd = S.nodes + root;
 	float forceInt = 0.0f, forceExt = 0.0f;
 	uint32_t type = nd->type;
 	for (int guard = 0; type >= POLARIS_MAT_OP_MIX && guard < 64; ++guard) {
@@ -269,7 +290,7 @@ PD f3 cosine_hemisphere(f3 n, f2 rnd) { // cosWeightedHemisphereGetSample, :101-
 }
 
 // ---- BxDFs: bxdf/*.cl ------------------------------------------------------------------
-PD float alpha_of(const Surf &sf, const Mat &m, const SceneDev &S) { // "Disney remapping", rough_conductor.cl:11-13
+template <bool LDS> PD float alpha_of(const Surf &sf, const MatT<LDS> &m, const SceneT<LDS> &S) { // "Disney remapping", rough_conductor.cl:11-13
 	float r = pm_clamp(mat_scalar(sf.uv, m.nd->scale, m.nd->roughness_tex, S), kMinRoughness, 1.0f);
 	return r * r;
 }
@@ -280,7 +301,7 @@ PD f3 specular_tail(const Surf &sf, float a, f3 ks, float f, f3 i, f3 o, f3 h) {
 	float denom = 4.0f * iDotN * oDotN;
 	return denom > 0.0f ? ks * f * d * g / denom : splat(0.0f);
 }
-PD f3 transmit_tail(const Surf &sf, const Mat &m, const SceneDev &S, float a, float etaI, float etaT, float f, float iDotN,
+template <bool LDS> PD f3 transmit_tail(const Surf &sf, const MatT<LDS> &m, const SceneT<LDS> &S, float a, float etaI, float etaT, float f, float iDotN,
                     f3 i, f3 o, f3 h) { // eq. 21: rough_dielectric.cl:73-93
 	float iDotH = pm_fabs(dot(i, h)), oDotH = pm_fabs(dot(o, h));
 	float oDotN = dot(o, sf.n);
@@ -292,14 +313,14 @@ PD f3 transmit_tail(const Surf &sf, const Mat &m, const SceneDev &S, float a, fl
 	f3 tf = mat_color(sf.uv, m.nd->t, m.nd->right_child, S);
 	return tf * (1.0f - f) * d * g * focus;
 }
-PD f3 mirror_value(const Surf &sf, const Mat &m, const SceneDev &S, float iDotN) { // conductor.cl:23-29
+template <bool LDS> PD f3 mirror_value(const Surf &sf, const MatT<LDS> &m, const SceneT<LDS> &S, float iDotN) { // conductor.cl:23-29
 	float f = m.int_ior != 0.0f ? schlick(m.ext_ior, m.int_ior, iDotN) : 1.0f;
 	f3 ks = mat_color(sf.uv, m.nd->k, m.nd->tex, S);
 	return iDotN != 0.0f ? f * ks / iDotN : splat(0.0f);
 }
 
 // bxdfGetSample, bxdf/bxdf.cl:31-55
-PD f3 bxdf_sample(const Surf &sf, const Mat &m, const SceneDev &S, f2 rnd, f3 i, f3 &o, float &pdf) {
+template <bool LDS> PD f3 bxdf_sample(const Surf &sf, const MatT<LDS> &m, const SceneT<LDS> &S, f2 rnd, f3 i, f3 &o, float &pdf) {
 	const f3 n = sf.n;
 	switch (m.type) {
 	case POLARIS_BXDF_DIFFUSE: { // diffuse.cl:12-20
@@ -370,7 +391,7 @@ PD f3 bxdf_sample(const Surf &sf, const Mat &m, const SceneDev &S, f2 rnd, f3 i,
 
 // bxdfGetPdf (bxdf.cl:58-78) and bxdfEval (bxdf.cl:82-105) for a given outgoing direction,
 // evaluated together (the NEE path of shadeHits needs both for the same direction).
-PD void bxdf_pdf_eval(const Surf &sf, const Mat &m, const SceneDev &S, f3 i, f3 o, bool want_eval, float &pdf, f3 &val) {
+template <bool LDS> PD void bxdf_pdf_eval(const Surf &sf, const MatT<LDS> &m, const SceneT<LDS> &S, f3 i, f3 o, bool want_eval, float &pdf, f3 &val) {
 	const f3 n = sf.n;
 	pdf = 0.0f;
 	val = splat(0.0f);
@@ -431,9 +452,9 @@ PD void bxdf_pdf_eval(const Surf &sf, const Mat &m, const SceneDev &S, f3 i, f3 
 // ---- lights: samplers/emissive_sampler.cl ---------------------------------------------
 struct LightSample { f3 radiance, dir; float pdf, dist; };
 
-PD LightSample light_sample(const Surf &sf, const PolarisEmissive *em, const SceneDev &S, f2 rnd) { // emissiveGetSample, :176-198
+template <bool LDS> PD LightSample light_sample(const Surf &sf, typename Tbl<LDS>::Light em, const SceneT<LDS> &S, f2 rnd) { // emissiveGetSample, :176-198
 	LightSample L;
-	const PolarisMaterialNode *mn = S.nodes + em->mat_node_index;
+	typename Tbl<LDS>::Node mn = S.nodes + em->mat_node_index;
 	if (em->type == POLARIS_EMISSIVE_ENVIRONMENT) { // :16-37
 		L.dir = cosine_hemisphere(sf.n, rnd);
 		L.pdf = pm_max(0.0f, dot(sf.n, L.dir)) * kInvPi;
@@ -472,7 +493,7 @@ PD LightSample light_sample(const Surf &sf, const PolarisEmissive *em, const Sce
 	return L;
 }
 
-PD float light_pdf(const Surf &sf, const PolarisEmissive *em, const SceneDev &S, f3 o) { // emissiveGetPdf, :201-223
+template <bool LDS> PD float light_pdf(const Surf &sf, typename Tbl<LDS>::Light em, const SceneT<LDS> &S, f3 o) { // emissiveGetPdf, :201-223
 	if (em->type == POLARIS_EMISSIVE_ENVIRONMENT) return pm_max(0.0f, dot(sf.n, o) * kInvPi); // :39-47
 	if (em->type != POLARIS_EMISSIVE_AREA) return 0.0f;
 	// areaLightGetPdf, :117-173 (edges go through the point transform: quirk kept)
