@@ -251,9 +251,9 @@ def main() -> None:
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
             if os.path.exists(tpath) and (W, H, spp, B, args.scene) == (512, 512, 128, 5, "cornell"):
-                kn = {"intersect": "pol::k_trace<false, 16>", "occlusion": "pol::k_trace<true, 16>", "shade": "pol::k_shade",
+                kn = {"intersect": "pol::k_trace<false", "occlusion": "pol::k_trace<true", "shade": "pol::k_shade<",
                       "generate": "pol::k_generate", "intersect_packet": "pol::k_trace_packet<false>"}[dom]
-                tk = json.load(open(tpath))["kernels"].get(kn)
+                tk = next((v for k, v in sorted(json.load(open(tpath))["kernels"].items()) if k.startswith(kn)), None)
                 if tk:
                     traffic = tk["hbm_bytes_per_launch"]    # PMC (FETCH_SIZE x2 + WRITE_SIZE), scripts/traffic.sh
             names = {"intersect": "k_trace<false,16> (closest hit, bounce rays)", "intersect_packet": "k_trace_packet<false> (camera rays)",
