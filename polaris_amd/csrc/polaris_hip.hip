@@ -53,6 +53,7 @@ struct polaris_hip_tracer {
 	BvhDev bvh{};
 	SceneDev scene{};
 	int max_stack = 0;
+	int trace_resident_per_cu = 6; // workgroups of the selected k_trace variant a CU holds at once (occupancy API, at upload)
 
 	// camera (tracer.go:175-179)
 	bool have_camera = false;
@@ -242,6 +243,18 @@ void launch_trace(polaris_hip_tracer *h, polaris_hip_tracer::Pipe &P, uint32_t g
 	else launch_trace_v<ANY_HIT, false>(h, P, grid, chunks, acc);
 }
 
+// Resident workgroups per CU of the closest-hit variant launch_trace<false> would pick.
+int trace_occupancy(polaris_hip_tracer *h) {
+	const bool lds_top = h->bvh.num_pairs <= 8u * kLdsTopNodes;
+	const void *fn;
+	if (h->max_stack <= 16) fn = lds_top ? (const void *)k_trace<false, 16, true> : (const void *)k_trace<false, 16, false>;
+	else if (h->max_stack <= 24) fn = lds_top ? (const void *)k_trace<false, 24, true> : (const void *)k_trace<false, 24, false>;
+	else fn = lds_top ? (const void *)k_trace<false, 32, true> : (const void *)k_trace<false, 32, false>;
+	int n = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, WG, 0) != hipSuccess || n < 1) n = h->max_stack <= 24 ? 6 : 5;
+	return std::min(n, 8);
+}
+
 // One wavefront batch: K samples starting at sample s0, on pipeline p.
 void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, uint32_t s0, uint32_t K, uint32_t N, uint32_t Npad,
                   bool exact, hipEvent_t resolve_after) {
@@ -263,9 +276,15 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 	const bool staged = h->opt_stage_lds && h->scene.num_nodes <= kLdsMatNodes && h->scene.num_emissives <= kLdsLights &&
 	                    h->scene.num_textures <= kLdsTextures;
 	A.acc = exact ? h->trace_acc : P.st.lsum;
-	// persistent grid: as many workgroups as the LDS stack lets a CU hold (16-entry stack: 16 KB per
+	// persistent grid: chunks are dealt to workgroups statically, so a workgroup that is not resident
+	// from the start begins with its whole share still to do -- the grid must not exceed what the GPU
+	// holds at once (measured: 8 workgroups per CU where 6 fit cost the closest-hit kernel 12 %).  One
+	// batch at a time: exactly the resident capacity.  Several batches in flight: two thirds of it per
+	// launch (the launches share the CUs; measured flat to +5 % across the bench scenes).
+	// (LDS: 16-entry stack: 16 KB per
 	// workgroup -> 8 by LDS, VGPRs allow 7-8 waves/SIMD; 32-entry: 5)
-	uint32_t per_cu = h->max_stack <= 16 ? 8u : (h->max_stack <= 24 ? 6u : 5u);
+	uint32_t per_cu = (uint32_t)std::max(1, h->trace_resident_per_cu);
+	if (std::min(h->opt_overlap, (int)polaris_hip_tracer::kMaxPipes) > 1 && !exact) per_cu = std::max(2u, per_cu * 2u / 3u);
 	if (h->opt_trace_wgs_per_cu > 0) per_cu = (uint32_t)h->opt_trace_wgs_per_cu;
 	const uint32_t persistent = std::min<uint32_t>(wgs, (uint32_t)h->num_cus * per_cu);
 	for (uint32_t b = 0; b < B; b++) {
@@ -475,6 +494,7 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 	                    sc->scene_diffuse_mat_index, sc->num_material_nodes, sc->num_textures};
 	h->max_stack = L.max_stack;
 	if (h->opt_packet_primary < 0) h->packet_primary = sc->num_triangles <= 262144u;
+	h->trace_resident_per_cu = trace_occupancy(h);
 	h->have_scene = true;
 	return POLARIS_OK;
 }
