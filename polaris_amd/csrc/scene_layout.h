@@ -65,8 +65,9 @@ inline bool is_leaf(const PolarisBvhNode &n) { return n.ldata <= 0; }
 // (surface-area-heuristic splits of the leaf's own triangles, where a split pays).  The reference's boxes, down to and including its
 // leaves, are kept bit for bit, so a triangle is still only ever tested when the reference's
 // traversal would have reached its leaf; the ADDED boxes only cull inside such a leaf and are
-// inflated by 2^-15 of the scene's extent in the mesh's object space -- four orders of magnitude
-// above the rounding of the slab test for any ray starting within ~100 scene radii -- so they can
+// inflated by 2^-13 of the scene's extent S in the mesh's object space.  A slab distance t carries a
+// rounding error of about |t| * 2^-23, the padding moves the slab planes by >= 2^-13 * S in t, so a
+// hit at distance t < 2^9 * S (a ray that starts within ~500 scene extents) is never lost -- they can
 // never hide a triangle the reference would have hit.  Results are unchanged (parity tests run
 // with and without); only the number of Moeller-Trumbore tests per ray drops.
 inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out, int max_leaf_tris = 0) {
@@ -249,7 +250,7 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out, in
 			}
 			const PolarisBvhNode &rb = sc.bvh_nodes[mi.bvh_root];
 			for (int k = 0; k < 3; k++) { ext = std::fmax(ext, std::fabs(rb.min[k])); ext = std::fmax(ext, std::fabs(rb.max[k])); }
-			float pad = ext * (1.0f / 32768.0f);
+			float pad = ext * (1.0f / 8192.0f);
 			if (!(pad <= 1e30f)) pad = 1e30f;
 			if (pad > root_pad[mi.bvh_root]) root_pad[mi.bvh_root] = pad;
 		}
