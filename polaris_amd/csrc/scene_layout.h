@@ -460,7 +460,9 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out, in
 			const Box &c = content[child];
 			bool inside = true;
 			for (int k = 0; k < 3; k++) {
-				const float tol = 1e-4f * std::fmax(std::fmax(std::fabs(c.lo[k]), std::fabs(c.hi[k])), c.hi[k] - c.lo[k]) + 1e-30f;
+				// a few ulps: the extent of an instance is recomputed here through the forward matrix in
+				// double, the host rounded its own way (far inside the 1.001 cull margin either way)
+				const float tol = 9.6e-7f * std::fmax(std::fmax(std::fabs(c.lo[k]), std::fabs(c.hi[k])), c.hi[k] - c.lo[k]) + 1e-30f;
 				if (!(n.min[k] - tol <= c.lo[k] && c.hi[k] <= n.max[k] + tol)) inside = false;
 			}
 			return inside ? kCullMargin : std::numeric_limits<float>::infinity();
