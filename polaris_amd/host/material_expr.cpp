@@ -135,6 +135,7 @@ struct Parser {
 	Lexer lx;
 	Tok tok;
 	bool failed = false;
+	int depth = 0; // operator nesting (the reference's yacc stack gives out at 1000 states)
 
 	explicit Parser(const std::string &s) : lx(s) { tok = lx.lex(); }
 	void advance() { tok = lx.lex(); }
@@ -220,6 +221,8 @@ struct Parser {
 		return nullptr;
 	}
 	std::unique_ptr<Expr> opSpec() {
+		struct Guard { int &d; Guard(int &x) : d(x) { d++; } ~Guard() { d--; } } guard(depth);
+		if (depth > 200) { lx.error("expression nested too deeply"); failed = true; return nullptr; }
 		const Tok op = tok;
 		auto e = std::make_unique<Expr>();
 		advance();

@@ -26,6 +26,7 @@ using types::Vec3;
 namespace {
 
 Error bad(const std::string &m) { return Error{POLARIS_E_BAD_SCENE, m}; }
+constexpr size_t kMaxIncludeDepth = 32;
 
 std::vector<std::string> fields(const std::string &line) { // strings.Fields
 	std::vector<std::string> out;
@@ -187,6 +188,8 @@ Error WavefrontSceneReader::Parse(const std::string &name, const std::string &co
 		Error err;
 		if (cmd == "call" || cmd == "mtllib") {
 			if (tok.size() != 2) return emitError(name, lineNum, fmt("unsupported syntax for \"%s\"; expected 1 argument; got %zu", cmd.c_str(), tok.size() - 1));
+			// (the reference recurses without a limit and dies on a file that calls itself)
+			if (errStack.size() >= kMaxIncludeDepth) return emitError(name, lineNum, "files nested too deeply (a file that calls itself?)");
 			errStack.insert(errStack.begin(), fmt("referenced from %s:%d [%s]", name.c_str(), lineNum, cmd.c_str()));
 			std::string inc = tok[1];
 			for (char &c : inc) if (c == '\\') c = '/';

@@ -176,3 +176,42 @@ def test_subdivision_cuts_triangle_tests_on_big_leaves(harness, oracle):
     _, c2 = traverse(harness, sc, rays, 2)
     assert c2[1] < 0.8 * c0[1]
     assert c2[4] == c0[4]  # same triangles, only regrouped
+
+
+# ---- corrupted scenes must be rejected (or be harmless), never walked out of bounds ----------------------
+@pytest.fixture(scope="module")
+def asan_harness():
+    """The same harness under AddressSanitizer + UBSan, in a child process (the sanitizer runtime must be
+    the first library of its process)."""
+    out = os.path.join(BUILD, "layout_check_asan")
+    drv = os.path.join(ROOT, "tests", "tools", "layout_corrupt.cpp")
+    deps = [SRC, drv, os.path.join(ROOT, "polaris_amd", "csrc", "scene_layout.h")]
+    os.makedirs(BUILD, exist_ok=True)
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                               "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "polaris_amd", "csrc"), SRC, drv, "-o", out])
+    return out
+
+
+@pytest.mark.parametrize("name", ["cubes", "cornell-refbvh", "materials"])
+def test_corrupted_scenes_are_rejected_not_followed(asan_harness, name, tmp_path):
+    """Every index the GPU would dereference is checked at upload (polaris_amd/csrc/scene_layout.h).
+    tests/tools/layout_corrupt.cpp overwrites random words of every scene array with hostile values,
+    builds the layout and, when the layout is accepted, traverses it: under ASan/UBSan nothing may be
+    read out of bounds and no traversal may run away."""
+    sc = RANDOM_RAY_SCENES[name](tmp_path) if name in RANDOM_RAY_SCENES else scenes.SCENES[name]()
+    raw = str(tmp_path / "scene.bin")
+    # flat binary for the C++ driver: counts then arrays
+    with open(raw, "wb") as f:
+        arrs = [sc.bvh_nodes, sc.mesh_instances, sc.material_nodes, sc.emissives, sc.texture_meta, sc.texture_data, sc.vertices, sc.normals, sc.uvs,
+                sc.material_index]
+        hdr = np.array([len(a) for a in arrs] + [sc.scene_diffuse_mat_index, sc.scene_emissive_mat_index], dtype=np.int64)
+        f.write(hdr.tobytes())
+        for a in arrs:
+            f.write(np.ascontiguousarray(a).tobytes())
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1")
+    p = subprocess.run([asan_harness, raw, "400", "7"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    assert "AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr, p.stderr[-3000:]
+    accepted, rejected = (int(t.split("=")[1]) for t in p.stdout.split()[:2])
+    assert rejected > 50 and accepted + rejected == 400
