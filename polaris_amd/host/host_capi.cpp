@@ -113,6 +113,12 @@ int polaris_host_renderer_read(void *h, uint8_t *rgba, size_t n_rgba, float *fra
 	if (frame_acc) if (Error e = p->ReadAccumulator(1, frame_acc, n_floats)) { box->error = e.msg; return e.code; }
 	return 0;
 }
+int polaris_host_renderer_save(void *h, const char *path) {
+	auto *box = static_cast<RendererBox *>(h);
+	if (Error e = box->r->SaveFrameBuffer(path)) { box->error = e.msg; return e.code; }
+	return 0;
+}
+int polaris_host_write_png(const char *path, const uint8_t *rgba, uint32_t w, uint32_t h) { return renderer::WritePNG(path, rgba, w, h).code; }
 const char *polaris_host_renderer_error(void *h) { return static_cast<RendererBox *>(h)->error.c_str(); }
 void polaris_host_renderer_free(void *h) {
 	auto *box = static_cast<RendererBox *>(h);

@@ -1,5 +1,10 @@
 #include "renderer.hpp"
 
+#include <zlib.h>
+
+#include <cstdio>
+#include <cstring>
+
 namespace polaris {
 namespace renderer {
 
@@ -105,6 +110,51 @@ Error DefaultRenderer::renderFrame(uint32_t accumulatedSamples) {
 	stats_.RenderTime = std::chrono::duration_cast<tracer::Duration>(clock_::now() - start);
 	for (size_t i = 0; i < tracers_.size(); i++) stats_.Tracers[i].RenderTime = tracers_[i]->GetStats()->RenderTime;
 	return Error::Nil();
+}
+
+Error DefaultRenderer::SaveFrameBuffer(const std::string &imgFile) {
+	auto *p = dynamic_cast<tracer::hip::HipTracer *>(Primary());
+	if (!p) return Error{POLARIS_E_UNSUPPORTED, "SaveFrameBuffer: the primary tracer has no readable frame buffer"};
+	const uint32_t W = options_.FrameW, H = options_.FrameH;
+	std::vector<uint8_t> rgba((size_t)W * H * 4);
+	if (Error e = p->ReadFrameBuffer(rgba.data(), rgba.size())) return e;
+	return WritePNG(imgFile, rgba.data(), W, H);
+}
+
+Error WritePNG(const std::string &path, const uint8_t *rgba, uint32_t w, uint32_t h) {
+	std::vector<uint8_t> raw((size_t)h * (1 + (size_t)w * 4));
+	for (uint32_t y = 0; y < h; y++) { // filter type 0 on every row
+		raw[(size_t)y * (1 + (size_t)w * 4)] = 0;
+		memcpy(&raw[(size_t)y * (1 + (size_t)w * 4) + 1], rgba + (size_t)y * w * 4, (size_t)w * 4);
+	}
+	uLongf clen = compressBound((uLong)raw.size());
+	std::vector<uint8_t> comp(clen);
+	if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 6) != Z_OK) return Error{POLARIS_E_DEVICE, "png: deflate failed"};
+	FILE *f = fopen(path.c_str(), "wb");
+	if (!f) return Error{POLARIS_E_BAD_ARGUMENT, "open " + path + ": cannot create file"};
+	auto be32 = [](uint8_t *p, uint32_t v) { p[0] = uint8_t(v >> 24); p[1] = uint8_t(v >> 16); p[2] = uint8_t(v >> 8); p[3] = uint8_t(v); };
+	auto chunk = [&](const char type[4], const uint8_t *body, uint32_t len) {
+		uint8_t hdr[8], crcb[4];
+		be32(hdr, len);
+		memcpy(hdr + 4, type, 4);
+		uLong crc = crc32(0L, hdr + 4, 4);
+		if (len) crc = crc32(crc, body, len);
+		be32(crcb, (uint32_t)crc);
+		fwrite(hdr, 1, 8, f);
+		if (len) fwrite(body, 1, len, f);
+		fwrite(crcb, 1, 4, f);
+	};
+	static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+	fwrite(sig, 1, 8, f);
+	uint8_t ihdr[13];
+	be32(ihdr, w); be32(ihdr + 4, h);
+	ihdr[8] = 8; ihdr[9] = 6; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0; // 8-bit RGBA, no interlace
+	chunk("IHDR", ihdr, 13);
+	chunk("IDAT", comp.data(), (uint32_t)clen);
+	chunk("IEND", nullptr, 0);
+	const bool ok = !ferror(f);
+	fclose(f);
+	return ok ? Error::Nil() : Error{POLARIS_E_DEVICE, "png: write to " + path + " failed"};
 }
 
 } // namespace renderer

@@ -34,6 +34,9 @@ struct FrameStats {
 	tracer::Duration RenderTime{0};
 };
 
+// w*h RGBA8 pixels, rows top to bottom, as a PNG file
+Error WritePNG(const std::string &path, const uint8_t *rgba, uint32_t w, uint32_t h);
+
 class DefaultRenderer { // renderer/default.go:21-196
 public:
 	// tracers are created by the caller (the seam of INTEGRATION.md section 3) and owned here
@@ -47,6 +50,9 @@ public:
 	const FrameStats &Stats() const { return stats_; }
 	const std::vector<uint32_t> &BlockAssignments() const { return blockAssignments_; }
 	tracer::Tracer *Primary() { return tracers_[primary_].get(); }
+	// The SaveFrameBuffer post-process stage (tracer/opencl/pipeline.go:215-235): the primary's RGBA8
+	// frame buffer as a PNG (8-bit RGBA, non-interlaced, like Go's image/png for an image.RGBA).
+	Error SaveFrameBuffer(const std::string &imgFile);
 	size_t NumTracers() const { return tracers_.size(); }
 
 private:

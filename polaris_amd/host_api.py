@@ -32,6 +32,8 @@ def load() -> C.CDLL:
                                                   C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_char_p]
         lib.polaris_host_renderer_render.argtypes = [vp, C.c_uint32, vp, C.POINTER(C.c_double)]
         lib.polaris_host_renderer_read.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t]
+        lib.polaris_host_renderer_save.argtypes = [vp, C.c_char_p]
+        lib.polaris_host_write_png.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
         lib.polaris_host_renderer_error.argtypes = [vp]
         lib.polaris_host_renderer_error.restype = C.c_char_p
         lib.polaris_host_renderer_free.argtypes = [vp]
@@ -122,6 +124,12 @@ class Renderer:
         if rc:
             raise RuntimeError(f"read failed ({rc})")
         return fb, acc
+
+    def save(self, path: str):
+        """The SaveFrameBuffer post-process stage: the primary's RGBA8 frame buffer as a PNG."""
+        rc = self._lib.polaris_host_renderer_save(self._h, path.encode())
+        if rc:
+            raise RuntimeError(f"save failed ({rc}): {self._lib.polaris_host_renderer_error(self._h).decode()}")
 
     def close(self):
         if self._h:
@@ -283,3 +291,11 @@ def texture_load(path: str):
     data = np.zeros(int(meta[3]), np.uint8)
     lib.polaris_host_texture_load(path.encode(), meta.ctypes.data, data.ctypes.data, data.size, err)
     return int(meta[0]), int(meta[1]), int(meta[2]), data
+
+
+def write_png(path: str, rgba: np.ndarray):
+    """renderer::WritePNG: (h, w, 4) uint8 -> PNG file (the encoder behind Renderer.save)."""
+    a = np.ascontiguousarray(rgba, dtype=np.uint8)
+    h, w = a.shape[:2]
+    if load().polaris_host_write_png(path.encode(), a.ctypes.data, w, h):
+        raise RuntimeError(f"write_png: could not write {path}")

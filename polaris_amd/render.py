@@ -10,8 +10,6 @@ import argparse
 import sys
 import time
 
-import numpy as np
-
 from . import host_api
 
 
@@ -42,12 +40,9 @@ def main(argv=None):
                           exposure=a.exposure, seed=a.seed)
     try:
         rows, ms = r.render()
-        fb, _ = r.read()
+        r.save(a.out)  # the SaveFrameBuffer post-process stage (pipeline.go:215-235)
     finally:
         r.close()
-    from PIL import Image
-
-    Image.fromarray(np.ascontiguousarray(fb[..., :3])).save(a.out)
     print(f"{a.scene}: {sc.vertices.shape[0] // 3} triangles, {len(sc.mesh_instances)} instances, {len(sc.material_nodes)} material nodes; "
           f"compiled in {1e3 * (t1 - t0):.0f} ms; {a.width}x{a.height} @ {a.spp} spp on {len(devs)} tracer(s) rows={rows}: {ms:.1f} ms -> {a.out}")
     return 0

@@ -52,3 +52,30 @@ def test_perfect_scheduler_feedback_and_progressive(host):
     _, acc_b = r.read()
     r.close()
     assert acc_b[..., :3].sum() > acc_a[..., :3].sum() * 1.5   # accumulated, not cleared (tracer.go:208-213)
+
+
+def test_obj_to_png_through_the_cpp_front_end_and_renderer(host, tmp_path):
+    """reader.ReadScene -> compiler.Compile -> DefaultRenderer -> SaveFrameBuffer, all in the C++ host
+    layer: the PNG on disk is the primary's RGBA8 frame buffer."""
+    import os
+    import sys
+
+    from PIL import Image
+
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "tools"))
+    import obj_fixtures
+
+    W, H = 80, 60
+    sc = host.read_scene(obj_fixtures.write_cornell(str(tmp_path)), aspect=W / H)
+    r = host.Renderer(sc, [0, 0], width=W, height=H, spp=8, seed=5)
+    try:
+        rows, _ = r.render()
+        fb, acc = r.read()
+        out = str(tmp_path / "frame.png")
+        r.save(out)
+    finally:
+        r.close()
+    assert rows == [30, 30]
+    png = np.array(Image.open(out))
+    assert png.shape == (H, W, 4) and np.array_equal(png, fb)
+    assert fb[..., :3].mean() > 10 and np.isfinite(acc).all()

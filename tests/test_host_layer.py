@@ -109,3 +109,21 @@ def test_compiler_matches_python_producer(host, oracle):
     ib, sb, _ = oracle.trace(b, ob.make_request(W, H, spp=spp, bounces=B), seeds)
     assert list(sa.rays_per_bounce[:B]) == list(sb.rays_per_bounce[:B])
     assert float(np.sqrt(np.mean((ia[..., :3] - ib[..., :3]) ** 2))) / spp <= 1e-6
+
+
+def test_png_writer_round_trips(tmp_path):
+    """renderer::WritePNG (the encoder of the SaveFrameBuffer stage, pipeline.go:215-235): what it writes
+    is what PIL and this repo's own PNG decoder read back."""
+    import numpy as np
+    from PIL import Image
+
+    from polaris_amd import host_api as H
+
+    rng = np.random.default_rng(4)
+    for shape in ((1, 1, 4), (37, 53, 4), (64, 200, 4)):
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        path = str(tmp_path / f"{shape[0]}x{shape[1]}.png")
+        H.write_png(path, img)
+        assert np.array_equal(np.array(Image.open(path)), img)
+        fmt, w, h, data = H.texture_load(path)
+        assert (w, h) == (shape[1], shape[0]) and np.array_equal(data.reshape(shape), img)
