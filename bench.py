@@ -147,7 +147,10 @@ def main() -> None:
     # scheduler gives the remainder rows to tracer 0, tracer/scheduler.go:101-103)
     max_rows = max(rows)
     strip = torch.zeros((max_rows * W, 4), dtype=torch.float32, device=dev)
-    gather_list = [torch.empty((max_rows * W, 4), dtype=torch.float32, device=dev) for i in range(world)] if rank == 0 and world > 1 else None
+    # rank 0 receives the strips into ONE buffer, in block order: with equal blocks that buffer is the frame
+    gathered = torch.empty((world, max_rows * W, 4), dtype=torch.float32, device=dev) if rank == 0 and world > 1 else None
+    gather_list = [gathered[i] for i in range(world)] if gathered is not None else None
+    uniform_rows = len(set(rows)) == 1
     totals = {k: 0 for k in ("primary_rays", "indirect_rays", "occlusion_rays", "shaded_hits", "shaded_misses", "emitter_hits", "unoccluded")}
 
     def frame(count: bool):
@@ -171,10 +174,13 @@ def main() -> None:
                         gather_list[i].copy_(host[i])
             if rank == 0:
                 torch.cuda.synchronize()
-                y = 0
-                for i in range(world):
-                    tr.merge_device(gather_list[i].data_ptr(), make_req(y, rows[i]))
-                    y += rows[i]
+                if uniform_rows:  # one merge over the whole frame instead of one per peer
+                    tr.merge_device(gathered.data_ptr(), make_req(0, H))
+                else:
+                    y = 0
+                    for i in range(world):
+                        tr.merge_device(gather_list[i].data_ptr(), make_req(y, rows[i]))
+                        y += rows[i]
         if rank == 0:
             full = make_req(0, H) if not args.emulate_rank else make_req(block_y, block_h)
             tr.SyncFramebuffer(full)               # default.go:159-161
