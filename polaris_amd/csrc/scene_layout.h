@@ -404,6 +404,29 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out, in
 			for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) o[4 * r + c] = m[r][4 + c]; // row major
 			return true;
 		};
+		// scene triangles below a mesh root (cached); empty when transforming them for every instance of the
+		// mesh would be too much work (more than ~32 M vertex transforms per upload)
+		std::vector<uint32_t> inst_count(n_nodes, 0);
+		for (uint32_t i = 0; i < NI; i++) inst_count[sc.mesh_instances[i].bvh_root]++;
+		std::vector<std::vector<uint32_t>> mesh_tri_cache(n_nodes);
+		std::vector<uint8_t> mesh_tri_done(n_nodes, 0);
+		auto mesh_tris = [&](uint32_t root) -> const std::vector<uint32_t> & {
+			if (!mesh_tri_done[root]) {
+				mesh_tri_done[root] = 1;
+				std::vector<uint32_t> &out_t = mesh_tri_cache[root];
+				std::vector<int32_t> stack{(int32_t)root};
+				while (!stack.empty()) {
+					const PolarisBvhNode &m = nodes[stack.back()];
+					stack.pop_back();
+					if (is_leaf(m)) {
+						const uint32_t f0 = (uint32_t)(-(int64_t)m.ldata);
+						for (uint32_t q = f0; q < f0 + (uint32_t)m.rdata; q++) out_t.push_back(slot_src[q]);
+					} else { stack.push_back(m.rdata); stack.push_back(m.ldata); }
+					if ((uint64_t)out_t.size() * inst_count[root] > (32ull << 20) / 3) { out_t.clear(); break; }
+				}
+			}
+			return mesh_tri_cache[root];
+		};
 		// post-order over a tree; instance leaves pull in the (already computed) box of their mesh
 		std::vector<std::pair<int32_t, int>> st;
 		auto bound_tree = [&](int32_t root) {
@@ -418,14 +441,30 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out, in
 					Box b = empty;
 					if (n.rdata == 0) {
 						const uint32_t inst = (uint32_t)(-(int64_t)n.ldata);
-						const Box &mb = content[sc.mesh_instances[inst].bvh_root];
+						const uint32_t root = sc.mesh_instances[inst].bvh_root;
+						const Box &mb = content[root];
 						double fwd[16];
 						if (invert(sc.mesh_instances[inst].inv_transform, fwd) && mb.lo[0] <= mb.hi[0]) {
-							for (int corner = 0; corner < 8; corner++) {
-								const double p[3] = {corner & 1 ? mb.hi[0] : mb.lo[0], corner & 2 ? mb.hi[1] : mb.lo[1], corner & 4 ? mb.hi[2] : mb.lo[2]};
-								float w[3];
+							auto world = [&](const double *p, float *w) {
 								for (int r = 0; r < 3; r++) w[r] = (float)(fwd[4 * r] * p[0] + fwd[4 * r + 1] * p[1] + fwd[4 * r + 2] * p[2] + fwd[4 * r + 3]);
-								grow(b, w);
+							};
+							const std::vector<uint32_t> &tris_of_mesh = mesh_tris(root);
+							if (!tris_of_mesh.empty()) { // exact: every vertex of the mesh through the instance's matrix
+								for (uint32_t t : tris_of_mesh)
+									for (int k = 0; k < 3; k++) {
+										const float *v = sc.vertices + 4 * (size_t)(3 * t + k);
+										const double p[3] = {v[0], v[1], v[2]};
+										float w[3];
+										world(p, w);
+										grow(b, w);
+									}
+							} else { // big mesh x many instances: the 8 corners of the mesh's box (a superset: may flag a tight host box)
+								for (int corner = 0; corner < 8; corner++) {
+									const double p[3] = {corner & 1 ? mb.hi[0] : mb.lo[0], corner & 2 ? mb.hi[1] : mb.lo[1], corner & 4 ? mb.hi[2] : mb.lo[2]};
+									float w[3];
+									world(p, w);
+									grow(b, w);
+								}
 							}
 						} else { // singular matrix: nothing can be promised about this instance
 							for (int k = 0; k < 3; k++) { b.lo[k] = -3.0e38f; b.hi[k] = 3.0e38f; }
