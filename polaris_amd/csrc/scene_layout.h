@@ -278,15 +278,11 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out, in
 				work.pop_back();
 				const uint32_t cnt = rg.hi - rg.lo;
 				float bmin[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bmax[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-				float cmin[3] = {3.0e38f, 3.0e38f, 3.0e38f}, cmax[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
 				for (uint32_t s = rg.lo; s < rg.hi; s++) {
 					const float *v = sc.vertices + 4 * (size_t)(3 * slot_src[s]);
 					for (int k = 0; k < 3; k++) {
 						bmin[k] = std::fmin(bmin[k], std::fmin(v[k], std::fmin(v[4 + k], v[8 + k])));
 						bmax[k] = std::fmax(bmax[k], std::fmax(v[k], std::fmax(v[4 + k], v[8 + k])));
-						const float c = centroid(slot_src[s], k);
-						cmin[k] = std::fmin(cmin[k], c);
-						cmax[k] = std::fmax(cmax[k], c);
 					}
 				}
 				PolarisBvhNode &nd = nodes[rg.node];
