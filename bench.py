@@ -63,6 +63,15 @@ def kernel_algorithmic_bytes(st: dict) -> dict:
     }
 
 
+def host_cpu() -> str:
+    """'<n> x <model name>' of the host the CPU baseline runs on (state the cores)."""
+    try:
+        models = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")]
+        return f"{len(models)} x {models[0]}" if models else f"{os.cpu_count()} logical CPUs"
+    except OSError:
+        return f"{os.cpu_count()} logical CPUs"
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -298,7 +307,7 @@ def main() -> None:
                         cpu_rays, cpu_dt, cpu_n = cs2.total_rays(), time.perf_counter() - t, more
                 out["cpu_baseline"] = {"value": cpu_rays / cpu_dt / 1e6, "unit": "Mrays/s", "cores": min(cores, cpu_n), "kind": "port",
                                        "sample": f"same scene/frame/options, {cpu_n} samples per pixel ({cpu_rays} rays, {cpu_dt:.1f} s wall), "
-                                                 f"oracle/polaris_oracle.cpp, OpenMP over samples on {min(cores, cpu_n)} threads",
+                                                 f"oracle/polaris_oracle.cpp, OpenMP over samples on {min(cores, cpu_n)} threads of {host_cpu()}",
                                        "ms_per_frame_extrapolated": cpu_dt / cpu_n * spp * 1e3}
             except Exception as e:  # the baseline is a reported extra, never a reason to lose the bench line
                 out["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
