@@ -447,30 +447,57 @@ __global__ __launch_bounds__(WG) void k_trace(Streams st, BvhDev B, uint32_t num
 				inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)};
 				cur = I.meta.x;
 			} else {
-				const int first = -li.x;
+				const int first = -li.x, end = first + li.y;
 				bool occluded = false;
-				for (int t = first; t < first + li.y; t++) {
-					TC(c_tri++; if (lane == __ffsll((long long)__ballot(true)) - 1) c_triiter++;)
-					const TriRec T = B.tris[t];
-					f3 e1 = xyz(T.e1), e2 = xyz(T.e2);
-					f3 pv = cross(d, e2);
-					float det = dot(e1, pv);
-					if (pm_fabs(det) < kEps) continue;
-					float idet = pm_rcp(det);
-					f3 tv = o - xyz(T.v0);
-					float u = dot(tv, pv) * idet;
-					if (u < 0.0f || u > 1.0f) continue;
-					f3 qv = cross(tv, e1);
-					float v = dot(d, qv) * idet;
-					if (v < 0.0f || u + v > 1.0f) continue;
-					float tt = dot(e2, qv) * idet;
-					if (ANY_HIT) {
-						if (tt > kEps && tt < maxDist) { occluded = true; break; }
-					} else if (tt > kEps) {
-						const uint32_t trank = (uint32_t)fbits(T.v0.w);
-						const bool closer = tt < best.t;
-						const bool tie = tt == best.t && best.tri >= 0 && (irank < best.irank || (irank == best.irank && trank < best.trank));
-						if (closer || tie) { best.t = tt; best.u = u; best.v = v; best.tri = fbits(T.e1.w); best.inst = inst; best.irank = irank; best.trank = trank; }
+				if constexpr (ANY_HIT) {
+					// shadow rays: Moeller-Trumbore without early exits (a lane's early exit saves the wave
+					// nothing), two triangles per round -- their six loads are in flight together and the round
+					// count halves: -10 % kernel time.  (For closest hits the same change costs 4 %: kept as it was.)
+					auto mt = [&](const TriRec &T, bool valid, float &tt, float &u, float &v) -> bool {
+						const f3 e1 = xyz(T.e1), e2 = xyz(T.e2);
+						const f3 pv = cross(d, e2);
+						const float det = dot(e1, pv);
+						bool ok = valid && !(pm_fabs(det) < kEps);
+						const float idet = pm_rcp(det);
+						const f3 tv = o - xyz(T.v0);
+						u = dot(tv, pv) * idet;
+						ok = ok && !(u < 0.0f || u > 1.0f);
+						const f3 qv = cross(tv, e1);
+						v = dot(d, qv) * idet;
+						ok = ok && !(v < 0.0f || u + v > 1.0f);
+						tt = dot(e2, qv) * idet;
+						return ok && tt > kEps;
+					};
+					for (int t = first; t < end && !occluded; t += 2) {
+						TC(c_tri += (t + 1 < end) ? 2 : 1; if (lane == __ffsll((long long)__ballot(true)) - 1) c_triiter++;)
+						const bool two = t + 1 < end;
+						const TriRec T0 = B.tris[t], T1 = B.tris[two ? t + 1 : t];
+						float tt0, u0, v0, tt1, u1, v1;
+						const bool h0 = mt(T0, true, tt0, u0, v0), h1 = mt(T1, two, tt1, u1, v1);
+						occluded = (h0 && tt0 < maxDist) || (h1 && tt1 < maxDist);
+					}
+				} else {
+					for (int t = first; t < end; t++) {
+						TC(c_tri++; if (lane == __ffsll((long long)__ballot(true)) - 1) c_triiter++;)
+						const TriRec T = B.tris[t];
+						f3 e1 = xyz(T.e1), e2 = xyz(T.e2);
+						f3 pv = cross(d, e2);
+						float det = dot(e1, pv);
+						if (pm_fabs(det) < kEps) continue;
+						float idet = pm_rcp(det);
+						f3 tv = o - xyz(T.v0);
+						float u = dot(tv, pv) * idet;
+						if (u < 0.0f || u > 1.0f) continue;
+						f3 qv = cross(tv, e1);
+						float v = dot(d, qv) * idet;
+						if (v < 0.0f || u + v > 1.0f) continue;
+						float tt = dot(e2, qv) * idet;
+						if (tt > kEps) {
+							const uint32_t trank = (uint32_t)fbits(T.v0.w);
+							const bool closer = tt < best.t;
+							const bool tie = tt == best.t && best.tri >= 0 && (irank < best.irank || (irank == best.irank && trank < best.trank));
+							if (closer || tie) { best.t = tt; best.u = u; best.v = v; best.tri = fbits(T.e1.w); best.inst = inst; best.irank = irank; best.trank = trank; }
+						}
 					}
 				}
 				if (ANY_HIT && occluded) finish(true);

@@ -53,7 +53,7 @@ struct polaris_hip_tracer {
 	BvhDev bvh{};
 	SceneDev scene{};
 	int max_stack = 0;
-	int trace_resident_per_cu = 6; // workgroups of the selected k_trace variant a CU holds at once (occupancy API, at upload)
+	int trace_resident_per_cu = 6, occl_resident_per_cu = 6; // workgroups of the selected k_trace<closest | any hit> variant a CU holds at once (occupancy API, at upload)
 
 	// camera (tracer.go:175-179)
 	bool have_camera = false;
@@ -243,13 +243,14 @@ void launch_trace(polaris_hip_tracer *h, polaris_hip_tracer::Pipe &P, uint32_t g
 	else launch_trace_v<ANY_HIT, false>(h, P, grid, chunks, acc);
 }
 
-// Resident workgroups per CU of the closest-hit variant launch_trace<false> would pick.
+// Resident workgroups per CU of the k_trace variant launch_trace<ANY_HIT> would pick.
+template <bool ANY_HIT>
 int trace_occupancy(polaris_hip_tracer *h) {
 	const bool lds_top = h->bvh.num_pairs <= 8u * kLdsTopNodes;
 	const void *fn;
-	if (h->max_stack <= 16) fn = lds_top ? (const void *)k_trace<false, 16, true> : (const void *)k_trace<false, 16, false>;
-	else if (h->max_stack <= 24) fn = lds_top ? (const void *)k_trace<false, 24, true> : (const void *)k_trace<false, 24, false>;
-	else fn = lds_top ? (const void *)k_trace<false, 32, true> : (const void *)k_trace<false, 32, false>;
+	if (h->max_stack <= 16) fn = lds_top ? (const void *)k_trace<ANY_HIT, 16, true> : (const void *)k_trace<ANY_HIT, 16, false>;
+	else if (h->max_stack <= 24) fn = lds_top ? (const void *)k_trace<ANY_HIT, 24, true> : (const void *)k_trace<ANY_HIT, 24, false>;
+	else fn = lds_top ? (const void *)k_trace<ANY_HIT, 32, true> : (const void *)k_trace<ANY_HIT, 32, false>;
 	int n = 0;
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, WG, 0) != hipSuccess || n < 1) n = h->max_stack <= 24 ? 6 : 5;
 	return std::min(n, 8);
@@ -283,10 +284,13 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 	// launch (the launches share the CUs; measured flat to +5 % across the bench scenes).
 	// (LDS: 16-entry stack: 16 KB per
 	// workgroup -> 8 by LDS, VGPRs allow 7-8 waves/SIMD; 32-entry: 5)
-	uint32_t per_cu = (uint32_t)std::max(1, h->trace_resident_per_cu);
-	if (std::min(h->opt_overlap, (int)polaris_hip_tracer::kMaxPipes) > 1 && !exact) per_cu = std::max(2u, per_cu * 2u / 3u);
-	if (h->opt_trace_wgs_per_cu > 0) per_cu = (uint32_t)h->opt_trace_wgs_per_cu;
-	const uint32_t persistent = std::min<uint32_t>(wgs, (uint32_t)h->num_cus * per_cu);
+	auto grid_of = [&](int resident) {
+		uint32_t per_cu = (uint32_t)std::max(1, resident);
+		if (std::min(h->opt_overlap, (int)polaris_hip_tracer::kMaxPipes) > 1 && !exact) per_cu = std::max(2u, per_cu * 2u / 3u);
+		if (h->opt_trace_wgs_per_cu > 0) per_cu = (uint32_t)h->opt_trace_wgs_per_cu;
+		return std::min<uint32_t>(wgs, (uint32_t)h->num_cus * per_cu);
+	};
+	const uint32_t persistent = grid_of(h->trace_resident_per_cu), persistent_occl = grid_of(h->occl_resident_per_cu);
 	for (uint32_t b = 0; b < B; b++) {
 		{
 			Timed t(h, (b == 0 && h->packet_primary) ? "intersect_packet" : "intersect", q);
@@ -319,7 +323,7 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 			if ((int)b < h->opt_packet_shadow)
 				hipLaunchKernelGGL(k_trace_packet<true>, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, A.acc, h->d_stats);
 			else if (h->opt_traversal)
-				launch_trace<true>(h, P, persistent, wgs, A.acc);
+				launch_trace<true>(h, P, persistent_occl, wgs, A.acc);
 			else
 				hipLaunchKernelGGL(k_occlusion, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, A.acc, h->d_stats);
 		}
@@ -494,7 +498,8 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 	                    sc->scene_diffuse_mat_index, sc->num_material_nodes, sc->num_textures};
 	h->max_stack = L.max_stack;
 	if (h->opt_packet_primary < 0) h->packet_primary = sc->num_triangles <= 262144u;
-	h->trace_resident_per_cu = trace_occupancy(h);
+	h->trace_resident_per_cu = trace_occupancy<false>(h);
+	h->occl_resident_per_cu = trace_occupancy<true>(h);
 	h->have_scene = true;
 	return POLARIS_OK;
 }
