@@ -31,6 +31,9 @@ CASES = [
     # a Wavefront scene through the C++ reader + compiler: `instance` statements with rotation and scale (whose boxes the
     # reference's reader computes from the translation alone), mat_expr trees, PNM + PNG textures, a refractive prism
     ("obj_room_40", "obj-room", 40, 30, 4, 5, 3, 0, 30),
+    # the C4 stand-in at low tessellation: bump-mapped mix of rough conductor over diffuse, rough glass, textured floor,
+    # two area lights + environment, 16:9, an inner row block
+    ("material_ball_48", "material-ball-small", 48, 27, 3, 5, 3, 5, 17),
 ]
 
 
