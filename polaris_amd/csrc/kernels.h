@@ -36,7 +36,7 @@ struct PairNode { float4 lo0, hi0, lo1, hi1; };  // .w of lo0/lo1 carry the chil
 struct TriRec { float4 v0, e1, e2; };             // v0.w = DFS rank, e1.w = scene triangle index (uint bits)
 struct InstRec { float4 r0, r1, r2; int4 meta; }; // meta.x = root ref, meta.y = rank
 
-constexpr int kLdsTopNodes = 128; // pair records (8 KB) of the top of the tree staged in LDS per workgroup
+constexpr int kLdsTopNodes = 64;  // (64 x 64 B = 4 KB: with the 16 KB stack a CU holds 8 workgroups) // pair records (8 KB) of the top of the tree staged in LDS per workgroup
 
 struct BvhDev {
 	const PairNode *pairs; // inner nodes in breadth-first order
@@ -284,8 +284,12 @@ __device__ __forceinline__ float slab_entry_hw(float4 lo, float4 hi, f3 o, f3 in
 // ticket counter was measured first: it saturates at ~88 dequeues/us (MI355X_MICROARCH.md,
 // "dequeue"), a ~190 us floor under every launch of a 16 Ki-chunk batch.
 
+// The closest-hit kernel with the 16-entry stack is asked for 7 waves per SIMD: 71 VGPRs without a
+// spill, 20 KB of LDS per workgroup (-2.4 % kernel time on the Cornell box, -9 % on the sphere scene;
+// the any-hit kernel spills at that budget and stays at its natural 5).
 template <bool ANY_HIT, int STACK, bool LDS_TOP>
-__global__ __launch_bounds__(WG) void k_trace(Streams st, BvhDev B, uint32_t num_chunks, uint32_t *ticket, float4 *acc,
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((!ANY_HIT && STACK == 16) ? 7 : 1, (!ANY_HIT && STACK == 16) ? 7 : 10)))
+void k_trace(Streams st, BvhDev B, uint32_t num_chunks, uint32_t *ticket, float4 *acc,
                                               unsigned long long *stats) {
 	__shared__ int stk[STACK][WG]; // STACK = smallest of {16, 24, 32} that fits the scene: LDS per wave sets the occupancy
 	__shared__ uint32_t wg_cursor;
