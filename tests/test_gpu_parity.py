@@ -297,3 +297,17 @@ def test_full_size_invariants(built):
     finally:
         tr.Close()
     assert rmse(a + b, outs[0], spp) <= 1e-6
+
+
+def test_soak_one_handle_many_shapes_scenes_and_options(built):
+    """150 Trace calls on one handle with random frame sizes, row blocks, scenes, bounce counts,
+    overlap depths and accumulation modes (tests/tools/soak.py): every call succeeds, radiance stays
+    finite, device memory does not creep."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "tools"))
+    import soak
+
+    start, end, worst = soak.run(150)
+    assert start - end < 512

@@ -1,0 +1,62 @@
+"""Soak run (GPU): many Trace calls with changing frame sizes, blocks, scenes and options on ONE
+handle; device memory must return to where it started and every call must succeed.
+    python tests/tools/soak.py [iterations]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402  (device memory accounting only)
+
+from conftest import make_hip_tracer  # noqa: E402
+from oracle import pybind as ob  # noqa: E402
+from polaris_amd import scenes  # noqa: E402
+from polaris_amd.tracer import ChangeType, UpdateMode  # noqa: E402
+
+
+def free_mb():
+    torch.cuda.synchronize()
+    return torch.cuda.mem_get_info()[0] / 2**20
+
+
+def run(iters=200):
+    rng = np.random.default_rng(1)
+    names = ["cornell", "sphere", "cubes", "materials", "transformed", "material-ball-small", "terrain-small", "instanced-small"]
+    built = {n: scenes.SCENES[n]() for n in names}
+    torch.zeros(1, device="cuda")
+    tr = make_hip_tracer(built["cornell"], 64, 64)
+    start = None
+    worst = 0.0
+    for it in range(iters):
+        n = names[int(rng.integers(0, len(names)))]
+        W, H = int(rng.integers(8, 300)), int(rng.integers(8, 200))
+        tr.UpdateState(UpdateMode.Synchronous, ChangeType.FrameDimensions, (W, H))
+        tr.UpdateState(UpdateMode.Synchronous, ChangeType.SceneData, built[n])
+        tr.UpdateState(UpdateMode.Asynchronous, ChangeType.CameraData, built[n])
+        tr.set_option("overlap", int(rng.integers(1, 9)))
+        tr.set_option("exact_accumulate", int(rng.integers(0, 4) == 0))
+        spp, B = int(rng.integers(1, 40)), int(rng.integers(1, 7))
+        by = int(rng.integers(0, H))
+        bh = int(rng.integers(1, H - by + 1))
+        req = ob.make_request(W, H, spp=spp, bounces=B, rr=int(rng.integers(1, B + 2)), block_y=by, block_h=bh)
+        tr.Trace(req, scenes.make_seeds(spp, B, base=it))
+        tr.MergeOutput(tr, req)
+        tr.SyncFramebuffer(req)
+        acc = tr.read_accumulator(0)
+        assert np.isfinite(acc).all(), (it, n)
+        if it == 20:
+            start = free_mb()
+        if start is not None:
+            worst = max(worst, start - free_mb())
+    end = free_mb()
+    tr.Close()
+    print(f"soak: {iters} iterations ok; free memory {start:.0f} MiB after warm-up, {end:.0f} MiB at the end, largest dip {worst:.0f} MiB")
+    assert start - end < 512, "device memory keeps growing"
+    return start, end, worst
+
+
+if __name__ == "__main__":
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 200)
