@@ -9,7 +9,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-import torch  # noqa: E402  (device memory accounting only)
+import ctypes  # noqa: E402
 
 from conftest import make_hip_tracer  # noqa: E402
 from oracle import pybind as ob  # noqa: E402
@@ -17,16 +17,25 @@ from polaris_amd import scenes  # noqa: E402
 from polaris_amd.tracer import ChangeType, UpdateMode  # noqa: E402
 
 
+_hip = None
+
+
 def free_mb():
-    torch.cuda.synchronize()
-    return torch.cuda.mem_get_info()[0] / 2**20
+    """hipMemGetInfo through the HIP runtime the tracer library itself is linked against (no torch here:
+    a second HIP runtime in the process would not see the device)."""
+    global _hip
+    if _hip is None:
+        _hip = ctypes.CDLL("libamdhip64.so")
+    free, total = ctypes.c_size_t(), ctypes.c_size_t()
+    assert _hip.hipDeviceSynchronize() == 0
+    assert _hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+    return free.value / 2**20
 
 
 def run(iters=200):
     rng = np.random.default_rng(1)
     names = ["cornell", "sphere", "cubes", "materials", "transformed", "material-ball-small", "terrain-small", "instanced-small"]
     built = {n: scenes.SCENES[n]() for n in names}
-    torch.zeros(1, device="cuda")
     tr = make_hip_tracer(built["cornell"], 64, 64)
     start = None
     worst = 0.0
