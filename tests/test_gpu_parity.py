@@ -299,6 +299,31 @@ def test_full_size_invariants(built):
     assert rmse(a + b, outs[0], spp) <= 1e-6
 
 
+@pytest.mark.parametrize("name", ["material-ball", "instanced"])
+def test_big_scene_kernel_variants_agree_with_the_oracle(built, oracle, name):
+    """Scenes that select the other kernel variants -- 24-entry traversal stack, no LDS tree top, leaves
+    of up to 4 triangles, (for > 256 K triangles) per-ray camera traversal -- traced in exact mode with
+    each upload / traversal option flipped: all bit-identical to the CPU oracle."""
+    from oracle import pybind as ob
+    from polaris_amd import scenes
+
+    sc = scenes.SCENES[name](4 / 3)
+    W, H, spp, B = 96, 72, 2, 4
+    req = ob.make_request(W, H, spp=spp, bounces=B, rr=2)
+    seeds = scenes.make_seeds(spp, B, base=21)
+    want, wst, _ = oracle.trace(sc, req, seeds)
+    assert wst.shaded_hits > 0
+    for opts in ({}, {"max_leaf_tris": 0}, {"max_leaf_tris": 1}, {"packet_primary": 0}, {"traversal": 0}, {"stage_lds": 0}):
+        tr = make_hip_tracer(sc, W, H, exact_accumulate=1, **opts)
+        try:
+            tr.Trace(req, seeds)
+            got, st = tr.read_accumulator(0), tr.last_trace_stats
+        finally:
+            tr.Close()
+        assert counters(st, B) == counters(wst, B), opts
+        assert np.array_equal(bits(got[..., :3]), bits(want[..., :3])), opts
+
+
 def test_soak_one_handle_many_shapes_scenes_and_options(built):
     """150 Trace calls on one handle with random frame sizes, row blocks, scenes, bounce counts,
     overlap depths and accumulation modes (tests/tools/soak.py): every call succeeds, radiance stays
