@@ -299,6 +299,33 @@ def test_full_size_invariants(built):
     assert rmse(a + b, outs[0], spp) <= 1e-6
 
 
+def test_headline_frame_against_the_oracle(built, oracle):
+    """BASELINE.json's headline workload at FULL size -- layered Cornell box, 512x512, 128 spp, 5
+    bounces, RR from bounce 3, 163.5 M rays -- default (batched, overlapped) mode against the CPU
+    oracle run over the same seeds (sample-parallel OpenMP mode: a few seconds on the GPU box's host
+    cores): every ray counter identical (=> identical paths), per-pixel RMSE <= 1e-6 (the two differ
+    only in the association of the per-sample sums; north_star bar: 1e-4)."""
+    from oracle import pybind as ob
+    from polaris_amd import scenes
+
+    sc = scenes.SCENES["cornell"]()
+    W = H = 512
+    spp, B = 128, 5
+    req = ob.make_request(W, H, spp=spp, bounces=B, rr=3)
+    seeds = scenes.make_seeds(spp, B)
+    want, wst, _ = oracle.trace(sc, req, seeds, flags=ob.FIX_EMITTER_INDEX | ob.PARALLEL_SAMPLES)
+    tr = make_hip_tracer(sc, W, H)
+    try:
+        tr.Trace(req, seeds)
+        got, st = tr.read_accumulator(0), tr.last_trace_stats
+    finally:
+        tr.Close()
+    assert st.primary_rays == W * H * spp
+    assert counters(st, B) == counters(wst, B)
+    assert st.primary_rays + st.indirect_rays + st.occlusion_rays == 163525398  # the frame bench.py reports
+    assert rmse(got, want, spp) <= 1e-6
+
+
 @pytest.mark.parametrize("name", ["material-ball", "instanced"])
 def test_big_scene_kernel_variants_agree_with_the_oracle(built, oracle, name):
     """Scenes that select the other kernel variants -- 24-entry traversal stack, no LDS tree top, leaves
