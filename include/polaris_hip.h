@@ -81,12 +81,14 @@ int polaris_hip_set_camera(polaris_hip_tracer *h, const float eye[3], const floa
  *   "exact_accumulate"   1 = add every contribution straight into the trace accumulator in
  *                        the reference's order (forces one sample per batch; bit-exact with
  *                        the CPU oracle), 0 = per-path radiance + ordered resolve (default)
- *   "packet_primary"     1 = wave-packet traversal for primary rays (default), 0 = per-ray
+ *   "packet_primary"     1 = wave-packet traversal for primary rays, 0 = per-ray, -1 = by scene
+ *                        size (default: packets up to 256 K triangles)
  *   "time_kernels"       1 = bracket every kernel with HIP events (polaris_hip_kernel_ms)
  *   "overlap"            batches in flight on separate streams (1-8, default 4)
  *   "max_leaf_tris"      applies to the NEXT upload_scene: triangle leaves with more triangles
- *                        than this are subdivided where a surface-area split pays (default 2,
- *                        0 = keep the caller's leaves).  Never changes a result: DESIGN.md 3.1
+ *                        than this are subdivided where a surface-area split pays (default -1:
+ *                        2 up to 32 K triangles, 4 above; 0 = keep the caller's leaves).  Never
+ *                        changes a result: DESIGN.md 2 (HBM data layout)
  *   further A/B switches of the kernels ("traversal", "packet_shadow", "shade_wave",
  *   "shade_wave_from", "shade_wgs_per_cu", "stage_lds", "trace_wgs_per_cu"): see DESIGN.md 3 */
 int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value);
