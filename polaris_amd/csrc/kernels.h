@@ -425,7 +425,9 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, uint32_t *ticket, float4
 			int c0 = fbits(P.lo0.w), c1 = fbits(P.lo1.w);
 			const bool h0 = t0 < kFltMax, h1 = t1 < kFltMax;
 			if (h0 && h1) {
-				if (t1 < t0) { int t = c0; c0 = c1; c1 = t; }
+				// closest hit: nearer child first (that is what makes the distance cull bite); any hit: the order is
+				// irrelevant for the answer and sorting by entry distance is not worth its instructions (-4 %)
+				if (!ANY_HIT && t1 < t0) { int t = c0; c0 = c1; c1 = t; }
 				stk[sp++][tid] = c1;
 				cur = c0;
 			} else if (h0 || h1) {
