@@ -260,11 +260,11 @@ __global__ __launch_bounds__(WG) void k_occlusion(Streams st, BvhDev B, float4 *
 // same tie rule), so results are bit-identical; only the schedule changes.
 // ------------------------------------------------------------------------------------------
 #ifndef POLARIS_REFILL_MIN
-#define POLARIS_REFILL_MIN 48
+#define POLARIS_REFILL_MIN 40
 #endif
 constexpr int kRefillMin = POLARIS_REFILL_MIN;
 #ifndef POLARIS_STRAGGLERS
-#define POLARIS_STRAGGLERS 8
+#define POLARIS_STRAGGLERS 16
 #endif
 constexpr int kStragglers = POLARIS_STRAGGLERS;
 
