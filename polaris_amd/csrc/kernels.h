@@ -36,7 +36,10 @@ struct PairNode { float4 lo0, hi0, lo1, hi1; };  // .w of lo0/lo1 carry the chil
 struct TriRec { float4 v0, e1, e2; };             // v0.w = DFS rank, e1.w = scene triangle index (uint bits)
 struct InstRec { float4 r0, r1, r2; int4 meta; }; // meta.x = root ref, meta.y = rank
 
-constexpr int kLdsTopNodes = 64;  // (64 x 64 B = 4 KB: with the 16 KB stack a CU holds 8 workgroups) // pair records (8 KB) of the top of the tree staged in LDS per workgroup
+#ifndef POLARIS_LDS_TOP_NODES
+#define POLARIS_LDS_TOP_NODES 64
+#endif
+constexpr int kLdsTopNodes = POLARIS_LDS_TOP_NODES;  // (64 x 64 B = 4 KB: with the 16 KB stack a CU holds 8 workgroups) // pair records (8 KB) of the top of the tree staged in LDS per workgroup
 
 struct BvhDev {
 	const PairNode *pairs; // inner nodes in breadth-first order
