@@ -266,13 +266,14 @@ def main() -> None:
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
             if os.path.exists(tpath) and (W, H, spp, B, args.scene) == (512, 512, 128, 5, "cornell"):
-                kn = {"intersect": "pol::k_trace<false", "occlusion": "pol::k_trace<true", "shade": "pol::k_shade<",
-                      "generate": "pol::k_generate", "intersect_packet": "pol::k_trace_packet<false>"}[dom]
-                tk = next((v for k, v in sorted(json.load(open(tpath))["kernels"].items()) if k.startswith(kn)), None)
-                if tk:
-                    traffic = tk["hbm_bytes_per_launch"]    # PMC (FETCH_SIZE x2 + WRITE_SIZE), scripts/traffic.sh
+                kn = {"intersect": ("pol::k_trace<false",), "occlusion": ("pol::k_trace<true",), "shade": ("pol::k_shade<", "pol::k_shade_wave<"),
+                      "generate": ("pol::k_generate",), "intersect_packet": ("pol::k_trace_packet<false>",)}[dom]
+                tks = [v for k, v in json.load(open(tpath))["kernels"].items() if k.startswith(kn)]  # the bench timer's kernels
+                if tks:  # PMC (FETCH_SIZE x2 + WRITE_SIZE), scripts/traffic.sh, per launch of that timer
+                    traffic = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for v in tks) / max(sum(v["launches"] for v in tks), 1)
             names = {"intersect": "k_trace<false,16> (closest hit, bounce rays)", "intersect_packet": "k_trace_packet<false> (camera rays)",
-                     "occlusion": "k_trace<true,16> (any hit + NEE accumulate)", "shade": "k_shade", "generate": "k_generate"}
+                     "occlusion": "k_trace<true,16> (any hit + NEE accumulate)", "shade": "k_shade + k_shade_wave (shadeHits, miss shading, compaction)",
+                     "generate": "k_generate"}
             out["roofline"] = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "algorithmic_bytes_per_launch": alg[dom] / max(n, 1), "avg_launch_ms": ms / max(n, 1), "launches": n,
