@@ -91,8 +91,8 @@ struct polaris_hip_tracer {
 	int opt_stage_lds = 1;    // k_shade stages material nodes / lights / texture metadata in LDS when they fit
 	int opt_shade_wave = 1;   // 1 = persistent wave-per-chunk shading (k_shade_wave), 0 = one workgroup per chunk (k_shade)
 	int opt_shade_wgs_per_cu = 8;
-	int opt_shade_wave_from = -1; // first bounce shaded by k_shade_wave; -1 = where Russian roulette starts thinning the
-	                              // chunks (min_bounces_for_rr); earlier, denser bounces use k_shade
+	int opt_shade_wave_from = -1; // first bounce shaded by k_shade_wave; -1 = the bounce AFTER Russian roulette starts thinning the
+	                              // chunks (min_bounces_for_rr + 1: the RR bounce itself still shades dense chunks); earlier bounces use k_shade
 	int opt_traversal = 1; // 1 = persistent waves with lane refill (k_trace), 0 = one ray per lane (k_intersect/k_occlusion)
 
 	// per-kernel timing (option time_kernels)
@@ -305,7 +305,7 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 		A.last_bounce = (b + 1 == B) ? 1 : 0;
 		{
 			Timed t(h, "shade", q);
-			if (h->opt_shade_wave && (int)b >= (h->opt_shade_wave_from >= 0 ? h->opt_shade_wave_from : (int)r->min_bounces_for_rr)) {
+			if (h->opt_shade_wave && (int)b >= (h->opt_shade_wave_from >= 0 ? h->opt_shade_wave_from : (int)r->min_bounces_for_rr + 1)) {
 				const uint32_t grid = std::min<uint32_t>(wgs, (uint32_t)h->num_cus * (uint32_t)std::max(1, h->opt_shade_wgs_per_cu));
 				if (staged) hipLaunchKernelGGL(k_shade_wave<true>, dim3(grid), dim3(WG), 0, q, P.st, h->scene, A, wgs);
 				else hipLaunchKernelGGL(k_shade_wave<false>, dim3(grid), dim3(WG), 0, q, P.st, h->scene, A, wgs);
