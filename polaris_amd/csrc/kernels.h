@@ -270,6 +270,13 @@ constexpr int kRefillMin = POLARIS_REFILL_MIN;
 #define POLARIS_STRAGGLERS 16
 #endif
 constexpr int kStragglers = POLARIS_STRAGGLERS;
+#ifndef POLARIS_REFILL_MIN_ANY
+#define POLARIS_REFILL_MIN_ANY POLARIS_REFILL_MIN
+#endif
+#ifndef POLARIS_STRAGGLERS_ANY
+#define POLARIS_STRAGGLERS_ANY POLARIS_STRAGGLERS
+#endif
+constexpr int kRefillMinAny = POLARIS_REFILL_MIN_ANY, kStragglersAny = POLARIS_STRAGGLERS_ANY; // the same two for shadow rays
 
 __device__ __forceinline__ float slab_entry_hw(float4 lo, float4 hi, f3 o, f3 inv, float maxDist) {
 	// identical to slab_entry except that min/max are the hardware's IEEE minNum/maxNum
@@ -368,7 +375,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, uint32_t *ticket, float4
 		TC(c_outer++;)
 		// ---- refill idle lanes ---------------------------------------------------------------
 		unsigned long long freem = __ballot(!has);
-		if (!drained && (freem == ~0ull || __popcll(freem) >= kRefillMin)) {
+		if (!drained && (freem == ~0ull || __popcll(freem) >= (ANY_HIT ? kRefillMinAny : kRefillMin))) {
 			TC(c_refill++;)
 			for (;;) {
 				if (off >= cnt) {
@@ -413,7 +420,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, uint32_t *ticket, float4
 		for (int it1 = 0;; it1++) {
 			const bool descending = has && cur >= 0;
 			const int nd = __popcll(__ballot(descending));
-			if (nd == 0 || (it1 > 0 && nd < kStragglers)) break;
+			if (nd == 0 || (it1 > 0 && nd < (ANY_HIT ? kStragglersAny : kStragglers))) break;
 			if (!descending) continue;
 			TC(c_node++; if (lane == __ffsll((long long)__ballot(true)) - 1) c_iter1++;)
 			PairNode P;
