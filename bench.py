@@ -26,9 +26,10 @@ workload on the host cores.
 from __future__ import annotations
 
 import argparse
-import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -39,15 +40,6 @@ import numpy as np  # noqa: E402
 
 KERNELS = ("generate", "intersect_packet", "intersect", "shade", "scan", "occlusion", "resolve", "aggregate", "tonemap")
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
-
-
-def naive_schedule(n_tracers: int, frame_h: int) -> list[int]:
-    """tracer/scheduler.go:83-106 assignBlocksBasedOnSpeed with equal speeds."""
-    scaler = frame_h / float(n_tracers)
-    rows = [int(max(1.0, 1.0 * scaler)) for _ in range(n_tracers)]
-    if sum(rows) < frame_h:
-        rows[0] += frame_h - sum(rows)
-    return rows
 
 
 def kernel_algorithmic_bytes(st: dict) -> dict:
@@ -87,6 +79,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--save-png", default="")
+    ap.add_argument("--save-accumulator", default="", help="rank 0 writes its frame accumulator of the last frame as .npy (tests)")
     ap.add_argument("--opt", action="append", default=[], help="tracer option key=value (polaris_hip_set_option)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to test the N>1 flow on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="testing aid: every rank uses GPU 0 (needs --backend gloo)")
@@ -94,11 +87,31 @@ def main() -> None:
                     "(tuning aid for the strong-scaling path; not a valid bench line)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Launched bare (`python bench.py --gpus N`): start the N ranks ourselves, one process per GPU, BEFORE anything in
+        # this process touches HIP (torch.cuda.device_count() does not initialise the GPU on this image), relay the
+        # child's output (rank 0 prints the JSON line) and exit with its status.  renderer/default.go:127-156 is the
+        # reference's equivalent: one worker per device inside one Render().
+        if not args.same_device:
+            import torch
+
+            visible = torch.cuda.device_count()
+            if visible < args.gpus:
+                raise SystemExit(f"bench.py --gpus {args.gpus}: only {visible} HIP device(s) visible on this host")
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        raise SystemExit(subprocess.run(cmd).returncode)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} launched with WORLD_SIZE={world}: they must agree")
 
     import torch
 
@@ -119,25 +132,24 @@ def main() -> None:
 
     from polaris_amd import ctypes_api as T
     from polaris_amd import scenes
+    from polaris_amd.distributed import StripExchange, block_of, naive_rows
     from polaris_amd.tracer import ChangeType, HipTracer, UpdateMode
 
     W, H, spp, B = args.width, args.height, args.spp, args.bounces
     sc = scenes.SCENES[args.scene](W / H)
     seeds = scenes.make_seeds(spp, B)
-    rows = naive_schedule(world, H)
-    block_y = sum(rows[:rank])
-    block_h = rows[rank]
+    rows = naive_rows(world, H)                      # tracer/scheduler.go:83-106, equal speeds
+    block_y, block_h = block_of(rank, rows)
     if args.emulate_rank:
         er, en = (int(v) for v in args.emulate_rank.split("/"))
-        erows = naive_schedule(en, H)
-        block_y, block_h = sum(erows[:er]), erows[er]
+        block_y, block_h = block_of(er, naive_rows(en, H))
         rows = [block_h]
 
     tr = HipTracer(f"hip-{rank}", local_rank)
     tr.Init()
     if args.samples_per_batch:
         tr.set_option("samples_per_batch", args.samples_per_batch)
-    tr.set_option("time_kernels", 0 if args.no_kernel_timers else 1)
+    tr.set_option("time_kernels", 0)  # no event pairs inside the timed region; per-kernel times come from one extra frame afterwards
     for kv in args.opt:  # before the upload: some options shape the scene layout
         k, v = kv.split("=")
         tr.set_option(k, int(v))
@@ -152,15 +164,22 @@ def main() -> None:
         r.exposure, r.seed, r.accumulated_samples = 1.2, 0, 0
         return r
 
-    # RCCL gather wants equally sized pieces: strips are padded to the tallest block (the naive
-    # scheduler gives the remainder rows to tracer 0, tracer/scheduler.go:101-103)
-    max_rows = max(rows)
-    strip = torch.zeros((max_rows * W, 4), dtype=torch.float32, device=dev)
-    # rank 0 receives the strips into ONE buffer, in block order: with equal blocks that buffer is the frame
-    gathered = torch.empty((world, max_rows * W, 4), dtype=torch.float32, device=dev) if rank == 0 and world > 1 else None
-    gather_list = [gathered[i] for i in range(world)] if gathered is not None else None
-    uniform_rows = len(set(rows)) == 1
+    # The path's one exchange step (renderer/default.go:191): gather of the blocks' strips to the primary.  It runs one
+    # frame behind the tracing (polaris_amd/distributed.py): frame i's gather / merge / tone-map overlap frame i+1's Trace.
+    ex = StripExchange(dist, rank, rows, W, dev, via_host=args.backend != "nccl") if world > 1 else None
     totals = {k: 0 for k in ("primary_rays", "indirect_rays", "occlusion_rays", "shaded_hits", "shaded_misses", "emitter_hits", "unoccluded")}
+    pending = []
+
+    def finish_frame(ticket):
+        parts = ex.wait(ticket)
+        if rank == 0:
+            for y, h, t in parts:                  # ONE merge over the whole frame when the blocks are equally tall
+                tr.merge_device(t.data_ptr(), make_req(y, h))
+            tr.SyncFramebuffer(make_req(0, H))     # default.go:159-161
+
+    def flush():
+        while pending:
+            finish_frame(pending.pop(0))
 
     def frame(count: bool):
         req = make_req(block_y, block_h)
@@ -170,29 +189,12 @@ def main() -> None:
             for k in totals:
                 totals[k] += int(getattr(st, k))
         if world == 1:
-            tr.MergeOutput(tr, make_req(block_y, block_h))  # primary merges its own block (default.go:191)
+            tr.MergeOutput(tr, req)                # primary merges its own block (default.go:191)
+            tr.SyncFramebuffer(make_req(0, H) if not args.emulate_rank else req)
         else:
-            tr.export_block(make_req(block_y, block_h), strip.data_ptr())
-            if args.backend == "nccl":
-                dist.gather(strip, gather_list, dst=0)  # the path's one exchange step
-            else:  # gloo test mode: stage through host memory
-                host = [torch.empty((max_rows * W, 4), dtype=torch.float32) for i in range(world)] if rank == 0 else None
-                dist.gather(strip.cpu(), host, dst=0)
-                if rank == 0:
-                    for i in range(world):
-                        gather_list[i].copy_(host[i])
-            if rank == 0:
-                torch.cuda.synchronize()
-                if uniform_rows:  # one merge over the whole frame instead of one per peer
-                    tr.merge_device(gathered.data_ptr(), make_req(0, H))
-                else:
-                    y = 0
-                    for i in range(world):
-                        tr.merge_device(gather_list[i].data_ptr(), make_req(y, rows[i]))
-                        y += rows[i]
-        if rank == 0:
-            full = make_req(0, H) if not args.emulate_rank else make_req(block_y, block_h)
-            tr.SyncFramebuffer(full)               # default.go:159-161
+            ticket = ex.post(lambda strip: tr.export_block(req, strip.data_ptr()))
+            flush()                                # the PREVIOUS frame: its gather ran beside this frame's Trace
+            pending.append(ticket)
 
     def fence():
         torch.cuda.synchronize()
@@ -202,20 +204,16 @@ def main() -> None:
 
     for _ in range(args.warmup):
         frame(False)
-    for name in KERNELS:
-        tr.kernel_ms(name)  # reset timers accumulated during warm-up
+    flush()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         frame(True)
+    flush()                                        # all K frames merged and tone-mapped inside the timed region
     fence()
     elapsed = time.perf_counter() - t0
-
-    kt = {}
-    if not args.no_kernel_timers:
-        for name in KERNELS:
-            ms, n = tr.kernel_ms(name)
-            kt[name] = (ms, n)
+    if args.save_accumulator and rank == 0:
+        np.save(args.save_accumulator, tr.read_accumulator(1))  # the primary's frame accumulator of the last frame (tests)
 
     rdev = dev if args.backend == "nccl" else torch.device("cpu")
     el = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
@@ -245,42 +243,57 @@ def main() -> None:
             "data": "synthetic",
             "config": {"workload": f"{sc.name} {W}x{H} {spp}spp {B} bounces rr>={args.rr}, {sc.num_triangles} tris, "
                                    f"row blocks {rows} (naive scheduler), gather-to-primary + tonemap",
+                       "ranks": world, "exchange": "none (1 GPU)" if world == 1 else f"{args.backend} gather of the row-block strips to rank 0, one frame behind the tracing",
                        "frame": [W, H], "spp": spp, "bounces": B, "rays_per_frame": rays // args.steps,
                        "paths_per_s": W * H * spp * args.steps / elapsed},
         }
         # ---- roofline of the dominant kernel ---------------------------------------------------
-        # Kernel durations come from HIP events on the tracer's own streams (the library brackets
-        # every launch when time_kernels=1).  In the timed region up to four batches are in flight
-        # on separate streams, so a kernel's event time there includes the time it shares the GPU
-        # with other kernels; the roofline therefore uses one extra frame traced with overlap=1
-        # (same kernels, same inputs, one batch at a time), reported next to the overlapped times.
-        if kt:
+        # Kernel durations are HIP events on the tracer's own streams (the library brackets every launch
+        # when time_kernels=1).  They are NOT taken inside the timed region (event pairs around ~88 launches
+        # per frame, and up to four batches share the GPU there): ONE extra frame is traced afterwards with
+        # overlap=1 -- same kernels, same inputs, one batch at a time -- and the roofline uses those times.
+        if not args.no_kernel_timers:
             mine = {k: totals[k] // args.steps for k in totals}     # per-frame counters of rank 0
             tr.set_option("overlap", 1)
+            tr.set_option("time_kernels", 1)
+            for name in KERNELS:
+                tr.kernel_ms(name)
             tr.Trace(make_req(block_y, block_h), seeds)   # local to rank 0: no collective in here
             iso = {name: tr.kernel_ms(name) for name in KERNELS[:-2]}
             alg = kernel_algorithmic_bytes(mine)
             dom = max(("generate", "intersect_packet", "intersect", "shade", "occlusion"), key=lambda k: iso[k][0])
             ms, n = iso[dom]
             achieved = alg[dom] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-            if os.path.exists(tpath) and (W, H, spp, B, args.scene) == (512, 512, 128, 5, "cornell"):
-                kn = {"intersect": ("pol::k_trace<false",), "occlusion": ("pol::k_trace<true",), "shade": ("pol::k_shade<", "pol::k_shade_wave<"),
-                      "generate": ("pol::k_generate",), "intersect_packet": ("pol::k_trace_packet<false>",)}[dom]
-                tks = [v for k, v in json.load(open(tpath))["kernels"].items() if k.startswith(kn)]  # the bench timer's kernels
-                if tks:  # PMC (FETCH_SIZE x2 + WRITE_SIZE), scripts/traffic.sh, per launch of that timer
-                    traffic = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for v in tks) / max(sum(v["launches"] for v in tks), 1)
+            # HBM traffic per launch of that kernel: PMC data (FETCH_SIZE x2 + WRITE_SIZE, separate passes: scripts/traffic.sh)
+            # cannot be collected inside this run; it is read from the newest committed profile of THIS workload, and
+            # traffic_source says which file that was (null + null when there is none for the workload).
+            traffic, traffic_source = None, None
+            if (W, H, spp, B, args.scene, world) == (512, 512, 128, 5, "cornell", 1):
+                import glob
+
+                for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+                    tj = json.load(open(tpath))
+                    ent = tj.get("timers", {}).get(dom)
+                    if ent is None:  # round-1 file: keyed by kernel name
+                        kn = {"intersect": ("pol::k_trace<false",), "occlusion": ("pol::k_trace<true",), "shade": ("pol::k_shade<", "pol::k_shade_wave<"),
+                              "generate": ("pol::k_generate",), "intersect_packet": ("pol::k_trace_packet<false>",)}[dom]
+                        tks = [v for k, v in tj["kernels"].items() if k.startswith(kn)]
+                        if tks:
+                            ent = {"hbm_bytes": sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for v in tks), "launches": sum(v["launches"] for v in tks)}
+                    if ent and ent.get("launches"):
+                        traffic = ent["hbm_bytes"] / ent["launches"]
+                        traffic_source = "profiles/" + os.path.basename(tpath) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 1`, " \
+                            "collected on the builder's MI355X lease; not re-measured in this run)"
+                        break
             names = {"intersect": "k_trace<false,16> (closest hit, bounce rays)", "intersect_packet": "k_trace_packet<false> (camera rays)",
                      "occlusion": "k_trace<true,16> (any hit + NEE accumulate)", "shade": "k_shade + k_shade_wave (shadeHits, miss shading, compaction)",
                      "generate": "k_generate"}
             out["roofline"] = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                                "algorithmic_bytes_per_launch": alg[dom] / max(n, 1), "avg_launch_ms": ms / max(n, 1), "launches": n,
                                "measured": "HIP events, one extra frame with overlap=1 after the timed region"}
             out["kernels_isolated_ms_per_frame"] = {k: round(v[0], 3) for k, v in iso.items()}
             out["kernels_isolated_GBps_algorithmic"] = {k: round(alg[k] / (iso[k][0] * 1e-3) / 1e9, 1) for k in alg if iso[k][0] > 0}
-            out["kernels_timed_region_ms"] = {k: round(v[0], 3) for k, v in kt.items()}
             whole = (112 * mine["primary_rays"] + 68 * mine["shaded_hits"] + 92 * mine["indirect_rays"] + 80 * mine["occlusion_rays"]
                      + 44 * mine["unoccluded"] + 60 * mine["shaded_misses"] + 24 * mine["emitter_hits"] + (48 + 16) * rows[0] * W)
             out["whole_path_algorithmic_GBps_rank0"] = whole / (elapsed / args.steps) / 1e9

@@ -252,13 +252,15 @@ __global__ __launch_bounds__(WG) void k_occlusion(Streams st, BvhDev B, float4 *
 // of an issued VALU instruction are live (SQ_THREAD_CYCLES_VALU / 64 / SQ_ACTIVE_INST_VALU) --
 // rays of a wave finish at very different times and lanes sit in different phases (box tests
 // vs triangle tests).  This kernel attacks both:
-//   * a wave is a persistent worker: it pulls 256-slot chunks (= one workgroup's compacted rays)
-//     from a global ticket counter and, whenever >= kRefillMin of its lanes are idle, hands them
-//     the next rays of the chunk (ballot/popcount ranks) -- the wave's tail is filled with new
-//     work instead of waiting for its longest ray;
+//   * a workgroup is a persistent worker: the 256-slot chunks (= one workgroup's compacted rays) are
+//     dealt statically (chunk c belongs to workgroup c % gridDim.x; its 4 waves share an LDS cursor)
+//     and, whenever >= kRefillMin of a wave's lanes are idle, they are handed the next rays of the
+//     chunk (ballot/popcount ranks) -- the wave's tail is filled with new work instead of waiting
+//     for its longest ray.  Because the deal is static the grid must not exceed what the GPU holds at
+//     once (the host sizes it from the occupancy API);
 //   * "while-while" phases: all lanes first descend through inner nodes (lanes that already
 //     reached a leaf wait), then all lanes with a leaf test triangles.
-// The queue needs no co-residency: a wave exits when the ticket counter passes the chunk count.
+// The queue needs no co-residency: a wave exits when its workgroup's share of the chunks is used up.
 // Per-ray arithmetic is the same as traverse<> above (same slab test, same Moeller-Trumbore,
 // same tie rule), so results are bit-identical; only the schedule changes.
 // ------------------------------------------------------------------------------------------
@@ -299,8 +301,7 @@ __device__ __forceinline__ float slab_entry_hw(float4 lo, float4 hi, f3 o, f3 in
 // the any-hit kernel spills at that budget and stays at its natural 5).
 template <bool ANY_HIT, int STACK, bool LDS_TOP>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((!ANY_HIT && STACK == 16) ? 7 : 1, (!ANY_HIT && STACK == 16) ? 7 : 10)))
-void k_trace(Streams st, BvhDev B, uint32_t num_chunks, uint32_t *ticket, float4 *acc,
-                                              unsigned long long *stats) {
+void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned long long *stats) {
 	__shared__ int stk[STACK][WG]; // STACK = smallest of {16, 24, 32} that fits the scene: LDS per wave sets the occupancy
 	__shared__ uint32_t wg_cursor;
 	if (threadIdx.x == 0) wg_cursor = 0;
@@ -316,7 +317,6 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, uint32_t *ticket, float4
 		for (uint32_t i = threadIdx.x; i < n4; i += WG) top[i] = src[i];
 	}
 	__syncthreads();
-	(void)ticket;
 	const int tid = threadIdx.x;
 	const uint32_t lane = tid & 63;
 	const unsigned long long below = (1ull << lane) - 1ull;
@@ -371,8 +371,19 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, uint32_t *ticket, float4
 #else
 #define TC(x)
 #endif
+#ifdef POLARIS_STAMPS
+	unsigned long long sk_refill = 0, sk_wait1 = 0, sk_comp1 = 0, sk_wait2 = 0, sk_comp2 = 0, sk_total = 0, sk_t = 0, sk_t0 = __builtin_amdgcn_s_memtime();
+#define STAMP_BEGIN() sk_t = __builtin_amdgcn_s_memtime()
+#define STAMP(acc) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - sk_t; sk_t = now_; }
+#define STAMP_WAIT() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#else
+#define STAMP_BEGIN()
+#define STAMP(acc)
+#define STAMP_WAIT()
+#endif
 	for (;;) {
 		TC(c_outer++;)
+		STAMP_BEGIN();
 		// ---- refill idle lanes ---------------------------------------------------------------
 		unsigned long long freem = __ballot(!has);
 		if (!drained && (freem == ~0ull || __popcll(freem) >= (ANY_HIT ? kRefillMinAny : kRefillMin))) {
@@ -409,6 +420,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, uint32_t *ticket, float4
 				off += take;
 			}
 		}
+		STAMP(sk_refill)
 		if (__ballot(has) == 0ull) {
 			if (drained) break;
 			continue;
@@ -421,11 +433,16 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, uint32_t *ticket, float4
 			const bool descending = has && cur >= 0;
 			const int nd = __popcll(__ballot(descending));
 			if (nd == 0 || (it1 > 0 && nd < (ANY_HIT ? kStragglersAny : kStragglers))) break;
+			STAMP(sk_comp1)
 			if (!descending) continue;
 			TC(c_node++; if (lane == __ffsll((long long)__ballot(true)) - 1) c_iter1++;)
 			PairNode P;
 			if (LDS_TOP && cur < kLdsTopNodes) { P.lo0 = top[4 * cur]; P.hi0 = top[4 * cur + 1]; P.lo1 = top[4 * cur + 2]; P.hi1 = top[4 * cur + 3]; }
 			else P = B.pairs[cur];
+#ifdef POLARIS_STAMPS
+			asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(P.lo0.x), "+v"(P.hi0.x), "+v"(P.lo1.x), "+v"(P.hi1.x) :: "memory");
+			STAMP(sk_wait1)
+#endif
 			float t0 = slab_entry_hw(P.lo0, P.hi0, o, inv, maxDist);
 			float t1 = slab_entry_hw(P.lo1, P.hi1, o, inv, maxDist);
 			if (!ANY_HIT) {
@@ -446,6 +463,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, uint32_t *ticket, float4
 				pop();
 			}
 		}
+		STAMP(sk_comp1)
 		// ---- phase 2: leaves ---------------------------------------------------------------------
 		if (has && cur < 0) {
 			TC(c_leaf++; if (lane == __ffsll((long long)__ballot(true)) - 1) c_iter2++;)
@@ -520,7 +538,15 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, uint32_t *ticket, float4
 				else pop();
 			}
 		}
+		STAMP(sk_comp2)
 	}
+#ifdef POLARIS_STAMPS
+	if (lane == 0) {
+		sk_total = __builtin_amdgcn_s_memtime() - sk_t0;
+		const unsigned long long v[6] = {sk_refill, sk_wait1, sk_comp1, sk_comp2, sk_total, 1ull};
+		for (int i = 0; i < 6; i++) atomicAdd(&stats[ST_DEBUG + (ANY_HIT ? 8 : 0) + i], v[i]);
+	}
+#endif
 #ifdef POLARIS_TRACE_COUNTERS
 	{
 		uint32_t v[8] = {c_node, c_leaf, c_tri, c_iter1, c_iter2, c_outer, c_refill, c_triiter};

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -19,6 +20,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "trace_pool.h"
 #include "polaris_hip.h"
 
 using namespace pol;
@@ -74,7 +76,6 @@ struct polaris_hip_tracer {
 	uint32_t *d_seeds = nullptr;
 	size_t seeds_cap = 0;
 	unsigned long long *d_stats = nullptr;
-	uint32_t *d_tickets = nullptr; // work-queue ticket counters of the persistent traversal launches of one batch
 	int num_cus = 256;
 	void *staging = nullptr; // peer-merge staging strip
 	size_t staging_bytes = 0;
@@ -184,6 +185,16 @@ void collect_timers(polaris_hip_tracer *h) { // stream must be idle
 	h->pending.clear();
 }
 
+hipError_t sync_all(polaris_hip_tracer *h) { // every pipeline of the handle idle (before anything the kernels use is freed)
+	hipError_t first = hipSuccess;
+	for (int p = 0; p < polaris_hip_tracer::kMaxPipes; p++)
+		if (h->pipe[p].q) {
+			const hipError_t e = hipStreamSynchronize(h->pipe[p].q);
+			if (first == hipSuccess) first = e;
+		}
+	return first;
+}
+
 int ensure_streams(polaris_hip_tracer *h, int p, size_t slots, bool want_inst) {
 	polaris_hip_tracer::Pipe &P = h->pipe[p];
 	if (slots <= P.slots && (!want_inst || P.st.hit_inst)) return POLARIS_OK;
@@ -229,11 +240,11 @@ template <bool ANY_HIT, bool LDS_TOP>
 void launch_trace_v(polaris_hip_tracer *h, polaris_hip_tracer::Pipe &P, uint32_t grid, uint32_t chunks, float4 *acc) {
 	hipStream_t q = P.q;
 	if (h->max_stack <= 16)
-		hipLaunchKernelGGL((k_trace<ANY_HIT, 16, LDS_TOP>), dim3(grid), dim3(WG), 0, q, P.st, h->bvh, chunks, h->d_tickets, acc, h->d_stats);
+		hipLaunchKernelGGL((k_trace<ANY_HIT, 16, LDS_TOP>), dim3(grid), dim3(WG), 0, q, P.st, h->bvh, chunks, acc, h->d_stats);
 	else if (h->max_stack <= 24)
-		hipLaunchKernelGGL((k_trace<ANY_HIT, 24, LDS_TOP>), dim3(grid), dim3(WG), 0, q, P.st, h->bvh, chunks, h->d_tickets, acc, h->d_stats);
+		hipLaunchKernelGGL((k_trace<ANY_HIT, 24, LDS_TOP>), dim3(grid), dim3(WG), 0, q, P.st, h->bvh, chunks, acc, h->d_stats);
 	else
-		hipLaunchKernelGGL((k_trace<ANY_HIT, 32, LDS_TOP>), dim3(grid), dim3(WG), 0, q, P.st, h->bvh, chunks, h->d_tickets, acc, h->d_stats);
+		hipLaunchKernelGGL((k_trace<ANY_HIT, 32, LDS_TOP>), dim3(grid), dim3(WG), 0, q, P.st, h->bvh, chunks, acc, h->d_stats);
 }
 
 template <bool ANY_HIT>
@@ -243,16 +254,39 @@ void launch_trace(polaris_hip_tracer *h, polaris_hip_tracer::Pipe &P, uint32_t g
 	else launch_trace_v<ANY_HIT, false>(h, P, grid, chunks, acc);
 }
 
+#ifndef POLARIS_POOL_RAYS
+#define POLARIS_POOL_RAYS 128
+#endif
+constexpr int kPoolRays = POLARIS_POOL_RAYS;
+
+template <bool ANY_HIT>
+const void *pool_kernel(polaris_hip_tracer *h) {
+	if (h->max_stack <= 16) return (const void *)k_trace_pool<ANY_HIT, 16, kPoolRays>;
+	return nullptr; // deeper trees: k_trace
+}
+
+template <bool ANY_HIT>
+void launch_trace_pool(polaris_hip_tracer *h, polaris_hip_tracer::Pipe &P, uint32_t grid, uint32_t chunks, float4 *acc) {
+	hipLaunchKernelGGL((k_trace_pool<ANY_HIT, 16, kPoolRays>), dim3(grid), dim3(WG), 0, P.q, P.st, h->bvh, chunks, acc, h->d_stats);
+}
+
 // Resident workgroups per CU of the k_trace variant launch_trace<ANY_HIT> would pick.
 template <bool ANY_HIT>
 int trace_occupancy(polaris_hip_tracer *h) {
 	const bool lds_top = h->bvh.num_pairs <= 8u * kLdsTopNodes;
 	const void *fn;
+	if (h->opt_traversal == 2 && pool_kernel<ANY_HIT>(h)) {
+		int n = 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pool_kernel<ANY_HIT>(h), WG, 0) != hipSuccess || n < 1) n = 1;
+		if (getenv("POLARIS_DEBUG")) fprintf(stderr, "[polaris] k_trace_pool<%d> resident workgroups per CU: %d\n", (int)ANY_HIT, n);
+		return std::min(n, 8);
+	}
 	if (h->max_stack <= 16) fn = lds_top ? (const void *)k_trace<ANY_HIT, 16, true> : (const void *)k_trace<ANY_HIT, 16, false>;
 	else if (h->max_stack <= 24) fn = lds_top ? (const void *)k_trace<ANY_HIT, 24, true> : (const void *)k_trace<ANY_HIT, 24, false>;
 	else fn = lds_top ? (const void *)k_trace<ANY_HIT, 32, true> : (const void *)k_trace<ANY_HIT, 32, false>;
 	int n = 0;
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, WG, 0) != hipSuccess || n < 1) n = h->max_stack <= 24 ? 6 : 5;
+	if (getenv("POLARIS_DEBUG")) fprintf(stderr, "[polaris] k_trace<%d> resident workgroups per CU: %d\n", (int)ANY_HIT, n);
 	return std::min(n, 8);
 }
 
@@ -286,7 +320,7 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 	// workgroup -> 8 by LDS, VGPRs allow 7-8 waves/SIMD; 32-entry: 5)
 	auto grid_of = [&](int resident) {
 		uint32_t per_cu = (uint32_t)std::max(1, resident);
-		if (std::min(h->opt_overlap, (int)polaris_hip_tracer::kMaxPipes) > 1 && !exact) per_cu = std::max(2u, per_cu * 2u / 3u);
+		if (std::min(h->opt_overlap, (int)polaris_hip_tracer::kMaxPipes) > 1 && !exact && per_cu > 2) per_cu = std::max(2u, per_cu * 2u / 3u);
 		if (h->opt_trace_wgs_per_cu > 0) per_cu = (uint32_t)h->opt_trace_wgs_per_cu;
 		return std::min<uint32_t>(wgs, (uint32_t)h->num_cus * per_cu);
 	};
@@ -296,6 +330,8 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 			Timed t(h, (b == 0 && h->packet_primary) ? "intersect_packet" : "intersect", q);
 			if (b == 0 && h->packet_primary)
 				hipLaunchKernelGGL(k_trace_packet<false>, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, (float4 *)nullptr, h->d_stats);
+			else if (h->opt_traversal == 2 && pool_kernel<false>(h))
+				launch_trace_pool<false>(h, P, persistent, wgs, nullptr);
 			else if (h->opt_traversal)
 				launch_trace<false>(h, P, persistent, wgs, nullptr);
 			else
@@ -322,6 +358,8 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 			Timed t(h, "occlusion", q);
 			if ((int)b < h->opt_packet_shadow)
 				hipLaunchKernelGGL(k_trace_packet<true>, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, A.acc, h->d_stats);
+			else if (h->opt_traversal == 2 && pool_kernel<true>(h))
+				launch_trace_pool<true>(h, P, persistent_occl, wgs, A.acc);
 			else if (h->opt_traversal)
 				launch_trace<true>(h, P, persistent_occl, wgs, A.acc);
 			else
@@ -379,7 +417,6 @@ int polaris_hip_create(int device_index, polaris_hip_tracer **out) {
 	for (int p = 0; p < polaris_hip_tracer::kMaxPipes && e == hipSuccess; p++) e = hipEventCreateWithFlags(&h->pipe[p].done, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipMalloc((void **)&h->d_stats, ST_COUNT * sizeof(unsigned long long));
-	if (e == hipSuccess) e = hipMalloc((void **)&h->d_tickets, 2 * POLARIS_MAX_BOUNCES * sizeof(uint32_t));
 	if (e == hipSuccess) {
 		hipDeviceProp_t p;
 		if (hipGetDeviceProperties(&p, device_index) == hipSuccess && p.multiProcessorCount > 0) h->num_cus = p.multiProcessorCount;
@@ -418,7 +455,6 @@ void polaris_hip_destroy(polaris_hip_tracer *h) {
 		if (h->framebuffer) (void)hipFree(h->framebuffer);
 		if (h->d_seeds) (void)hipFree(h->d_seeds);
 		if (h->d_stats) (void)hipFree(h->d_stats);
-		if (h->d_tickets) (void)hipFree(h->d_tickets);
 		if (h->staging) (void)hipFree(h->staging);
 		if (h->ev_start) (void)hipEventDestroy(h->ev_start);
 		if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
@@ -427,7 +463,15 @@ void polaris_hip_destroy(polaris_hip_tracer *h) {
 	delete h;
 }
 
-const char *polaris_hip_last_error(polaris_hip_tracer *h) { return h ? h->error.c_str() : g_thread_error.c_str(); }
+const char *polaris_hip_last_error(polaris_hip_tracer *h) {
+	if (!h) return g_thread_error.c_str();
+	thread_local std::string copy; // a concurrent merge may be failing on the same handle: read under its lock
+	{
+		std::lock_guard<std::mutex> lk(h->mu);
+		copy = h->error;
+	}
+	return copy.c_str();
+}
 
 int polaris_hip_resize(polaris_hip_tracer *h, uint32_t frame_w, uint32_t frame_h) {
 	if (!h) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "handle is null");
@@ -435,7 +479,7 @@ int polaris_hip_resize(polaris_hip_tracer *h, uint32_t frame_w, uint32_t frame_h
 	if (frame_w == 0 || frame_h == 0 || (uint64_t)frame_w * frame_h > (1ull << 28))
 		return fail(h, POLARIS_E_BAD_ARGUMENT, "bad frame dimensions %ux%u", frame_w, frame_h);
 	HIP_TRY(h, hipSetDevice(h->device));
-	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	HIP_TRY(h, sync_all(h));
 	if (h->trace_acc) (void)hipFree(h->trace_acc);
 	if (h->frame_acc) (void)hipFree(h->frame_acc);
 	if (h->framebuffer) (void)hipFree(h->framebuffer);
@@ -471,7 +515,7 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 	}
 	if (!err.empty()) return fail(h, POLARIS_E_BAD_SCENE, "%s", err.c_str());
 	HIP_TRY(h, hipSetDevice(h->device));
-	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	HIP_TRY(h, sync_all(h));
 	free_pool(h->scene_bufs);
 	h->have_scene = false;
 	int rc = 0;
@@ -527,7 +571,10 @@ int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value
 	else if (k == "packet_primary") { h->opt_packet_primary = value < 0 ? -1 : (value != 0); if (value >= 0) h->packet_primary = value != 0; }
 	else if (k == "packet_shadow") h->opt_packet_shadow = (int)std::max<int64_t>(0, std::min<int64_t>(value, POLARIS_MAX_BOUNCES));
 	else if (k == "time_kernels") h->opt_time_kernels = value != 0;
-	else if (k == "traversal") h->opt_traversal = value != 0;
+	else if (k == "traversal") { // 0 = one ray per lane, 1 = persistent waves with lane refill, 2 = per-wave ray pool in LDS; re-sizes the persistent grids
+		h->opt_traversal = (int)std::max<int64_t>(0, std::min<int64_t>(value, 2));
+		if (h->have_scene) { h->trace_resident_per_cu = trace_occupancy<false>(h); h->occl_resident_per_cu = trace_occupancy<true>(h); }
+	}
 	else if (k == "shade_wave") h->opt_shade_wave = value != 0;
 	else if (k == "shade_wave_from") h->opt_shade_wave_from = (int)std::max<int64_t>(-1, std::min<int64_t>(value, POLARIS_MAX_BOUNCES));
 	else if (k == "shade_wgs_per_cu") h->opt_shade_wgs_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(value, 64));
@@ -597,6 +644,12 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 		HIP_TRY(h, hipEventRecord(h->ev_fork, q));
 		for (int p = 1; p < n_pipes; p++) HIP_TRY(h, hipStreamWaitEvent(h->pipe[p].q, h->ev_fork, 0));
 	}
+	// From here on batches are in flight on several streams: a failure must not return before every one
+	// of them has drained (resize / upload_scene / destroy free what the kernels still write to).
+	struct DrainOnError {
+		polaris_hip_tracer *h; int n; bool armed = true;
+		~DrainOnError() { if (armed) for (int p = 0; p < n; p++) (void)hipStreamSynchronize(h->pipe[p].q); }
+	} drain{h, n_pipes};
 	uint32_t bi = 0;
 	for (uint32_t s0 = 0; s0 < spp; s0 += K, bi++) {
 		const int p = (int)(bi % (uint32_t)n_pipes), prev = (int)((bi + (uint32_t)n_pipes - 1) % (uint32_t)n_pipes);
@@ -608,6 +661,7 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 	HIP_TRY(h, hipMemcpyAsync(hs, h->d_stats, sizeof hs, hipMemcpyDeviceToHost, q));
 	HIP_TRY(h, hipEventRecord(h->ev_stop, q));
 	HIP_TRY(h, hipStreamSynchronize(q));
+	drain.armed = false; // the join above made q wait for every pipeline
 	collect_timers(h);
 	if (stats) {
 		memset(stats, 0, sizeof *stats);
@@ -628,6 +682,13 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 		float ms = 0.0f;
 		(void)hipEventElapsedTime(&ms, h->ev_start, h->ev_stop);
 		stats->device_ms = ms;
+#ifdef POLARIS_STAMPS
+		for (int a = 0; a < 2; a++) {
+			fprintf(stderr, "[stamps %s]", a ? "anyhit" : "closest");
+			for (int i = 0; i < 8; i++) fprintf(stderr, " %llu", hs[ST_DEBUG + 8 * a + i]);
+			fprintf(stderr, "\n");
+		}
+#endif
 #ifdef POLARIS_TRACE_COUNTERS
 		static const char *names[8] = {"node_tests", "leaf_visits", "tri_tests", "wave_iters_inner", "wave_iters_leaf", "wave_outer", "wave_refills", "wave_iters_tri"};
 		for (int a = 0; a < 2; a++)
@@ -639,7 +700,10 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 
 int polaris_hip_merge(polaris_hip_tracer *dst, polaris_hip_tracer *src, const PolarisBlockRequest *r) {
 	if (!dst || !src) return fail(dst, POLARIS_E_BAD_ARGUMENT, "merge: null tracer handle");
-	std::lock_guard<std::mutex> lk(dst->mu);
+	// both handles' state is read: lock both (in one deadlock-free step when they differ)
+	std::unique_lock<std::mutex> lk(dst->mu, std::defer_lock), lk_src(src->mu, std::defer_lock);
+	if (src == dst) lk.lock();
+	else std::lock(lk, lk_src);
 	if (int rc = check_request(dst, r)) return rc;
 	if (src->W != dst->W || src->H != dst->H || !src->trace_acc)
 		return fail(dst, POLARIS_E_BAD_ARGUMENT, "merge: source tracer has different frame dimensions");

@@ -102,8 +102,10 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out, in
 			if ((m.type == POLARIS_MAT_OP_MIX || m.type == POLARIS_MAT_OP_MIX_MAP) &&
 			    (m.right_child < 0 || (uint32_t)m.right_child >= sc.num_material_nodes))
 				return who + ": right child out of range";
-			if (m.type == POLARIS_MAT_OP_MIX_MAP || m.type == POLARIS_MAT_OP_BUMP_MAP || m.type == POLARIS_MAT_OP_NORMAL_MAP)
+			if (m.type == POLARIS_MAT_OP_MIX_MAP || m.type == POLARIS_MAT_OP_BUMP_MAP || m.type == POLARIS_MAT_OP_NORMAL_MAP) {
 				if (m.tex < 0 || (uint32_t)m.tex >= sc.num_textures) return who + ": operator texture out of range";
+			} else if (!tex_ok(m.tex)) // mix / disperse: unused by the operator, but a background or light reference may land on any node
+				return who + ": texture out of range";
 		} else {
 			if (!tex_ok(m.tex) || !tex_ok(m.roughness_tex)) return who + ": texture out of range";
 			if ((m.type == POLARIS_BXDF_DIELECTRIC || m.type == POLARIS_BXDF_ROUGH_DIELECTRIC) && !tex_ok(m.right_child))
@@ -131,7 +133,8 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out, in
 	std::vector<uint32_t> tri_rank(NT, 0xFFFFFFFFu);
 	std::vector<uint32_t> slot_src;          // triangle slot of the kernels -> scene triangle (pass 2)
 	std::vector<int32_t> leaf_root(NN, -1);  // reachable triangle leaf -> root of its mesh BVH
-	std::vector<uint8_t> seen;
+	std::vector<uint32_t> seen;              // generation stamps: seen[n] == seen_gen <=> reached in the current walk
+	uint32_t seen_gen = 0;
 	// tagged child reference: inner node -> its index; leaf -> ~code, see the header comment
 	auto ref_of = [&](int32_t idx) -> int32_t {
 		const PolarisBvhNode &n = nodes[idx];
@@ -155,10 +158,11 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out, in
 			Item it = st.back();
 			st.pop_back();
 			if (it.node < 0 || (uint32_t)it.node >= n_nodes) { err = "BVH child index out of range"; return false; }
-			if (seen[it.node] && level == 0) { err = "BVH node " + std::to_string(it.node) + " reachable twice"; return false; }
-			seen[it.node] = 1;
+			// a node reached twice within one tree (a DAG) makes every walk -- this one and the GPU's -- exponential in the depth
+			if (seen[it.node] == seen_gen) { err = "BVH node " + std::to_string(it.node) + " reachable twice"; return false; }
+			seen[it.node] = seen_gen;
 			if (it.depth > max_depth) max_depth = it.depth;
-			if (it.depth > 4 * kTraversalStack) { err = "BVH too deep"; return false; }
+			if (it.depth > kTraversalStack) { err = pass == 2 ? "@retry-without-subdivision" : "BVH too deep for the traversal stack"; return false; }
 			const PolarisBvhNode &n = nodes[it.node];
 			if (is_leaf(n)) {
 				if (pass == 2) out.leaves[it.node] = {n.ldata, n.rdata};
@@ -200,6 +204,7 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out, in
 	int need = 0;
 	auto walk_scene = [&]() -> std::string {
 		seen.assign(n_nodes, 0);
+		seen_gen = 1;
 		next_inst_rank = 0;
 		top_max = 0;
 		uint32_t dummy = 0;
@@ -214,7 +219,7 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out, in
 			if (root_depth[mi.bvh_root] < 0) {
 				int md = 0;
 				uint32_t rank = 0;
-				std::fill(seen.begin(), seen.end(), 0);
+				seen_gen++; // distinct mesh roots may share subtrees; one walk may not reach a node twice
 				if (!walk((int32_t)mi.bvh_root, 1, rank, md)) return err;
 				root_depth[mi.bvh_root] = md;
 			}

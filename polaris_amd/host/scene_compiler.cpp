@@ -79,7 +79,10 @@ struct Builder {
 			// best is kept with a strict "<": ties go to whichever goroutine reports first.
 			// Here: ascending (axis, splitPoint) order, deterministic.
 			std::vector<float> points;
-			for (float p = mn[axis]; p < mx[axis]; p += splitStep) points.push_back(p);
+			for (float p = mn[axis]; p < mx[axis]; p += splitStep) {
+				points.push_back(p);
+				if (p + splitStep == p) break; // step below half an ulp of p (coordinates far from the origin): the reference spins here
+			}
 			std::vector<float> scores(points.size());
 #pragma omp parallel for schedule(static) if (points.size() * w.size() > (1u << 16))
 			for (long k = 0; k < (long)points.size(); k++) {

@@ -1,15 +1,18 @@
-"""The N>1 path of bench.py on CPU: 2 ranks over gloo partition the frame by row block, each
-renders its block (the CPU oracle stands in for the GPU tracer -- it is the checker, used here as
-test infrastructure only), rank 0 gathers the strips and assembles the frame accumulator.  The
-assembled frame must equal the per-block oracle results bit for bit."""
+"""The N>1 path of bench.py on CPU: 2 ranks over gloo partition the frame by row block, each renders
+its block (the CPU oracle stands in for the GPU tracer -- it is the checker, used here as test
+infrastructure only), and the strips travel to rank 0 through polaris_amd.distributed.StripExchange
+-- the SAME class, used the same way (post -> trace the next frame -> wait), that bench.py runs over
+RCCL.  Three frames with different seeds are in flight one behind the other; every assembled frame
+must equal the per-block oracle results bit for bit (uneven blocks: 31 rows -> [16, 15])."""
 import os
 import socket
 import sys
 
 import numpy as np
-import pytest
 
 from conftest import ROOT
+
+W, H, SPP, B, FRAMES = 40, 31, 2, 4, 3
 
 
 def _free_port():
@@ -28,24 +31,39 @@ def _worker(rank, world, port, out_path):
 
     from oracle import pybind as ob
     from polaris_amd import scenes
-    from polaris_amd.distributed import block_of, gather_strips, naive_rows
+    from polaris_amd.distributed import StripExchange, block_of, naive_rows
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    W, H, spp, B = 40, 30, 2, 4
     sc = scenes.SCENES["cornell-diffuse"](W / H)
-    seeds = scenes.make_seeds(spp, B)
     rows = naive_rows(world, H)
     by, bh = block_of(rank, rows)
-    acc, _, _ = ob.Oracle("oracle").trace(sc, ob.make_request(W, H, spp=spp, bounces=B, block_y=by, block_h=bh), seeds)
-    strip = torch.from_numpy(np.ascontiguousarray(acc[by:by + bh].reshape(-1, 4)))
-    strips = gather_strips(strip, rows, W, dist, rank)
+    ex = StripExchange(dist, rank, rows, W, "cpu")
+    orc = ob.Oracle("oracle")
+    frames, pending = [], []
+
+    def finish(ticket):
+        parts = ex.wait(ticket)
+        if rank == 0:
+            frame = np.zeros((H, W, 4), np.float32)
+            for y, h, t in parts:  # what bench.py hands to polaris_hip_merge_device
+                frame[y:y + h] += t.numpy().reshape(-1, W, 4)[:h] if t.dim() == 2 else t.numpy().reshape(-1, 4)[: h * W].reshape(h, W, 4)
+            frames.append(frame)
+
+    for f in range(FRAMES):
+        seeds = scenes.make_seeds(SPP, B, base=100 + f)
+        acc, _, _ = orc.trace(sc, ob.make_request(W, H, spp=SPP, bounces=B, block_y=by, block_h=bh), seeds)
+
+        def fill(strip, acc=acc):
+            strip[: bh * W].copy_(torch.from_numpy(np.ascontiguousarray(acc[by:by + bh].reshape(-1, 4))))
+
+        ticket = ex.post(fill)
+        while pending:
+            finish(pending.pop(0))
+        pending.append(ticket)
+    while pending:
+        finish(pending.pop(0))
     if rank == 0:
-        frame = np.zeros((H, W, 4), np.float32)
-        y = 0
-        for r in range(world):
-            frame[y:y + rows[r]] += strips[r].numpy().reshape(rows[r], W, 4)
-            y += rows[r]
-        np.save(out_path, frame)
+        np.save(out_path, np.stack(frames))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -57,17 +75,29 @@ def test_two_rank_row_block_gather(built, tmp_path):
     from polaris_amd import scenes
     from polaris_amd.distributed import block_of, naive_rows
 
-    out = str(tmp_path / "frame.npy")
+    out = str(tmp_path / "frames.npy")
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
-    frame = np.load(out)
-    W, H, spp, B = 40, 30, 2, 4
+    frames = np.load(out)
+    assert frames.shape == (FRAMES, H, W, 4)
     sc = scenes.SCENES["cornell-diffuse"](W / H)
-    seeds = scenes.make_seeds(spp, B)
     rows = naive_rows(2, H)
-    expect = np.zeros((H, W, 3), np.float32)
+    assert rows == [16, 15]
     orc = ob.Oracle("oracle")
-    for r in range(2):
-        by, bh = block_of(r, rows)
-        a, _, _ = orc.trace(sc, ob.make_request(W, H, spp=spp, bounces=B, block_y=by, block_h=bh), seeds)
-        expect[by:by + bh] = a[by:by + bh, :, :3]
-    assert np.array_equal(frame[..., :3].view(np.uint32), expect.view(np.uint32))
+    for f in range(FRAMES):
+        seeds = scenes.make_seeds(SPP, B, base=100 + f)
+        expect = np.zeros((H, W, 3), np.float32)
+        for r in range(2):
+            by, bh = block_of(r, rows)
+            a, _, _ = orc.trace(sc, ob.make_request(W, H, spp=SPP, bounces=B, block_y=by, block_h=bh), seeds)
+            expect[by:by + bh] = a[by:by + bh, :, :3]
+        assert np.array_equal(frames[f][..., :3].view(np.uint32), expect.view(np.uint32)), f
+
+
+def test_naive_rows_is_the_reference_schedule():
+    """tracer/scheduler_test.go:16-20 known answers (speeds -> rows at H=10) + the equal-speed split bench.py uses."""
+    from polaris_amd.distributed import naive_rows
+
+    assert naive_rows(2, 10, [1, 2]) == [4, 6]
+    assert naive_rows(2, 10, [2, 1]) == [7, 3]
+    assert naive_rows(2, 10, [1, 1000]) == [1, 9]
+    assert naive_rows(8, 512) == [64] * 8 and naive_rows(8, 1080) == [135] * 8 and naive_rows(2, 97) == [49, 48]

@@ -40,7 +40,57 @@ def test_bench_single_gpu_line(built):
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
 
 
-def test_bench_two_ranks_complete(built):
+def _two_rank_frame_matches_the_oracle(d, acc_path):
+    """rank 0's frame accumulator of the last frame == the oracle run block by block, bit for bit
+    (exact_accumulate=1), like test_row_blocks_merge_to_the_full_frame does in-process."""
+    import numpy as np
+
+    from oracle import pybind as ob
+    from polaris_amd import scenes
+    from polaris_amd.distributed import block_of, naive_rows
+
+    W, H, spp, B = 128, 97, 8, 5
+    frame = np.load(acc_path)
+    assert frame.shape == (H, W, 4)
+    sc = scenes.SCENES["cornell"](W / H)
+    seeds = scenes.make_seeds(spp, B)
+    rows = naive_rows(2, H)
+    orc = ob.Oracle("oracle")
+    expect = np.zeros((H, W, 3), np.float32)
+    rays = 0
+    for r in range(2):
+        by, bh = block_of(r, rows)
+        a, st, _ = orc.trace(sc, ob.make_request(W, H, spp=spp, bounces=B, rr=3, block_y=by, block_h=bh), seeds)
+        expect[by:by + bh] = a[by:by + bh, :, :3]
+        rays += st.total_rays()
+    assert np.array_equal(frame[..., :3].view(np.uint32), expect.view(np.uint32))
+    assert d["config"]["rays_per_frame"] == rays
+
+
+def test_bench_two_ranks_bare_launch_and_frame(built, tmp_path):
+    """`python bench.py --gpus 2` with NO launcher: bench.py starts its own ranks (two ranks share the one
+    GPU over gloo -- the same frame loop the driver runs over RCCL on 8 GPUs), reports n_gpus == 2, and the
+    frame the primary assembled from the gathered strips equals the per-block oracle bit for bit."""
+    acc = str(tmp_path / "frame.npy")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--backend", "gloo", "--same-device", "--no-cpu-baseline",
+           "--opt", "exact_accumulate=1", "--save-accumulator", acc]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert "row blocks [49, 48]" in d["config"]["workload"]
+    _two_rank_frame_matches_the_oracle(d, acc)
+
+
+def test_bench_refuses_more_gpus_than_visible(built):
+    """--gpus 64 on this box must fail loudly, never print a 1-GPU line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", *SMALL], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0 and "only" in (out.stderr + out.stdout) and "{" not in out.stdout
+
+
+def test_bench_two_ranks_under_the_drivers_launcher(built):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--backend", "gloo", "--same-device",
            "--no-cpu-baseline"]

@@ -70,6 +70,8 @@ def test_hip_vs_oracle_exact_and_batched(built, oracle, name):
                 ({"exact_accumulate": 1, "packet_primary": 0}, True), ({}, False),
                 ({"samples_per_batch": 4}, False), ({"samples_per_batch": 1, "overlap": 3}, False),
                 ({"samples_per_batch": 2, "overlap": 1, "traversal": 0}, False),
+                ({"exact_accumulate": 1, "traversal": 1}, True), ({"exact_accumulate": 1, "traversal": 2}, True),
+                ({"traversal": 1}, False), ({"traversal": 2, "samples_per_batch": 3}, False),
                 ({"exact_accumulate": 1, "shade_wave": 0}, True), ({"exact_accumulate": 1, "shade_wave_from": 0}, True),
                 ({"shade_wave": 0, "stage_lds": 0, "samples_per_batch": 3}, False), ({"shade_wave_from": 1, "samples_per_batch": 2}, False))
     for opts, exact in variants:
@@ -173,6 +175,38 @@ def test_row_blocks_merge_to_the_full_frame(built, oracle):
     e4 = np.zeros((H, W, 4), np.float32)
     e4[..., :3] = expect
     assert np.array_equal(fb, oracle.tonemap(e4, 1.0 / spp, 1.2).reshape(H, W, 4))
+
+
+def test_merge_from_a_tracer_on_another_gpu(built, oracle):
+    """The in-process multi-GPU path the Go renderer uses (renderer/default.go:188-191,
+    tracer/opencl/resources.go:108-124): the primary on device 0 merges the row block traced on
+    device 1 -- polaris_hip_merge's peer branch (xGMI peer access, or the staged hipMemcpyPeerAsync).
+    Needs two visible GPUs: skips itself on a one-GPU lease."""
+    from oracle import pybind as ob
+    from polaris_amd import ctypes_api as T
+    from polaris_amd import scenes
+
+    if T.load_library().polaris_hip_device_count() < 2:
+        pytest.skip("needs 2 HIP devices (the in-process peer merge cannot run on a 1-GPU lease)")
+    sc = scenes.SCENES["cornell"]()
+    W, H, spp, B = 64, 48, 3, 5
+    seeds = scenes.make_seeds(spp, B)
+    blocks = [(0, 29), (29, 19)]
+    trs = [make_hip_tracer(sc, W, H, device=d, exact_accumulate=1) for d in (0, 1)]
+    try:
+        expect = np.zeros((H, W, 3), np.float32)
+        for tr, (by, bh) in zip(trs, blocks):
+            req = ob.make_request(W, H, spp=spp, bounces=B, block_y=by, block_h=bh)
+            tr.Trace(req, seeds)
+            trs[0].MergeOutput(tr, ob.make_request(W, H, spp=spp, bounces=B, block_y=by, block_h=bh))
+            o, _, _ = oracle.trace(sc, ob.make_request(W, H, spp=spp, bounces=B, block_y=by, block_h=bh), seeds)
+            expect[by:by + bh] = o[by:by + bh, :, :3]
+        trs[0].SyncFramebuffer(ob.make_request(W, H, spp=spp, bounces=B))
+        frame = trs[0].read_accumulator(1)
+    finally:
+        for tr in trs:
+            tr.Close()
+    assert np.array_equal(bits(frame[..., :3]), bits(expect))
 
 
 def test_progressive_accumulation(built, oracle):
@@ -342,7 +376,8 @@ def test_big_scene_kernel_variants_agree_with_the_oracle(built, oracle, name):
     seeds = scenes.make_seeds(spp, B, base=21)
     want, wst, _ = oracle.trace(sc, req, seeds)
     assert wst.shaded_hits > 0
-    for opts in ({}, {"max_leaf_tris": 0}, {"max_leaf_tris": 1}, {"packet_primary": 0}, {"traversal": 0}, {"stage_lds": 0}):
+    for opts in ({}, {"max_leaf_tris": 0}, {"max_leaf_tris": 1}, {"packet_primary": 0}, {"traversal": 0}, {"traversal": 1}, {"traversal": 2},
+                 {"stage_lds": 0}):
         tr = make_hip_tracer(sc, W, H, exact_accumulate=1, **opts)
         try:
             tr.Trace(req, seeds)

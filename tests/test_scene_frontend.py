@@ -95,6 +95,14 @@ def test_ior_table():
     assert H.material_ior("air") == pytest.approx(1.0002926)
     assert H.material_ior("Mercury (liq)") == pytest.approx(1.62)
     assert H.material_ior("unobtainium") is None
+    # every name of the reference's table (asset/material/ior.go:12-257; data dumped by scripts/gen_ior_table.py)
+    import json
+    table = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ior_table.json")))
+    assert len(table) == 245
+    for name, ior in table.items():
+        assert H.material_ior(name) == np.float32(ior), name
+        assert H.material_ior(name.lower()) == np.float32(ior), name
+    assert H.material_ior("Zirconia, Cubic") == np.float32(2.170)
 
 
 # ---- reader: wavefront_test.go -------------------------------------------------------------------

@@ -215,3 +215,55 @@ def test_corrupted_scenes_are_rejected_not_followed(asan_harness, name, tmp_path
     assert "AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr, p.stderr[-3000:]
     accepted, rejected = (int(t.split("=")[1]) for t in p.stdout.split()[:2])
     assert rejected > 50 and accepted + rejected == 400
+
+
+def _layout_error(lib, sc, max_leaf=2):
+    hit = np.zeros((1, 6), np.int32)
+    cnt = np.zeros(7, np.uint64)
+    rays = np.zeros((1, 8), np.float32)
+    rays[0, 4] = 1.0
+    err = C.create_string_buffer(256)
+    view = T.scene_view(sc)
+    rc = lib.layout_check_traverse(C.byref(view), max_leaf, rays.ctypes.data, 1, 0, hit.ctypes.data, cnt.ctypes.data, err, 256)
+    return rc, err.value.decode()
+
+
+@pytest.mark.parametrize("depth", [6, 20, 60])
+def test_a_mesh_bvh_that_is_a_dag_is_rejected_at_once(harness, depth):
+    """A chain of inner nodes whose two children are the SAME next node passes every index check, but
+    every walk of it -- the upload's and the GPU traversal's -- costs 2^depth steps.  A node reached
+    twice inside one tree is rejected (and quickly: 60 levels used to hang the upload)."""
+    import time
+
+    sc = scenes.cornell_box()
+    nodes = sc.bvh_nodes.copy()
+    roots = sorted({int(r) for r in sc.mesh_instances["bvh_root"]})
+    root = roots[0]
+    assert nodes[root]["ldata"] > 0, "mesh root is an inner node"
+    first_new = len(nodes)
+    chain = np.zeros(depth, dtype=nodes.dtype)
+    for k in range(depth):
+        chain[k]["min"], chain[k]["max"] = nodes[root]["min"], nodes[root]["max"]
+        nxt = first_new + k + 1 if k + 1 < depth else int(nodes[root]["ldata"])
+        chain[k]["ldata"], chain[k]["rdata"] = nxt, nxt          # both children -> the same node
+    nodes = np.concatenate([nodes, chain])
+    nodes[root]["ldata"] = first_new                              # hang the chain under the mesh root
+    sc.bvh_nodes = nodes
+    t = time.perf_counter()
+    rc, msg = _layout_error(harness, sc)
+    assert rc != 0 and ("reachable twice" in msg or (depth > 32 and "too deep" in msg)), msg  # left-first: a chain deeper than the stack trips the depth limit first
+    assert time.perf_counter() - t < 5.0
+
+
+def test_texture_index_of_mix_and_disperse_nodes_is_range_checked(harness):
+    """scene_diffuse_mat_index / an emissive's material may point at ANY node, and the shading code
+    reads that node's texture: an operator node's unused `tex` must be -1 or a real texture."""
+    sc = scenes.cornell_box("layered")
+    ops = np.nonzero(sc.material_nodes["type"] == T.OP_MIX)[0]
+    assert len(ops) > 0
+    assert _layout_error(harness, sc)[0] == 0
+    mn = sc.material_nodes.copy()
+    mn[ops[0]]["tex"] = 12345
+    sc.material_nodes = mn
+    rc, msg = _layout_error(harness, sc)
+    assert rc != 0 and "texture out of range" in msg, msg
