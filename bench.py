@@ -173,6 +173,7 @@ def main() -> None:
     def finish_frame(ticket):
         parts = ex.wait(ticket)
         if rank == 0:
+            tr.reset_frame()                       # the Reset stage: this frame's blocks land on a cleared accumulator
             for y, h, t in parts:                  # ONE merge over the whole frame when the blocks are equally tall
                 tr.merge_device(t.data_ptr(), make_req(y, h))
             tr.SyncFramebuffer(make_req(0, H))     # default.go:159-161

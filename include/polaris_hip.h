@@ -120,6 +120,12 @@ int polaris_hip_merge(polaris_hip_tracer *dst, polaris_hip_tracer *src, const Po
 int polaris_hip_export_block(polaris_hip_tracer *h, const PolarisBlockRequest *req, void *device_dst);
 int polaris_hip_merge_device(polaris_hip_tracer *dst, const void *device_rows, const PolarisBlockRequest *req);
 
+/* The pipeline's Reset stage on its own (tracer/opencl/tracer.go:208-213: clearAccumulator(frameAccumulator)).
+ * Trace runs it whenever accumulated_samples == 0.  A host that merges a frame's blocks only after the NEXT
+ * frame's Trace has started (bench.py keeps the strip exchange one frame behind the tracing) calls it before
+ * merging, so that exactly one frame's blocks are ever summed.  Asynchronous on the handle's stream. */
+int polaris_hip_reset_frame(polaris_hip_tracer *h);
+
 /* Tracer.SyncFramebuffer: wait for pending merges, then tonemapSimpleReinhard over rows of
  * req with weight 1/(accumulated_samples+samples_per_pixel) into the RGBA8 frame buffer. */
 int polaris_hip_sync_framebuffer(polaris_hip_tracer *h, const PolarisBlockRequest *req);

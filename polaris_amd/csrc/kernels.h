@@ -257,12 +257,26 @@ __global__ __launch_bounds__(WG) void k_occlusion(Streams st, BvhDev B, float4 *
 //     and, whenever >= kRefillMin of a wave's lanes are idle, they are handed the next rays of the
 //     chunk (ballot/popcount ranks) -- the wave's tail is filled with new work instead of waiting
 //     for its longest ray.  Because the deal is static the grid must not exceed what the GPU holds at
-//     once (the host sizes it from the occupancy API);
+//     once (the host sizes it from the occupancy API).  A single global ticket counter was measured
+//     first: it saturates at ~88 dequeues/us (MI355X_MICROARCH.md, "dequeue"), a ~190 us floor under
+//     every launch of a 16 Ki-chunk batch;
 //   * "while-while" phases: all lanes first descend through inner nodes (lanes that already
 //     reached a leaf wait), then all lanes with a leaf test triangles.
-// The queue needs no co-residency: a wave exits when its workgroup's share of the chunks is used up.
 // Per-ray arithmetic is the same as traverse<> above (same slab test, same Moeller-Trumbore,
 // same tie rule), so results are bit-identical; only the schedule changes.
+//
+// The body is written branch-light (round 2).  PMC on the headline frame: the first version issued
+// 83 VALU + 39 SALU + 12 branch instructions per wave-iteration -- a third of it control flow the
+// structurizer made out of nested `if`s (exec save / restore, branches over empty halves):
+//   * the inner step is straight-line code under ONE exec mask: the far child is stored to the stack
+//     slot unconditionally (the slot is free), the pop value is read unconditionally, and child order /
+//     push / pop are selects;
+//   * everything rare leaves the inner loop as a negative node code and is handled once per round in
+//     the leaf phase: "ray finished" (kDone), "leaving the instance" (kExitMarker), instance leaves,
+//     leaves of more than 15 triangles;
+//   * Moeller-Trumbore runs without early exits (a lane's early exit saves the wave nothing): one
+//     predicate accumulates the rejections, the hit record is updated with selects.
+// -6 % (closest hit) / -13.5 % (any hit, which now also fits 7 waves per SIMD) kernel time.
 // ------------------------------------------------------------------------------------------
 #ifndef POLARIS_REFILL_MIN
 #define POLARIS_REFILL_MIN 40
@@ -291,25 +305,19 @@ __device__ __forceinline__ float slab_entry_hw(float4 lo, float4 hi, f3 o, f3 in
 	return (minmax < 0 || maxmin > minmax) ? kFltMax : (maxmin >= maxDist ? kFltMax : maxmin);
 }
 
-// Work distribution: chunks are dealt round-robin to the persistent workgroups (chunk c belongs
-// to workgroup c % gridDim.x) and the 4 waves of a workgroup share an LDS cursor.  A single global
-// ticket counter was measured first: it saturates at ~88 dequeues/us (MI355X_MICROARCH.md,
-// "dequeue"), a ~190 us floor under every launch of a 16 Ki-chunk batch.
+// The closest-hit kernel with the 16-entry stack is asked for 7 waves per SIMD (20 KB of LDS per workgroup: -2.4 % kernel
+// time on the Cornell box, -9 % on the sphere scene); the any-hit variant fits 7 by itself since the rewrite.
+// negative node codes that are not leaf references (a leaf code first << 4 | count never has all of bits 4..30 set)
+constexpr int kDone = (int)0x80000001;  // the ray has nothing pending: write its result
+constexpr int kIdle = (int)0x80000002;  // the lane holds no ray
+constexpr int kFirstLeafRef = (int)0x80000010;
 
-// The closest-hit kernel with the 16-entry stack is asked for 7 waves per SIMD: 71 VGPRs without a
-// spill, 20 KB of LDS per workgroup (-2.4 % kernel time on the Cornell box, -9 % on the sphere scene;
-// the any-hit kernel spills at that budget and stays at its natural 5).
 template <bool ANY_HIT, int STACK, bool LDS_TOP>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((!ANY_HIT && STACK == 16) ? 7 : 1, (!ANY_HIT && STACK == 16) ? 7 : 10)))
 void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned long long *stats) {
-	__shared__ int stk[STACK][WG]; // STACK = smallest of {16, 24, 32} that fits the scene: LDS per wave sets the occupancy
+	__shared__ int stk[STACK][WG];
 	__shared__ uint32_t wg_cursor;
 	if (threadIdx.x == 0) wg_cursor = 0;
-	// LDS_TOP (small scenes only): the first kLdsTopNodes PairNodes (breadth-first = the hot top of the
-	// tree) are staged in LDS.  The compiler turns the two-way fetch below into one FLAT load through a
-	// selected pointer; that is a win while a large share of the tree is in LDS (Cornell: -2 %) and a
-	// loss on big trees, where nearly every fetch is global and pays the FLAT path (-11 % / -18 % frame
-	// time on the 59 K / 1 M triangle scenes without it), so the host picks the variant by tree size.
 	__shared__ float4 top[LDS_TOP ? kLdsTopNodes * 4 : 1];
 	if (LDS_TOP) {
 		const uint32_t n4 = min((uint32_t)kLdsTopNodes, B.num_pairs) * 4;
@@ -324,70 +332,30 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 	const float4 *src_o = ANY_HIT ? st.occ_o : st.ray_o;
 	const float4 *src_d = ANY_HIT ? st.occ_d : st.ray_d;
 
-	// wave-uniform queue state
-	uint32_t chunk = 0, off = 0, cnt = 0;
+	uint32_t chunk = 0, off = 0, cnt = 0; // wave-uniform queue state
 	bool drained = false;
-	// per-lane ray state
-	bool has = false;
-	uint32_t slot = 0;
+	uint32_t slot = 0; // per-lane ray state
 	f3 o = {0, 0, 0}, d = {0, 0, 0}, inv = {0, 0, 0};
 	float maxDist = 0.0f;
-	int sp = 0, cur = -1, inst = 0, cell = 0;
+	int sp = 0, cur = kIdle, cell = 0;
 	uint32_t irank = 0, unocc = 0;
-	HitRec best;
-	best.t = 0; best.u = best.v = 0; best.tri = -1; best.inst = 0; best.irank = best.trank = 0;
+	float best_t = 0.0f, best_u = 0.0f, best_v = 0.0f;
+	int best_tri = -1;
+	uint32_t best_irank = 0, best_trank = 0;
 
-	auto finish = [&](bool occluded) {
-		if (ANY_HIT) {
-			if (!occluded) {
-				const float4 e = st.occ_e[slot];
-				float4 a = acc[cell]; // one path per cell and launch: plain read-modify-write
-				a.x += e.x; a.y += e.y; a.z += e.z;
-				acc[cell] = a;
-				unocc++;
-			}
-		} else {
-			st.hit[slot] = make_float4(best.u, best.v, best.t, ibits(best.tri));
-			if (st.hit_inst) st.hit_inst[slot] = best.inst;
-		}
-		has = false;
-		cur = -1;
-	};
+	// next pending node of the lane's ray: the popped reference, or kDone when nothing is pending -- an instance's exit
+	// marker with nothing above it ends the ray too (no need to restore the world-space ray first)
 	auto pop = [&]() {
-		for (;;) {
-			if (sp == 0) { finish(false); return; }
-			cur = stk[--sp][tid];
-			if (cur != kExitMarker) return;
-			if (sp == 0) { finish(false); return; } // nothing pending above the instance: no need to restore the ray
-			const float4 o4 = src_o[slot], d4 = src_d[slot]; // leaving the instance: back to the world-space ray
-			o = xyz(o4); d = xyz(d4);
-			inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)};
-		}
+		const int spm = sp > 0 ? sp - 1 : 0;
+		const int popped = stk[spm][tid];
+		cur = (sp == 0 || (popped == kExitMarker && spm == 0)) ? kDone : popped;
+		sp = spm;
 	};
 
-#ifdef POLARIS_TRACE_COUNTERS
-	uint32_t c_node = 0, c_leaf = 0, c_tri = 0, c_iter1 = 0, c_iter2 = 0, c_outer = 0, c_refill = 0, c_triiter = 0;
-#define TC(x) x
-#else
-#define TC(x)
-#endif
-#ifdef POLARIS_STAMPS
-	unsigned long long sk_refill = 0, sk_wait1 = 0, sk_comp1 = 0, sk_wait2 = 0, sk_comp2 = 0, sk_total = 0, sk_t = 0, sk_t0 = __builtin_amdgcn_s_memtime();
-#define STAMP_BEGIN() sk_t = __builtin_amdgcn_s_memtime()
-#define STAMP(acc) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - sk_t; sk_t = now_; }
-#define STAMP_WAIT() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
-#else
-#define STAMP_BEGIN()
-#define STAMP(acc)
-#define STAMP_WAIT()
-#endif
 	for (;;) {
-		TC(c_outer++;)
-		STAMP_BEGIN();
-		// ---- refill idle lanes ---------------------------------------------------------------
-		unsigned long long freem = __ballot(!has);
+		// ---- refill idle lanes from the workgroup's chunks -------------------------------------------
+		unsigned long long freem = __ballot(cur == kIdle);
 		if (!drained && (freem == ~0ull || __popcll(freem) >= (ANY_HIT ? kRefillMinAny : kRefillMin))) {
-			TC(c_refill++;)
 			for (;;) {
 				if (off >= cnt) {
 					uint32_t c = 0;
@@ -399,168 +367,166 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 					cnt = cnts[chunk];
 					continue;
 				}
-				freem = __ballot(!has);
+				freem = __ballot(cur == kIdle);
 				const uint32_t nfree = __popcll(freem);
 				if (nfree == 0) break;
 				const uint32_t take = min(cnt - off, nfree);
 				const uint32_t rank = __popcll(freem & below);
-				if (!has && rank < take) {
+				if (cur == kIdle && rank < take) {
 					slot = chunk * WG + off + rank;
 					const float4 o4 = src_o[slot], d4 = src_d[slot];
 					o = xyz(o4); d = xyz(d4);
 					maxDist = o4.w;
 					cell = fbits(d4.w);
-					inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)};
+					inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)}; // native_recip(ray.dir), intersect.cl:302
 					sp = 0;
 					cur = B.root_ref;
-					inst = 0; irank = 0;
-					best.t = maxDist; best.tri = -1; best.inst = 0; best.u = best.v = 0.0f; best.irank = best.trank = 0;
-					has = true;
+					irank = 0;
+					best_t = maxDist; best_tri = -1; best_u = best_v = 0.0f; best_irank = best_trank = 0;
 				}
 				off += take;
 			}
 		}
-		STAMP(sk_refill)
-		if (__ballot(has) == 0ull) {
+		if (__ballot(cur != kIdle) == 0ull) {
 			if (drained) break;
 			continue;
 		}
-		// ---- phase 1: descend through inner nodes -----------------------------------------------
-		// (the loop is left early once fewer than kStragglers lanes are still descending: they
-		// continue in the next round, packed together with the lanes that come back from their
-		// leaves, instead of dragging the whole wave through sparsely populated iterations)
+		// ---- phase 1: descend through inner nodes (intersect.cl:296-328) ---------------------------------
+		// left early once fewer than kStragglers lanes are still descending (they continue next round)
 		for (int it1 = 0;; it1++) {
-			const bool descending = has && cur >= 0;
+			const bool descending = cur >= 0;
 			const int nd = __popcll(__ballot(descending));
 			if (nd == 0 || (it1 > 0 && nd < (ANY_HIT ? kStragglersAny : kStragglers))) break;
-			STAMP(sk_comp1)
-			if (!descending) continue;
-			TC(c_node++; if (lane == __ffsll((long long)__ballot(true)) - 1) c_iter1++;)
-			PairNode P;
-			if (LDS_TOP && cur < kLdsTopNodes) { P.lo0 = top[4 * cur]; P.hi0 = top[4 * cur + 1]; P.lo1 = top[4 * cur + 2]; P.hi1 = top[4 * cur + 3]; }
-			else P = B.pairs[cur];
-#ifdef POLARIS_STAMPS
-			asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(P.lo0.x), "+v"(P.hi0.x), "+v"(P.lo1.x), "+v"(P.hi1.x) :: "memory");
-			STAMP(sk_wait1)
-#endif
-			float t0 = slab_entry_hw(P.lo0, P.hi0, o, inv, maxDist);
-			float t1 = slab_entry_hw(P.lo1, P.hi1, o, inv, maxDist);
-			if (!ANY_HIT) {
-				if (t0 > best.t * P.hi0.w) t0 = kFltMax;
-				if (t1 > best.t * P.hi1.w) t1 = kFltMax;
-			}
-			int c0 = fbits(P.lo0.w), c1 = fbits(P.lo1.w);
-			const bool h0 = t0 < kFltMax, h1 = t1 < kFltMax;
-			if (h0 && h1) {
-				// closest hit: nearer child first (that is what makes the distance cull bite); any hit: the order is
-				// irrelevant for the answer and sorting by entry distance is not worth its instructions (-4 %)
-				if (!ANY_HIT && t1 < t0) { int t = c0; c0 = c1; c1 = t; }
-				stk[sp++][tid] = c1;
-				cur = c0;
-			} else if (h0 || h1) {
-				cur = h0 ? c0 : c1;
-			} else {
-				pop();
+			if (descending) {
+				PairNode P;
+				if (LDS_TOP && cur < kLdsTopNodes) { P.lo0 = top[4 * cur]; P.hi0 = top[4 * cur + 1]; P.lo1 = top[4 * cur + 2]; P.hi1 = top[4 * cur + 3]; }
+				else P = B.pairs[cur];
+				float t0 = slab_entry_hw(P.lo0, P.hi0, o, inv, maxDist);
+				float t1 = slab_entry_hw(P.lo1, P.hi1, o, inv, maxDist);
+				// closest hit: cull subtrees that start beyond the best hit (+inf factor = box does not bound its subtree)
+				const bool h0 = t0 < kFltMax && (ANY_HIT || !(t0 > best_t * P.hi0.w));
+				const bool h1 = t1 < kFltMax && (ANY_HIT || !(t1 > best_t * P.hi1.w));
+				// nearer child first for closest hits (what makes the cull bite); stored order for shadow rays
+				const bool second_first = h1 && (!h0 || (!ANY_HIT && t1 < t0));
+				const int c0 = fbits(P.lo0.w), c1 = fbits(P.lo1.w);
+				const int nearc = second_first ? c1 : c0, farc = second_first ? c0 : c1;
+				stk[sp][tid] = farc; // kept only when both children are hit (sp advances); otherwise the slot stays free
+				const int spm = sp > 0 ? sp - 1 : 0;
+				const int popped = stk[spm][tid];
+				const bool both = h0 && h1, none = !(h0 || h1);
+				const int after_pop = (sp == 0 || (popped == kExitMarker && spm == 0)) ? kDone : popped;
+				cur = none ? after_pop : nearc;
+				sp = both ? sp + 1 : (none ? spm : sp);
 			}
 		}
-		STAMP(sk_comp1)
-		// ---- phase 2: leaves ---------------------------------------------------------------------
-		if (has && cur < 0) {
-			TC(c_leaf++; if (lane == __ffsll((long long)__ballot(true)) - 1) c_iter2++;)
-			const int2 li = leaf_of(B, cur);
-			if (li.y == 0) { // top-level leaf: enter the instance
-				inst = -li.x;
-				const InstRec I = B.insts[inst];
+		// ---- phase 2: everything that is not an inner node ------------------------------------------------
+		if (cur == kDone) { // the ray is finished
+			if (ANY_HIT) { // unoccluded: accumulateEmissiveSamples, pt_integrator.cl:278-296
+				const float4 e = st.occ_e[slot];
+				float4 a = acc[cell]; // one path per cell and launch: plain read-modify-write
+				a.x += e.x; a.y += e.y; a.z += e.z;
+				acc[cell] = a;
+				unocc++;
+			} else {
+				st.hit[slot] = make_float4(best_u, best_v, best_t, ibits(best_tri));
+			}
+			cur = kIdle;
+		}
+		if (cur == kExitMarker) { // leaving the instance: back to the world-space ray (intersect.cl:330-335)
+			const float4 o4 = src_o[slot], d4 = src_d[slot];
+			o = xyz(o4); d = xyz(d4);
+			inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)};
+			pop();
+		}
+		if (cur < 0 && cur >= kFirstLeafRef && (((uint32_t)~cur) & 15u) == 0u) { // leaf described by LeafInfo
+			const int2 li = B.leaves[((uint32_t)~cur) >> 4];
+			if (li.y == 0) { // top-level leaf: enter the mesh instance (intersect.cl:239-252)
+				const InstRec I = B.insts[-li.x];
 				irank = (uint32_t)I.meta.y;
 				stk[sp++][tid] = kExitMarker;
-				f3 no = {I.r0.x * o.x + I.r0.y * o.y + I.r0.z * o.z + I.r0.w, I.r1.x * o.x + I.r1.y * o.y + I.r1.z * o.z + I.r1.w,
-				         I.r2.x * o.x + I.r2.y * o.y + I.r2.z * o.z + I.r2.w};
-				f3 nd = {I.r0.x * d.x + I.r0.y * d.y + I.r0.z * d.z, I.r1.x * d.x + I.r1.y * d.y + I.r1.z * d.z,
-				         I.r2.x * d.x + I.r2.y * d.y + I.r2.z * d.z};
+				// mul4x1 / mul3x1, util/transform.cl:9-26
+				const f3 no = {I.r0.x * o.x + I.r0.y * o.y + I.r0.z * o.z + I.r0.w, I.r1.x * o.x + I.r1.y * o.y + I.r1.z * o.z + I.r1.w,
+				               I.r2.x * o.x + I.r2.y * o.y + I.r2.z * o.z + I.r2.w};
+				const f3 nd = {I.r0.x * d.x + I.r0.y * d.y + I.r0.z * d.z, I.r1.x * d.x + I.r1.y * d.y + I.r1.z * d.z,
+				               I.r2.x * d.x + I.r2.y * d.y + I.r2.z * d.z};
 				o = no; d = nd;
 				inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)};
 				cur = I.meta.x;
-			} else {
-				const int first = -li.x, end = first + li.y;
+			} else { // more than 15 triangles: re-filed as a run of inline leaves is not possible (count > 15): walk it here
 				bool occluded = false;
-				if constexpr (ANY_HIT) {
-					// shadow rays: Moeller-Trumbore without early exits (a lane's early exit saves the wave
-					// nothing), two triangles per round -- their six loads are in flight together and the round
-					// count halves: -10 % kernel time.  (For closest hits the same change costs 4 %: kept as it was.)
-					auto mt = [&](const TriRec &T, bool valid, float &tt, float &u, float &v) -> bool {
-						const f3 e1 = xyz(T.e1), e2 = xyz(T.e2);
-						const f3 pv = cross(d, e2);
-						const float det = dot(e1, pv);
-						bool ok = valid && !(pm_fabs(det) < kEps);
-						const float idet = pm_rcp(det);
-						const f3 tv = o - xyz(T.v0);
-						u = dot(tv, pv) * idet;
-						ok = ok && !(u < 0.0f || u > 1.0f);
-						const f3 qv = cross(tv, e1);
-						v = dot(d, qv) * idet;
-						ok = ok && !(v < 0.0f || u + v > 1.0f);
-						tt = dot(e2, qv) * idet;
-						return ok && tt > kEps;
-					};
-					for (int t = first; t < end && !occluded; t += 2) {
-						TC(c_tri += (t + 1 < end) ? 2 : 1; if (lane == __ffsll((long long)__ballot(true)) - 1) c_triiter++;)
-						const bool two = t + 1 < end;
-						const TriRec T0 = B.tris[t], T1 = B.tris[two ? t + 1 : t];
-						float tt0, u0, v0, tt1, u1, v1;
-						const bool h0 = mt(T0, true, tt0, u0, v0), h1 = mt(T1, two, tt1, u1, v1);
-						occluded = (h0 && tt0 < maxDist) || (h1 && tt1 < maxDist);
-					}
-				} else {
-					for (int t = first; t < end; t++) {
-						TC(c_tri++; if (lane == __ffsll((long long)__ballot(true)) - 1) c_triiter++;)
-						const TriRec T = B.tris[t];
-						f3 e1 = xyz(T.e1), e2 = xyz(T.e2);
-						f3 pv = cross(d, e2);
-						float det = dot(e1, pv);
-						if (pm_fabs(det) < kEps) continue;
-						float idet = pm_rcp(det);
-						f3 tv = o - xyz(T.v0);
-						float u = dot(tv, pv) * idet;
-						if (u < 0.0f || u > 1.0f) continue;
-						f3 qv = cross(tv, e1);
-						float v = dot(d, qv) * idet;
-						if (v < 0.0f || u + v > 1.0f) continue;
-						float tt = dot(e2, qv) * idet;
-						if (tt > kEps) {
-							const uint32_t trank = (uint32_t)fbits(T.v0.w);
-							const bool closer = tt < best.t;
-							const bool tie = tt == best.t && best.tri >= 0 && (irank < best.irank || (irank == best.irank && trank < best.trank));
-							if (closer || tie) { best.t = tt; best.u = u; best.v = v; best.tri = fbits(T.e1.w); best.inst = inst; best.irank = irank; best.trank = trank; }
-						}
+				for (int t = -li.x; t < -li.x + li.y && !occluded; t++) {
+					const TriRec T = B.tris[t];
+					const f3 e1 = xyz(T.e1), e2 = xyz(T.e2);
+					const f3 pv = cross(d, e2);
+					const float det = dot(e1, pv);
+					if (pm_fabs(det) < kEps) continue;
+					const float idet = pm_rcp(det);
+					const f3 tv = o - xyz(T.v0);
+					const float u = dot(tv, pv) * idet;
+					if (u < 0.0f || u > 1.0f) continue;
+					const f3 qv = cross(tv, e1);
+					const float v = dot(d, qv) * idet;
+					if (v < 0.0f || u + v > 1.0f) continue;
+					const float tt = dot(e2, qv) * idet;
+					if (ANY_HIT) {
+						if (tt > kEps && tt < maxDist) occluded = true;
+					} else if (tt > kEps) {
+						const uint32_t trank = (uint32_t)fbits(T.v0.w);
+						const bool closer = tt < best_t;
+						const bool tie = tt == best_t && best_tri >= 0 && (irank < best_irank || (irank == best_irank && trank < best_trank));
+						if (closer || tie) { best_t = tt; best_u = u; best_v = v; best_tri = fbits(T.e1.w); best_irank = irank; best_trank = trank; }
 					}
 				}
-				if (ANY_HIT && occluded) finish(true);
+				if (occluded) cur = kIdle; // shadow ray blocked: nothing to add
 				else pop();
 			}
 		}
-		STAMP(sk_comp2)
-	}
-#ifdef POLARIS_STAMPS
-	if (lane == 0) {
-		sk_total = __builtin_amdgcn_s_memtime() - sk_t0;
-		const unsigned long long v[6] = {sk_refill, sk_wait1, sk_comp1, sk_comp2, sk_total, 1ull};
-		for (int i = 0; i < 6; i++) atomicAdd(&stats[ST_DEBUG + (ANY_HIT ? 8 : 0) + i], v[i]);
-	}
-#endif
-#ifdef POLARIS_TRACE_COUNTERS
-	{
-		uint32_t v[8] = {c_node, c_leaf, c_tri, c_iter1, c_iter2, c_outer, c_refill, c_triiter};
-		for (int i = 0; i < 8; i++) {
-			uint32_t x = v[i];
-			if (i == 5 || i == 6) { if (lane != 0) x = 0; }
-			for (int s = 32; s > 0; s >>= 1) x += __shfl_xor(x, s);
-			if (lane == 0 && x) atomicAdd(&stats[ST_DEBUG + (ANY_HIT ? 8 : 0) + i], (unsigned long long)x);
+		// ---- inline leaves (1..15 triangles): Moeller-Trumbore, intersect.cl:255-292, without early exits ----
+		{
+			const bool tl = cur < 0 && cur >= kFirstLeafRef && (((uint32_t)~cur) & 15u) != 0u;
+			if (__ballot(tl) != 0ull) {
+				const uint32_t code = (uint32_t)~cur;
+				const uint32_t first = code >> 4, ntri = tl ? (code & 15u) : 0u;
+				bool occluded = false;
+				for (uint32_t i = 0; __ballot(i < ntri && !occluded) != 0ull; i++) {
+					if (i < ntri && !occluded) {
+						const TriRec T = B.tris[first + i];
+						const f3 e1 = xyz(T.e1), e2 = xyz(T.e2);
+						const f3 pv = cross(d, e2);
+						const float det = dot(e1, pv);
+						bool ok = !(pm_fabs(det) < kEps);
+						const float idet = pm_rcp(det);
+						const f3 tv = o - xyz(T.v0);
+						const float u = dot(tv, pv) * idet;
+						ok = ok && !(u < 0.0f || u > 1.0f);
+						const f3 qv = cross(tv, e1);
+						const float v = dot(d, qv) * idet;
+						ok = ok && !(v < 0.0f || u + v > 1.0f);
+						const float tt = dot(e2, qv) * idet;
+						ok = ok && tt > kEps;
+						if (ANY_HIT) {
+							occluded = ok && tt < maxDist;
+						} else {
+							const uint32_t trank = (uint32_t)fbits(T.v0.w);
+							const bool closer = tt < best_t;
+							const bool tie = tt == best_t && best_tri >= 0 && (irank < best_irank || (irank == best_irank && trank < best_trank));
+							const bool take = ok && (closer || tie);
+							best_t = take ? tt : best_t; best_u = take ? u : best_u; best_v = take ? v : best_v;
+							best_tri = take ? fbits(T.e1.w) : best_tri;
+							best_irank = take ? irank : best_irank; best_trank = take ? trank : best_trank;
+						}
+					}
+				}
+				if (tl) {
+					if (ANY_HIT && occluded) cur = kIdle; // blocked: nothing to add
+					else pop();
+				}
+			}
 		}
 	}
-#endif
 	if (ANY_HIT) {
-		// wave sum -> workgroup sum in LDS -> ONE global atomic per workgroup (contended atomics on a
-		// single address run at ~80/us; see k_shade)
+		// wave sum -> workgroup sum in LDS -> ONE global atomic per workgroup (contended atomics on a single address run
+		// at ~80/us; see k_shade)
 		uint32_t v = unocc;
 #pragma unroll
 		for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
@@ -572,6 +538,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 		if (threadIdx.x == 0 && wg_cursor) atomicAdd(&stats[ST_UNOCCLUDED], (unsigned long long)wg_cursor);
 	}
 }
+
 
 // ------------------------------------------------------------------------------------------
 // Wave-packet traversal for PRIMARY rays (the role of rayPacketIntersectionQuery,

@@ -20,10 +20,13 @@
 #include <vector>
 
 #include "kernels.h"
-#include "trace_pool.h"
 #include "polaris_hip.h"
 
 using namespace pol;
+
+#ifndef POLARIS_LDS_TOP_MAX_PAIRS
+#define POLARIS_LDS_TOP_MAX_PAIRS (8u * kLdsTopNodes)
+#endif
 
 namespace {
 
@@ -249,38 +252,17 @@ void launch_trace_v(polaris_hip_tracer *h, polaris_hip_tracer::Pipe &P, uint32_t
 
 template <bool ANY_HIT>
 void launch_trace(polaris_hip_tracer *h, polaris_hip_tracer::Pipe &P, uint32_t grid, uint32_t chunks, float4 *acc) {
+
 	// top of the tree in LDS only while that is a large share of the tree (kernels.h, k_trace)
-	if (h->bvh.num_pairs <= 8u * kLdsTopNodes) launch_trace_v<ANY_HIT, true>(h, P, grid, chunks, acc);
+	if (h->bvh.num_pairs <= (uint32_t)(POLARIS_LDS_TOP_MAX_PAIRS)) launch_trace_v<ANY_HIT, true>(h, P, grid, chunks, acc);
 	else launch_trace_v<ANY_HIT, false>(h, P, grid, chunks, acc);
-}
-
-#ifndef POLARIS_POOL_RAYS
-#define POLARIS_POOL_RAYS 128
-#endif
-constexpr int kPoolRays = POLARIS_POOL_RAYS;
-
-template <bool ANY_HIT>
-const void *pool_kernel(polaris_hip_tracer *h) {
-	if (h->max_stack <= 16) return (const void *)k_trace_pool<ANY_HIT, 16, kPoolRays>;
-	return nullptr; // deeper trees: k_trace
-}
-
-template <bool ANY_HIT>
-void launch_trace_pool(polaris_hip_tracer *h, polaris_hip_tracer::Pipe &P, uint32_t grid, uint32_t chunks, float4 *acc) {
-	hipLaunchKernelGGL((k_trace_pool<ANY_HIT, 16, kPoolRays>), dim3(grid), dim3(WG), 0, P.q, P.st, h->bvh, chunks, acc, h->d_stats);
 }
 
 // Resident workgroups per CU of the k_trace variant launch_trace<ANY_HIT> would pick.
 template <bool ANY_HIT>
 int trace_occupancy(polaris_hip_tracer *h) {
-	const bool lds_top = h->bvh.num_pairs <= 8u * kLdsTopNodes;
+	const bool lds_top = h->bvh.num_pairs <= (uint32_t)(POLARIS_LDS_TOP_MAX_PAIRS);
 	const void *fn;
-	if (h->opt_traversal == 2 && pool_kernel<ANY_HIT>(h)) {
-		int n = 0;
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pool_kernel<ANY_HIT>(h), WG, 0) != hipSuccess || n < 1) n = 1;
-		if (getenv("POLARIS_DEBUG")) fprintf(stderr, "[polaris] k_trace_pool<%d> resident workgroups per CU: %d\n", (int)ANY_HIT, n);
-		return std::min(n, 8);
-	}
 	if (h->max_stack <= 16) fn = lds_top ? (const void *)k_trace<ANY_HIT, 16, true> : (const void *)k_trace<ANY_HIT, 16, false>;
 	else if (h->max_stack <= 24) fn = lds_top ? (const void *)k_trace<ANY_HIT, 24, true> : (const void *)k_trace<ANY_HIT, 24, false>;
 	else fn = lds_top ? (const void *)k_trace<ANY_HIT, 32, true> : (const void *)k_trace<ANY_HIT, 32, false>;
@@ -330,8 +312,6 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 			Timed t(h, (b == 0 && h->packet_primary) ? "intersect_packet" : "intersect", q);
 			if (b == 0 && h->packet_primary)
 				hipLaunchKernelGGL(k_trace_packet<false>, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, (float4 *)nullptr, h->d_stats);
-			else if (h->opt_traversal == 2 && pool_kernel<false>(h))
-				launch_trace_pool<false>(h, P, persistent, wgs, nullptr);
 			else if (h->opt_traversal)
 				launch_trace<false>(h, P, persistent, wgs, nullptr);
 			else
@@ -358,8 +338,6 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 			Timed t(h, "occlusion", q);
 			if ((int)b < h->opt_packet_shadow)
 				hipLaunchKernelGGL(k_trace_packet<true>, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, A.acc, h->d_stats);
-			else if (h->opt_traversal == 2 && pool_kernel<true>(h))
-				launch_trace_pool<true>(h, P, persistent_occl, wgs, A.acc);
 			else if (h->opt_traversal)
 				launch_trace<true>(h, P, persistent_occl, wgs, A.acc);
 			else
@@ -571,10 +549,7 @@ int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value
 	else if (k == "packet_primary") { h->opt_packet_primary = value < 0 ? -1 : (value != 0); if (value >= 0) h->packet_primary = value != 0; }
 	else if (k == "packet_shadow") h->opt_packet_shadow = (int)std::max<int64_t>(0, std::min<int64_t>(value, POLARIS_MAX_BOUNCES));
 	else if (k == "time_kernels") h->opt_time_kernels = value != 0;
-	else if (k == "traversal") { // 0 = one ray per lane, 1 = persistent waves with lane refill, 2 = per-wave ray pool in LDS; re-sizes the persistent grids
-		h->opt_traversal = (int)std::max<int64_t>(0, std::min<int64_t>(value, 2));
-		if (h->have_scene) { h->trace_resident_per_cu = trace_occupancy<false>(h); h->occl_resident_per_cu = trace_occupancy<true>(h); }
-	}
+	else if (k == "traversal") h->opt_traversal = value != 0; // 0 = one ray per lane (k_intersect / k_occlusion), 1 = persistent waves with lane refill (k_trace)
 	else if (k == "shade_wave") h->opt_shade_wave = value != 0;
 	else if (k == "shade_wave_from") h->opt_shade_wave_from = (int)std::max<int64_t>(-1, std::min<int64_t>(value, POLARIS_MAX_BOUNCES));
 	else if (k == "shade_wgs_per_cu") h->opt_shade_wgs_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(value, 64));
@@ -682,18 +657,6 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 		float ms = 0.0f;
 		(void)hipEventElapsedTime(&ms, h->ev_start, h->ev_stop);
 		stats->device_ms = ms;
-#ifdef POLARIS_STAMPS
-		for (int a = 0; a < 2; a++) {
-			fprintf(stderr, "[stamps %s]", a ? "anyhit" : "closest");
-			for (int i = 0; i < 8; i++) fprintf(stderr, " %llu", hs[ST_DEBUG + 8 * a + i]);
-			fprintf(stderr, "\n");
-		}
-#endif
-#ifdef POLARIS_TRACE_COUNTERS
-		static const char *names[8] = {"node_tests", "leaf_visits", "tri_tests", "wave_iters_inner", "wave_iters_leaf", "wave_outer", "wave_refills", "wave_iters_tri"};
-		for (int a = 0; a < 2; a++)
-			for (int i = 0; i < 8; i++) fprintf(stderr, "[trace %s] %s = %llu\n", a ? "anyhit" : "closest", names[i], hs[ST_DEBUG + 8 * a + i]);
-#endif
 	}
 	return POLARIS_OK;
 }
@@ -762,6 +725,15 @@ int polaris_hip_merge_device(polaris_hip_tracer *dst, const void *device_rows, c
 	                   (uint32_t)n);
 	HIP_TRY(dst, hipGetLastError());
 	HIP_TRY(dst, hipStreamSynchronize(dst->stream)); // the caller owns device_rows: do not outlive it
+	return POLARIS_OK;
+}
+
+int polaris_hip_reset_frame(polaris_hip_tracer *h) {
+	if (!h) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "handle is null");
+	std::lock_guard<std::mutex> lk(h->mu);
+	if (h->W == 0 || h->H == 0) return fail(h, POLARIS_E_BAD_ARGUMENT, "frame dimensions not set (UpdateState FrameDimensions)");
+	HIP_TRY(h, hipSetDevice(h->device));
+	HIP_TRY(h, hipMemsetAsync(h->frame_acc, 0, (size_t)h->W * h->H * sizeof(float4), h->stream));
 	return POLARIS_OK;
 }
 

@@ -116,7 +116,7 @@ C_ABI_SYMBOLS = [
     "polaris_hip_set_option", "polaris_hip_trace", "polaris_hip_merge", "polaris_hip_export_block",
     "polaris_hip_merge_device", "polaris_hip_sync_framebuffer", "polaris_hip_read_framebuffer",
     "polaris_hip_read_accumulator", "polaris_hip_tap_primary", "polaris_hip_abi_version",
-    "polaris_hip_kernel_ms",
+    "polaris_hip_kernel_ms", "polaris_hip_reset_frame",
 ]
 
 _lib = None
@@ -150,6 +150,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.polaris_hip_merge.argtypes = [vp, vp, C.POINTER(BlockRequest)]
     lib.polaris_hip_export_block.argtypes = [vp, C.POINTER(BlockRequest), vp]
     lib.polaris_hip_merge_device.argtypes = [vp, vp, C.POINTER(BlockRequest)]
+    lib.polaris_hip_reset_frame.argtypes = [vp]
     lib.polaris_hip_sync_framebuffer.argtypes = [vp, C.POINTER(BlockRequest)]
     lib.polaris_hip_read_framebuffer.argtypes = [vp, vp, C.c_size_t]
     lib.polaris_hip_read_accumulator.argtypes = [vp, i32, vp, C.c_size_t]

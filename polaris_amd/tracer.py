@@ -167,6 +167,10 @@ class HipTracer:
     def export_block(self, req: T.BlockRequest, device_ptr: int) -> None:
         self._check(self._lib.polaris_hip_export_block(self._h, C.byref(req), C.c_void_p(device_ptr)), self._h)
 
+    def reset_frame(self) -> None:
+        """The pipeline's Reset stage on its own (tracer/opencl/tracer.go:208-213)."""
+        self._check(self._lib.polaris_hip_reset_frame(self._h), self._h)
+
     def merge_device(self, device_ptr: int, req: T.BlockRequest) -> None:
         self._check(self._lib.polaris_hip_merge_device(self._h, C.c_void_p(device_ptr), C.byref(req)), self._h)
 
