@@ -57,9 +57,10 @@ PM_HD float pm_floor(float x) { return __builtin_floorf(x); }    /* exact */
 /* OpenCL min/max(float,float): "y < x ? y : x" / "x < y ? y : x" (OpenCL 1.2 s6.12.4). */
 PM_HD float pm_min(float x, float y) { return y < x ? y : x; }
 PM_HD float pm_max(float x, float y) { return x < y ? y : x; }
-/* OpenCL fmin/fmax: NaN-ignoring (s6.12.2). */
-PM_HD float pm_fmin(float x, float y) { return (x < y || y != y) ? x : y; }
-PM_HD float pm_fmax(float x, float y) { return (x > y || y != y) ? x : y; }
+/* OpenCL fmin/fmax (s6.12.2): "returns y if y < x, otherwise x; if one argument is a NaN, returns the other" --
+ * written so that the zero of fmin(+0, -0) / fmax(-0, +0) is the one that text selects (x). */
+PM_HD float pm_fmin(float x, float y) { return (y < x || x != x) ? y : x; }
+PM_HD float pm_fmax(float x, float y) { return (x < y || x != x) ? y : x; }
 /* clamp(x,lo,hi) = min(max(x,lo),hi) (s6.12.4). */
 PM_HD float pm_clamp(float x, float lo, float hi) { return pm_min(pm_max(x, lo), hi); }
 PM_HD int32_t pm_clampi(int32_t x, int32_t lo, int32_t hi) { return x < lo ? lo : (x > hi ? hi : x); }
@@ -142,7 +143,7 @@ PM_HD float pm_atan2(float y, float x) {
 		return 0.0f;
 	}
 	float w = 0.0f;
-	if (x < 0.0f) w = (y < 0.0f) ? -PM_PI : PM_PI;
+	if (x < 0.0f) w = (pm_f2u(y) >> 31) ? -PM_PI : PM_PI; /* sign BIT of y: atan2(-0, x < 0) = -pi (OpenCL 1.2 s7.5.1) */
 	return w + pm_atan(y / x);
 }
 

@@ -2,6 +2,8 @@
 // (ctypes).  Scheduler entry points use mock tracers (speed + last-frame stats), exactly like
 // tracer/scheduler_test.go's mockTracer; renderer entry points need a GPU.
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <random>
 
 #include "material_expr.hpp"
@@ -38,6 +40,10 @@ struct RendererBox {
 	std::unique_ptr<renderer::DefaultRenderer> r;
 	std::string error;
 	std::mt19937 rng;
+	std::mutex rng_mu; // the workers draw concurrently, like the goroutines on Go's global math/rand (tracer.go:222)
+	// injected seed lists (tests): tracer i draws from lists[i] while it has entries, then from the shared generator
+	std::vector<std::deque<uint32_t>> lists;
+	std::vector<tracer::hip::HipTracer *> hips; // owned by the renderer
 };
 } // namespace
 
@@ -72,14 +78,28 @@ void *polaris_host_renderer_new(const int *device_indices, uint32_t n_tracers, u
                                 uint32_t spp, uint32_t bounces, uint32_t min_rr, float exposure, uint32_t seed, char err[256]) {
 	auto *box = new RendererBox();
 	box->rng.seed(seed);
-	auto src = [box]() { return (uint32_t)box->rng(); };
+	box->lists.resize(n_tracers);
+	auto src = [box]() {
+		std::lock_guard<std::mutex> lk(box->rng_mu);
+		return (uint32_t)box->rng();
+	};
 	auto devs = tracer::hip::Devices({});
 	std::vector<std::unique_ptr<tracer::Tracer>> trs;
 	for (uint32_t i = 0; i < n_tracers; i++) {
 		int di = device_indices[i];
 		if (di < 0 || (size_t)di >= devs.size()) { snprintf(err, 256, "device %d not available", di); delete box; return nullptr; }
-		auto t = std::make_unique<tracer::hip::HipTracer>("hip-" + std::to_string(i), devs[di], src);
+		auto tracer_src = [box, i]() { // this tracer's injected list first (only its own worker thread pops it)
+			std::lock_guard<std::mutex> lk(box->rng_mu);
+			if (!box->lists[i].empty()) {
+				const uint32_t v = box->lists[i].front();
+				box->lists[i].pop_front();
+				return v;
+			}
+			return (uint32_t)box->rng();
+		};
+		auto t = std::make_unique<tracer::hip::HipTracer>("hip-" + std::to_string(i), devs[di], tracer_src);
 		if (Error e = t->Init()) { snprintf(err, 256, "%s", e.msg.c_str()); delete box; return nullptr; }
+		box->hips.push_back(t.get());
 		trs.push_back(std::move(t));
 	}
 	renderer::Options o;
@@ -95,6 +115,22 @@ void *polaris_host_renderer_new(const int *device_indices, uint32_t n_tracers, u
 	if (!e) e = box->r->UpdateAll(tracer::ChangeType::CameraData, &cam);
 	if (e) { snprintf(err, 256, "%s", e.msg.c_str()); delete box; return nullptr; }
 	return box;
+}
+// Test hooks: the host PRNG draws of tracer `tracer_index` (tracer.go:222, pipeline.go:146) come from this list until it is
+// used up -- what lets a frame rendered by several tracers be compared with the oracle block by block; and a tracer option
+// (polaris_hip_set_option) applied to every tracer of the renderer.
+int polaris_host_renderer_push_seeds(void *h, uint32_t tracer_index, const uint32_t *seeds, size_t n) {
+	auto *box = static_cast<RendererBox *>(h);
+	if (tracer_index >= box->lists.size()) return POLARIS_E_BAD_ARGUMENT;
+	std::lock_guard<std::mutex> lk(box->rng_mu);
+	box->lists[tracer_index].insert(box->lists[tracer_index].end(), seeds, seeds + n);
+	return 0;
+}
+int polaris_host_renderer_set_option(void *h, const char *key, int64_t value) {
+	auto *box = static_cast<RendererBox *>(h);
+	for (auto *t : box->hips)
+		if (int rc = polaris_hip_set_option(t->Handle(), key, value)) { box->error = polaris_hip_last_error(t->Handle()); return rc; }
+	return 0;
 }
 int polaris_host_renderer_render(void *h, uint32_t accumulated, uint32_t *rows_out, double *frame_ms) {
 	auto *box = static_cast<RendererBox *>(h);

@@ -53,6 +53,15 @@ void DefaultRenderer::jobWorker(size_t trIndex) {
 			ch.q.pop_front();
 		}
 		Error err = tracers_[trIndex]->Trace(&blockReq);
+		{ // merges of this frame may start once the primary's Trace (and with it the Reset of the frame accumulator) is over
+			std::unique_lock<std::mutex> lk(frameMu_);
+			if (trIndex == primary_) {
+				primaryTraced_ = frame_;
+				frameCv_.notify_all();
+			} else {
+				frameCv_.wait(lk, [&] { return primaryTraced_ == frame_; });
+			}
+		}
 		// merge this block into the primary's frame accumulator -- called from THIS worker onto the
 		// primary, concurrently with the other workers (default.go:188-191)
 		if (!err) err = tracers_[primary_]->MergeOutput(tracers_[trIndex].get(), &blockReq);
@@ -82,6 +91,10 @@ Error DefaultRenderer::renderFrame(uint32_t accumulatedSamples) {
 	std::vector<tracer::Tracer *> raw;
 	for (auto &t : tracers_) raw.push_back(t.get());
 	blockAssignments_ = scheduler_->Schedule(raw, blockReq.frame_h);
+	{
+		std::lock_guard<std::mutex> lk(frameMu_);
+		frame_++;
+	}
 	for (size_t trIndex = 0; trIndex < blockAssignments_.size(); trIndex++) {
 		const uint32_t blockH = blockAssignments_[trIndex];
 		blockReq.block_h = blockH;

@@ -73,6 +73,13 @@ private:
 	std::mutex doneMu_;
 	std::condition_variable doneCv_;
 	std::deque<Error> done_;
+	// The primary's Trace clears its frame accumulator when it STARTS (the pipeline's Reset stage, tracer.go:208-213), while the
+	// other workers merge their blocks into that accumulator as they finish (default.go:188-191): a block that finished before the
+	// primary's worker got going would be wiped.  The reference has this race; here a worker's merge waits until the primary's
+	// Trace of the same frame has returned (the frame cannot complete earlier anyway).
+	std::mutex frameMu_;
+	std::condition_variable frameCv_;
+	uint64_t frame_ = 0, primaryTraced_ = 0;
 	std::vector<uint32_t> blockAssignments_;
 	FrameStats stats_;
 	bool closed_ = false;

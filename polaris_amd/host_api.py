@@ -31,6 +31,8 @@ def load() -> C.CDLL:
         lib.polaris_host_renderer_new.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(T.SceneView), vp, vp, C.c_uint32,
                                                   C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_char_p]
         lib.polaris_host_renderer_render.argtypes = [vp, C.c_uint32, vp, C.POINTER(C.c_double)]
+        lib.polaris_host_renderer_push_seeds.argtypes = [vp, C.c_uint32, vp, C.c_size_t]
+        lib.polaris_host_renderer_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
         lib.polaris_host_renderer_read.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t]
         lib.polaris_host_renderer_save.argtypes = [vp, C.c_char_p]
         lib.polaris_host_write_png.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
@@ -108,6 +110,17 @@ class Renderer:
                                                       fr.ctypes.data, width, height, spp, bounces, min_rr, exposure, seed, err)
         if not self._h:
             raise RuntimeError(f"renderer: {err.value.decode()}")
+
+    def push_seeds(self, tracer_index: int, seeds) -> None:
+        """Test hook: tracer `tracer_index` takes its next host PRNG draws (one per sample + one per bounce,
+        tracer.go:222, pipeline.go:146) from this list."""
+        s = np.ascontiguousarray(seeds, dtype=np.uint32)
+        if self._lib.polaris_host_renderer_push_seeds(self._h, tracer_index, s.ctypes.data, s.size):
+            raise RuntimeError("push_seeds: bad tracer index")
+
+    def set_option(self, key: str, value: int) -> None:
+        if self._lib.polaris_host_renderer_set_option(self._h, key.encode(), int(value)):
+            raise RuntimeError(f"set_option failed: {self._lib.polaris_host_renderer_error(self._h).decode()}")
 
     def render(self, accumulated=0):
         rows = np.zeros(self.n, dtype=np.uint32)

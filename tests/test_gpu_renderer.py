@@ -38,6 +38,50 @@ def test_three_tracers_one_gpu_naive(host):
     assert fb3[..., 3].min() == 255 and fb3[..., :3].max() > 0
 
 
+@pytest.mark.parametrize("scheduler", ["naive", "perfect"])
+def test_frame_loop_equals_the_oracle_block_by_block(host, oracle, scheduler):
+    """renderer/default.go:106-196 end to end against the oracle: three tracers (worker threads) trace the row blocks the
+    scheduler hands out, each from its own injected seed list, and merge concurrently into the primary; the primary's
+    frame accumulator must equal the oracle run block by block, BIT FOR BIT (exact_accumulate), and the RGBA8 frame its
+    tone-map.  Perfect scheduler: the second frame's blocks come from the first frame's times (scheduler.go:50-80) --
+    whatever rows it picks, the frame must still be the per-block oracle result."""
+    from conftest import bits
+    from oracle import pybind as ob
+    from polaris_amd import scenes
+
+    sc = scenes.SCENES["cornell"]()
+    W, H, spp, B = 72, 90, 3, 5
+    r = host.Renderer(sc, [0, 0, 0], primary=1, scheduler=host.PERFECT if scheduler == "perfect" else host.NAIVE, width=W, height=H, spp=spp, seed=9)
+    try:
+        r.set_option("exact_accumulate", 1)
+        for frame in range(6 if scheduler == "naive" else 3):  # several frames: the Reset / merge ordering must hold every time
+            lists = [scenes.make_seeds(spp, B, base=1000 * frame + 17 * t) for t in range(3)]
+            for t in range(3):
+                r.push_seeds(t, lists[t])
+            rows, _ = r.render()
+            fb, acc = r.read()
+            assert sum(rows) == H and min(rows) >= 1
+            if frame == 0 or scheduler == "naive":
+                assert rows == [30, 30, 30]       # first frame of the perfect scheduler = the naive split (scheduler.go:52-56)
+            expect = np.zeros((H, W, 4), np.float32)
+            y = 0
+            for t in range(3):
+                a, _, _ = oracle.trace(sc, ob.make_request(W, H, spp=spp, bounces=B, rr=3, block_y=y, block_h=rows[t]), lists[t])
+                expect[y:y + rows[t], :, :3] = a[y:y + rows[t], :, :3]
+                y += rows[t]
+            diff = bits(acc[..., :3]) != bits(expect[..., :3])
+            per_block, y = [], 0
+            for t in range(3):
+                per_block.append(int(diff[y:y + rows[t]].sum()))
+                y += rows[t]
+            assert not diff.any(), (scheduler, frame, rows, "differing words per block:", per_block,
+                                    "block means got/want:", [float(acc[30 * t:30 * t + 30, :, :3].mean()) for t in range(3)],
+                                    [float(expect[30 * t:30 * t + 30, :, :3].mean()) for t in range(3)])
+            assert np.array_equal(fb, oracle.tonemap(expect, 1.0 / spp, 1.2).reshape(H, W, 4))
+    finally:
+        r.close()
+
+
 def test_perfect_scheduler_feedback_and_progressive(host):
     from polaris_amd import scenes
 
