@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""scripts/configs.py -- the BASELINE.json configurations on ONE MI355X (run inside gpurun), one bench.py run each:
+Mrays/s and ms/frame into profiles/<round>_configs.json.  The frame sizes are BASELINE.json's; where the full sample
+count would take minutes (C4: 512 spp, C5: 1024 spp) a stated fraction of it is traced -- throughput per frame does
+not depend on the sample count once a batch is full (samples are traced K at a time).
+
+    python scripts/configs.py r02            # -> profiles/r02_configs.json
+"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONFIGS = [
+    ("C2", "sphere 512x512x128spp (configs[1])", ["--scene", "sphere"]),
+    ("headline", "layered Cornell box 512x512x128spp", []),
+    ("headline-refbvh", "the same frame, BVH from the restated reference compiler (leaves of <= 10 triangles)", ["--scene", "cornell-refbvh"]),
+    ("C3", "layered Cornell box 1024x1024x256spp (configs[2])", ["--width", "1024", "--height", "1024", "--spp", "256"]),
+    ("C4", "material-ball (58,682 tris; stand-in for the Mitsuba scene) 1920x1080x512spp (configs[3])",
+     ["--scene", "material-ball", "--width", "1920", "--height", "1080", "--spp", "512", "--steps", "2"]),
+    ("C5", "instanced (1,060-tri mesh x 1,024 instances = 1.09 M tris) 2048x2048, 16 of 1024 spp (configs[4])",
+     ["--scene", "instanced", "--width", "2048", "--height", "2048", "--spp", "16"]),
+    ("terrain", "terrain (1.0 M unique triangles: real HBM gathers) 1024x1024x32spp", ["--scene", "terrain", "--width", "1024", "--height", "1024", "--spp", "32"]),
+]
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "rXX"
+    out = {"command": "python bench.py --steps 3 --warmup 1 --no-cpu-baseline <args>", "configs": {}}
+    for key, what, args in CONFIGS:
+        base = ["--steps", "3", "--warmup", "1"]
+        if "--steps" in args:
+            base = ["--warmup", "1"]
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *base, "--no-cpu-baseline", *args], capture_output=True, text=True, cwd=ROOT)
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        if p.returncode != 0 or not line:
+            out["configs"][key] = {"what": what, "error": p.stderr[-400:]}
+            continue
+        d = json.loads(line[-1])
+        out["configs"][key] = {"what": what, "args": args, "Mrays_per_s": round(d["value"], 1), "ms_per_frame": round(d["ms_per_frame"], 2),
+                               "rays_per_frame": d["config"]["rays_per_frame"], "workload": d["config"]["workload"],
+                               "kernels_isolated_ms_per_frame": d.get("kernels_isolated_ms_per_frame"), "roofline": d.get("roofline")}
+        print(key, out["configs"][key]["Mrays_per_s"], "Mrays/s", out["configs"][key]["ms_per_frame"], "ms/frame", flush=True)
+    path = os.path.join(ROOT, "gpurun_out", f"{tag}_configs.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    json.dump(out, open(path, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

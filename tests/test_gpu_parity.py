@@ -331,6 +331,39 @@ def test_full_size_invariants(built):
     assert rmse(a + b, outs[0], spp) <= 1e-6
 
 
+@pytest.mark.parametrize("name,W,H,spp", [("cornell", 1024, 1024, 256),        # C3 at its full size: 268 M primary samples
+                                          ("material-ball", 1920, 1080, 6),  # C4's frame (of 512 spp)
+                                          ("instanced", 2048, 2048, 4)])     # C5's frame (of 1024 spp): 4.19 M pixels, 1.09 M instanced triangles
+def test_full_frame_sizes_of_the_other_configs(built, name, W, H, spp):
+    """BASELINE.json configs[2..4] at their FULL frame sizes (slot / pixel index arithmetic at up to 4.19 M pixels x K
+    samples per batch): run-to-run bit determinism, every ray counter independent of batch size and overlap depth, radiance
+    independent of them up to the association of the per-sample sums, finite and non-negative."""
+    from oracle import pybind as ob
+    from polaris_amd import scenes
+
+    sc = scenes.SCENES[name](W / H)
+    B = 5
+    seeds = scenes.make_seeds(spp, B)
+    outs, cnts = [], []
+    for opts in ({}, {}, {"samples_per_batch": max(1, spp // 3), "overlap": 2}, {"overlap": 1}):
+        tr = make_hip_tracer(sc, W, H, **opts)
+        try:
+            tr.Trace(ob.make_request(W, H, spp=spp, bounces=B, rr=3), seeds)
+            outs.append(tr.read_accumulator(0))
+            cnts.append(counters(tr.last_trace_stats, B))
+            if len(outs) == 1:
+                st = tr.last_trace_stats
+                assert st.primary_rays == W * H * spp and st.shaded_hits > 0 and st.occlusion_rays > 0
+        finally:
+            tr.Close()
+    assert np.array_equal(bits(outs[0]), bits(outs[1])), "two identical runs differ"
+    assert cnts[0] == cnts[1] == cnts[2] == cnts[3]
+    assert rmse(outs[0], outs[2], spp) <= 1e-6 and rmse(outs[0], outs[3], spp) <= 1e-6
+    assert np.isfinite(outs[0]).all() and (outs[0][..., :3] >= 0).all()
+    lit = outs[0][..., :3].reshape(H, -1, 3).mean(axis=(1, 2)) > 0   # rows that received radiance: the whole height is traced
+    assert lit[H // 2] and lit[: H // 4].any() and lit[-(H // 4):].any() and lit.mean() > 0.5
+
+
 @pytest.mark.parametrize("name", ["cornell", "sphere"])
 def test_headline_frame_against_the_oracle(built, oracle, name):
     """BASELINE.json's headline workload (and configs[1], the diffuse sphere) at FULL size -- layered Cornell box, 512x512, 128 spp, 5

@@ -117,21 +117,31 @@ def test_emissive_probes_bit_exact(oracle, ref_pm):
                 assert np.array_equal(bits(a), bits(b)), (name, e)
 
 
-def test_libm_build_agrees_statistically(oracle, built):
-    """Same reference code with glibc libm behind sin/cos/atan/acos/pow instead of
-    polaris_math.h: individual paths may flip, the image must agree statistically."""
+@pytest.mark.parametrize("name", SCENES)
+def test_libm_build_agrees_pixel_by_pixel(oracle, built, name):
+    """The same reference kernels with glibc's libm behind sin / cos / atan / atan2 / acos / pow / sqrt instead of
+    polaris_math.h -- the one place where a second, independent implementation of the built-ins meets the whole path.
+    Last-bit differences of the built-ins move a path by ~1e-7 (images agree to 1e-5 of the mean, pixel by pixel) unless
+    they flip a discrete decision (Fresnel choice, Russian roulette, mix-node selection, a hit at an edge): the layered
+    scenes may flip a fraction of their paths, which moves single pixels by ~1/spp but not the image."""
     from oracle import pybind as ob
     from polaris_amd import scenes
 
     if not ob.available("ref_libm"):
-        pytest.skip("compiled reference not built")
+        pytest.skip("compiled reference kernels not built (needs /root/reference)")
     lib = ob.Oracle("ref_libm")
-    sc = scenes.SCENES["cornell-diffuse"]()
-    W = H = 24
+    sc = scenes.SCENES[name]()
+    W = H = 32
     spp, B = 64, 5
     seeds = scenes.make_seeds(spp, B)
     a, sa, _ = lib.trace(sc, ob.make_request(W, H, spp=spp, bounces=B), seeds)
     b, sb, _ = oracle.trace(sc, ob.make_request(W, H, spp=spp, bounces=B), seeds)
-    ma, mb = a[..., :3].mean() / spp, b[..., :3].mean() / spp
-    assert abs(ma - mb) / mb < 0.02
-    assert abs(sa.total_rays() - sb.total_rays()) / sb.total_rays() < 0.01
+    a, b = a[..., :3] / spp, b[..., :3] / spp
+    mean = float(b.mean())
+    d = np.abs(a - b).max(axis=2)
+    assert abs(float(a.mean()) - mean) / mean < 0.005
+    assert abs(sa.total_rays() - sb.total_rays()) / sb.total_rays() < 0.002
+    flipped = float((d > 1e-5 * mean).mean())               # pixels in which at least one path took another branch
+    assert flipped <= (0.40 if name == "cornell" else 0.03), (name, flipped)
+    assert float(np.sqrt((d ** 2).mean())) / mean < 0.05    # per-pixel RMS deviation, relative to the image mean
+    assert float(d.max()) / mean < 1.0                       # no pixel moves by more than the image mean (a few paths of 64)
