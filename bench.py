@@ -293,6 +293,15 @@ def main() -> None:
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                                "algorithmic_bytes_per_launch": alg[dom] / max(n, 1), "avg_launch_ms": ms / max(n, 1), "launches": n,
                                "measured": "HIP events, one extra frame with overlap=1 after the timed region"}
+            # the same object for every traversal / shading kernel (the dominant one is repeated above as `roofline`)
+            per_kernel = {}
+            for k in ("generate", "intersect_packet", "intersect", "shade", "occlusion"):
+                kms, kn_ = iso[k]
+                if kms > 0 and kn_:
+                    ach = alg[k] / (kms * 1e-3) / 1e9
+                    per_kernel[k] = {"kernel": names[k], "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "avg_launch_ms": round(kms / kn_, 4),
+                                     "launches": kn_, "algorithmic_bytes_per_launch": round(alg[k] / kn_)}
+            out["roofline_per_kernel"] = per_kernel
             out["kernels_isolated_ms_per_frame"] = {k: round(v[0], 3) for k, v in iso.items()}
             out["kernels_isolated_GBps_algorithmic"] = {k: round(alg[k] / (iso[k][0] * 1e-3) / 1e9, 1) for k in alg if iso[k][0] > 0}
             whole = (112 * mine["primary_rays"] + 68 * mine["shaded_hits"] + 92 * mine["indirect_rays"] + 80 * mine["occlusion_rays"]
