@@ -24,6 +24,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "scene_layout.h"
 #include "shading.h"
 
@@ -312,19 +314,48 @@ constexpr int kDone = (int)0x80000001;  // the ray has nothing pending: write it
 constexpr int kIdle = (int)0x80000002;  // the lane holds no ray
 constexpr int kFirstLeafRef = (int)0x80000010;
 
-template <bool ANY_HIT, int STACK, bool LDS_TOP>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((!ANY_HIT && STACK == 16) ? 7 : 1, (!ANY_HIT && STACK == 16) ? 7 : 10)))
+// Where the node records and the stack live (template parameter NODES of k_trace), chosen by the host from the scene's size:
+//   kNodesGlobal  plain global_load (big trees: nearly every fetch misses an LDS copy and would pay the FLAT path)
+//   kNodesLdsTop  the first kLdsTopNodes records (breadth-first = the hot top of the tree) staged in LDS per workgroup; the
+//                 two-way fetch compiles to ONE flat_load through a selected pointer (small trees: -13 % kernel time)
+//   kNodesLdsAll  "tiny scene" mode (<= kTinyPairs pair records, < 2047 triangle slots and nodes, stack <= 16): the WHOLE tree
+//                 sits in LDS and is read with ds_read_b128 (no FLAT path, no L1 gathers for nodes).  What makes that fit at
+//                 full occupancy: workgroups of 1024 threads share ONE copy of the tree (32 KB) and the stack entries are
+//                 16-bit node codes (32 KB for 1024 lanes x 16 entries) -- 64 KB per workgroup, two workgroups = 8 waves per
+//                 SIMD.  (Round 1 tried the whole tree in LDS with 256-thread workgroups: 48 KB each, 3 per CU, +-0.)
+enum NodeMode { kNodesGlobal = 0, kNodesLdsTop = 1, kNodesLdsAll = 2 };
+constexpr int kTinyPairs = 512;
+constexpr int kTinyBlock = 1024;
+constexpr uint32_t kTinyMaxIndex = 2046; // triangle slots and node ids must fit the 11-bit field of a 16-bit stack entry (0x7FFF is the exit marker)
+
+// 16-bit stack entries of the tiny mode: inner node -> its index (bit 15 clear); leaf code first << 4 | count -> 0x8000 | code;
+// exit marker -> 0xFFFF
+__device__ __forceinline__ uint16_t ref_to16(int ref) {
+	return ref >= 0 ? (uint16_t)ref : (ref == kExitMarker ? (uint16_t)0xFFFFu : (uint16_t)(0x8000u | ((uint32_t)~ref & 0x7FFFu)));
+}
+__device__ __forceinline__ int ref_from16(uint16_t v) {
+	return (v & 0x8000u) ? (v == 0xFFFFu ? kExitMarker : ~(int)(v & 0x7FFFu)) : (int)v;
+}
+
+template <bool ANY_HIT, int STACK, int NODES>
+__global__ __launch_bounds__(NODES == kNodesLdsAll ? kTinyBlock : WG)
+__attribute__((amdgpu_waves_per_eu(NODES == kNodesLdsAll ? 8 : ((!ANY_HIT && STACK == 16) ? 7 : 1), NODES == kNodesLdsAll ? 8 : ((!ANY_HIT && STACK == 16) ? 7 : 10))))
 void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned long long *stats) {
-	__shared__ int stk[STACK][WG];
+	constexpr bool LDS_TOP = NODES == kNodesLdsTop, TINY = NODES == kNodesLdsAll;
+	constexpr int BLOCK = TINY ? kTinyBlock : WG; // threads per workgroup (a CHUNK of rays is always WG = 256 slots)
+	typedef typename std::conditional<TINY, uint16_t, int>::type StackEntry;
+	__shared__ StackEntry stk[STACK][BLOCK];
 	__shared__ uint32_t wg_cursor;
 	if (threadIdx.x == 0) wg_cursor = 0;
-	__shared__ float4 top[LDS_TOP ? kLdsTopNodes * 4 : 1];
-	if (LDS_TOP) {
-		const uint32_t n4 = min((uint32_t)kLdsTopNodes, B.num_pairs) * 4;
+	__shared__ float4 top[TINY ? kTinyPairs * 4 : (LDS_TOP ? kLdsTopNodes * 4 : 1)];
+	if (LDS_TOP || TINY) {
+		const uint32_t n4 = min((uint32_t)(TINY ? kTinyPairs : kLdsTopNodes), B.num_pairs) * 4;
 		const float4 *src = reinterpret_cast<const float4 *>(B.pairs);
-		for (uint32_t i = threadIdx.x; i < n4; i += WG) top[i] = src[i];
+		for (uint32_t i = threadIdx.x; i < n4; i += BLOCK) top[i] = src[i];
 	}
 	__syncthreads();
+	auto push_ref = [&](int at, int ref) { stk[at][threadIdx.x] = TINY ? (StackEntry)ref_to16(ref) : (StackEntry)ref; };
+	auto read_ref = [&](int at) -> int { return TINY ? ref_from16((uint16_t)stk[at][threadIdx.x]) : (int)stk[at][threadIdx.x]; };
 	const int tid = threadIdx.x;
 	const uint32_t lane = tid & 63;
 	const unsigned long long below = (1ull << lane) - 1ull;
@@ -347,7 +378,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 	// marker with nothing above it ends the ray too (no need to restore the world-space ray first)
 	auto pop = [&]() {
 		const int spm = sp > 0 ? sp - 1 : 0;
-		const int popped = stk[spm][tid];
+		const int popped = read_ref(spm);
 		cur = (sp == 0 || (popped == kExitMarker && spm == 0)) ? kDone : popped;
 		sp = spm;
 	};
@@ -393,13 +424,11 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 		}
 		// ---- phase 1: descend through inner nodes (intersect.cl:296-328) ---------------------------------
 		// left early once fewer than kStragglers lanes are still descending (they continue next round)
-		for (int it1 = 0;; it1++) {
-			const bool descending = cur >= 0;
-			const int nd = __popcll(__ballot(descending));
-			if (nd == 0 || (it1 > 0 && nd < (ANY_HIT ? kStragglersAny : kStragglers))) break;
-			if (descending) {
+		// (one step always if anybody descends, further steps while at least kStragglers lanes still do)
+		if (__ballot(cur >= 0) != 0ull) do {
+			if (cur >= 0) {
 				PairNode P;
-				if (LDS_TOP && cur < kLdsTopNodes) { P.lo0 = top[4 * cur]; P.hi0 = top[4 * cur + 1]; P.lo1 = top[4 * cur + 2]; P.hi1 = top[4 * cur + 3]; }
+				if (TINY || (LDS_TOP && cur < kLdsTopNodes)) { P.lo0 = top[4 * cur]; P.hi0 = top[4 * cur + 1]; P.lo1 = top[4 * cur + 2]; P.hi1 = top[4 * cur + 3]; }
 				else P = B.pairs[cur];
 				float t0 = slab_entry_hw(P.lo0, P.hi0, o, inv, maxDist);
 				float t1 = slab_entry_hw(P.lo1, P.hi1, o, inv, maxDist);
@@ -410,15 +439,15 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 				const bool second_first = h1 && (!h0 || (!ANY_HIT && t1 < t0));
 				const int c0 = fbits(P.lo0.w), c1 = fbits(P.lo1.w);
 				const int nearc = second_first ? c1 : c0, farc = second_first ? c0 : c1;
-				stk[sp][tid] = farc; // kept only when both children are hit (sp advances); otherwise the slot stays free
+				push_ref(sp, farc); // kept only when both children are hit (sp advances); otherwise the slot stays free
 				const int spm = sp > 0 ? sp - 1 : 0;
-				const int popped = stk[spm][tid];
+				const int popped = read_ref(spm);
 				const bool both = h0 && h1, none = !(h0 || h1);
 				const int after_pop = (sp == 0 || (popped == kExitMarker && spm == 0)) ? kDone : popped;
 				cur = none ? after_pop : nearc;
 				sp = both ? sp + 1 : (none ? spm : sp);
 			}
-		}
+		} while (__popcll(__ballot(cur >= 0)) >= (ANY_HIT ? kStragglersAny : kStragglers));
 		// ---- phase 2: everything that is not an inner node ------------------------------------------------
 		if (cur == kDone) { // the ray is finished
 			if (ANY_HIT) { // unoccluded: accumulateEmissiveSamples, pt_integrator.cl:278-296
@@ -443,7 +472,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 			if (li.y == 0) { // top-level leaf: enter the mesh instance (intersect.cl:239-252)
 				const InstRec I = B.insts[-li.x];
 				irank = (uint32_t)I.meta.y;
-				stk[sp++][tid] = kExitMarker;
+				push_ref(sp++, kExitMarker);
 				// mul4x1 / mul3x1, util/transform.cl:9-26
 				const f3 no = {I.r0.x * o.x + I.r0.y * o.y + I.r0.z * o.z + I.r0.w, I.r1.x * o.x + I.r1.y * o.y + I.r1.z * o.z + I.r1.w,
 				               I.r2.x * o.x + I.r2.y * o.y + I.r2.z * o.z + I.r2.w};

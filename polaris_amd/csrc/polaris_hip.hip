@@ -58,6 +58,8 @@ struct polaris_hip_tracer {
 	BvhDev bvh{};
 	SceneDev scene{};
 	int max_stack = 0;
+	int node_mode = kNodesGlobal; // where k_trace reads node records from (kernels.h NodeMode), resolved at upload
+	int opt_node_mode = -1;       // -1 = by scene size
 	int trace_resident_per_cu = 6, occl_resident_per_cu = 6; // workgroups of the selected k_trace<closest | any hit> variant a CU holds at once (occupancy API, at upload)
 
 	// camera (tracer.go:175-179)
@@ -239,36 +241,33 @@ int check_request(polaris_hip_tracer *h, const PolarisBlockRequest *r) {
 
 inline uint32_t grid_for(size_t n) { return (uint32_t)((n + WG - 1) / WG); }
 
-template <bool ANY_HIT, bool LDS_TOP>
-void launch_trace_v(polaris_hip_tracer *h, polaris_hip_tracer::Pipe &P, uint32_t grid, uint32_t chunks, float4 *acc) {
-	hipStream_t q = P.q;
-	if (h->max_stack <= 16)
-		hipLaunchKernelGGL((k_trace<ANY_HIT, 16, LDS_TOP>), dim3(grid), dim3(WG), 0, q, P.st, h->bvh, chunks, acc, h->d_stats);
-	else if (h->max_stack <= 24)
-		hipLaunchKernelGGL((k_trace<ANY_HIT, 24, LDS_TOP>), dim3(grid), dim3(WG), 0, q, P.st, h->bvh, chunks, acc, h->d_stats);
-	else
-		hipLaunchKernelGGL((k_trace<ANY_HIT, 32, LDS_TOP>), dim3(grid), dim3(WG), 0, q, P.st, h->bvh, chunks, acc, h->d_stats);
+// k_trace<ANY_HIT, STACK, NODES> of the uploaded scene: STACK from the exact depth the scene needs, NODES from its size
+// (kernels.h, NodeMode).  fn = the kernel (for the occupancy query), block = its workgroup size.
+template <bool ANY_HIT>
+const void *trace_kernel(polaris_hip_tracer *h, int *block) {
+	*block = h->node_mode == kNodesLdsAll ? kTinyBlock : WG;
+	if (h->node_mode == kNodesLdsAll) return (const void *)k_trace<ANY_HIT, 16, kNodesLdsAll>;
+	const bool top = h->node_mode == kNodesLdsTop;
+	if (h->max_stack <= 16) return top ? (const void *)k_trace<ANY_HIT, 16, kNodesLdsTop> : (const void *)k_trace<ANY_HIT, 16, kNodesGlobal>;
+	if (h->max_stack <= 24) return top ? (const void *)k_trace<ANY_HIT, 24, kNodesLdsTop> : (const void *)k_trace<ANY_HIT, 24, kNodesGlobal>;
+	return top ? (const void *)k_trace<ANY_HIT, 32, kNodesLdsTop> : (const void *)k_trace<ANY_HIT, 32, kNodesGlobal>;
 }
 
 template <bool ANY_HIT>
 void launch_trace(polaris_hip_tracer *h, polaris_hip_tracer::Pipe &P, uint32_t grid, uint32_t chunks, float4 *acc) {
-
-	// top of the tree in LDS only while that is a large share of the tree (kernels.h, k_trace)
-	if (h->bvh.num_pairs <= (uint32_t)(POLARIS_LDS_TOP_MAX_PAIRS)) launch_trace_v<ANY_HIT, true>(h, P, grid, chunks, acc);
-	else launch_trace_v<ANY_HIT, false>(h, P, grid, chunks, acc);
+	int block = WG;
+	const void *fn = trace_kernel<ANY_HIT>(h, &block);
+	void *args[] = {(void *)&P.st, (void *)&h->bvh, (void *)&chunks, (void *)&acc, (void *)&h->d_stats};
+	(void)hipLaunchKernel(fn, dim3(grid), dim3(block), args, 0, P.q);
 }
 
-// Resident workgroups per CU of the k_trace variant launch_trace<ANY_HIT> would pick.
+// Resident workgroups per CU of the k_trace variant launch_trace<ANY_HIT> picks.
 template <bool ANY_HIT>
 int trace_occupancy(polaris_hip_tracer *h) {
-	const bool lds_top = h->bvh.num_pairs <= (uint32_t)(POLARIS_LDS_TOP_MAX_PAIRS);
-	const void *fn;
-	if (h->max_stack <= 16) fn = lds_top ? (const void *)k_trace<ANY_HIT, 16, true> : (const void *)k_trace<ANY_HIT, 16, false>;
-	else if (h->max_stack <= 24) fn = lds_top ? (const void *)k_trace<ANY_HIT, 24, true> : (const void *)k_trace<ANY_HIT, 24, false>;
-	else fn = lds_top ? (const void *)k_trace<ANY_HIT, 32, true> : (const void *)k_trace<ANY_HIT, 32, false>;
-	int n = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, WG, 0) != hipSuccess || n < 1) n = h->max_stack <= 24 ? 6 : 5;
-	if (getenv("POLARIS_DEBUG")) fprintf(stderr, "[polaris] k_trace<%d> resident workgroups per CU: %d\n", (int)ANY_HIT, n);
+	int block = WG, n = 0;
+	const void *fn = trace_kernel<ANY_HIT>(h, &block);
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, block, 0) != hipSuccess || n < 1) n = h->node_mode == kNodesLdsAll ? 1 : (h->max_stack <= 24 ? 6 : 5);
+	if (getenv("POLARIS_DEBUG")) fprintf(stderr, "[polaris] k_trace<%d> node mode %d: %d resident workgroups of %d threads per CU\n", (int)ANY_HIT, h->node_mode, n, block);
 	return std::min(n, 8);
 }
 
@@ -520,6 +519,10 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 	                    sc->scene_diffuse_mat_index, sc->num_material_nodes, sc->num_textures};
 	h->max_stack = L.max_stack;
 	if (h->opt_packet_primary < 0) h->packet_primary = sc->num_triangles <= 262144u;
+	// node records: whole tree in LDS for tiny scenes, its top for small ones, global memory otherwise (kernels.h NodeMode)
+	const bool tiny_ok = L.pairs.size() <= (size_t)kTinyPairs && L.tris.size() <= kTinyMaxIndex && L.leaves.size() <= kTinyMaxIndex && L.max_stack <= 16;
+	h->node_mode = tiny_ok ? kNodesLdsAll : (L.pairs.size() <= (size_t)(POLARIS_LDS_TOP_MAX_PAIRS) ? kNodesLdsTop : kNodesGlobal);
+	if (h->opt_node_mode >= 0 && (h->opt_node_mode != kNodesLdsAll || tiny_ok)) h->node_mode = h->opt_node_mode;
 	h->trace_resident_per_cu = trace_occupancy<false>(h);
 	h->occl_resident_per_cu = trace_occupancy<true>(h);
 	h->have_scene = true;
@@ -549,6 +552,7 @@ int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value
 	else if (k == "packet_primary") { h->opt_packet_primary = value < 0 ? -1 : (value != 0); if (value >= 0) h->packet_primary = value != 0; }
 	else if (k == "packet_shadow") h->opt_packet_shadow = (int)std::max<int64_t>(0, std::min<int64_t>(value, POLARIS_MAX_BOUNCES));
 	else if (k == "time_kernels") h->opt_time_kernels = value != 0;
+	else if (k == "node_mode") h->opt_node_mode = (int)std::max<int64_t>(-1, std::min<int64_t>(value, 2)); // next upload; 2 only where the scene is tiny enough
 	else if (k == "traversal") h->opt_traversal = value != 0; // 0 = one ray per lane (k_intersect / k_occlusion), 1 = persistent waves with lane refill (k_trace)
 	else if (k == "shade_wave") h->opt_shade_wave = value != 0;
 	else if (k == "shade_wave_from") h->opt_shade_wave_from = (int)std::max<int64_t>(-1, std::min<int64_t>(value, POLARIS_MAX_BOUNCES));

@@ -70,6 +70,9 @@ def test_hip_vs_oracle_exact_and_batched(built, oracle, name):
                 ({"exact_accumulate": 1, "packet_primary": 0}, True), ({}, False),
                 ({"samples_per_batch": 4}, False), ({"samples_per_batch": 1, "overlap": 3}, False),
                 ({"samples_per_batch": 2, "overlap": 1, "traversal": 0}, False),
+                # where k_trace reads its node records: global memory / top of the tree in LDS / (tiny scenes) whole tree in LDS
+                ({"exact_accumulate": 1, "node_mode": 0}, True), ({"exact_accumulate": 1, "node_mode": 1}, True),
+                ({"exact_accumulate": 1, "node_mode": 2}, True), ({"node_mode": 1, "samples_per_batch": 3}, False),
                 ({"exact_accumulate": 1, "shade_wave": 0}, True), ({"exact_accumulate": 1, "shade_wave_from": 0}, True),
                 ({"shade_wave": 0, "stage_lds": 0, "samples_per_batch": 3}, False), ({"shade_wave_from": 1, "samples_per_batch": 2}, False))
     for opts, exact in variants:
@@ -407,7 +410,7 @@ def test_big_scene_kernel_variants_agree_with_the_oracle(built, oracle, name):
     seeds = scenes.make_seeds(spp, B, base=21)
     want, wst, _ = oracle.trace(sc, req, seeds)
     assert wst.shaded_hits > 0
-    for opts in ({}, {"max_leaf_tris": 0}, {"max_leaf_tris": 1}, {"packet_primary": 0}, {"traversal": 0}, {"stage_lds": 0}):
+    for opts in ({}, {"max_leaf_tris": 0}, {"max_leaf_tris": 1}, {"packet_primary": 0}, {"traversal": 0}, {"stage_lds": 0}, {"node_mode": 0}, {"node_mode": 2}):
         tr = make_hip_tracer(sc, W, H, exact_accumulate=1, **opts)
         try:
             tr.Trace(req, seeds)
