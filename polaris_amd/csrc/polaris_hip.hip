@@ -586,17 +586,13 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 	const bool exact = h->opt_exact != 0;
 	uint32_t K = 1;
 	if (!exact) {
-		// ~8 M paths per batch; split further so that every pipeline has a batch -- but not below ~4 M
-		// paths while that still leaves two batches to overlap: smaller batches do not fill the GPU and
-		// the launch chain of a batch (22 kernels) stops being hidden (measured on the row blocks of a
-		// 4- and 8-GPU frame: 2 batches of 4 M / 2 M beat 4 batches of 2 M / 1 M by 5 % / 8 %)
+		// Up to ~32 M paths per batch, but at least two batches so that one's sparse late bounces run beside the other's
+		// dense early ones.  Bigger batches amortise the tail of every persistent launch (a workgroup finishes the longest
+		// of its last rays alone) over more chunks -- measured on the round-2 kernels: headline frame 2 x 16.8 M paths
+		// 17.5 ms, 4 x 8.4 M 18.3 ms, 8 x 4.2 M 19.8 ms, 1 x 33.5 M 18.8 ms; 1024^2 x 256 spp: 33.5 M per batch 130.7 ms,
+		// 16.8 M 134.9 ms, 8.4 M 142.4 ms.  (128 B of stream buffers per path: 4.3 GB per batch in flight, of 288 GB.)
 		if (h->opt_samples_per_batch > 0) K = (uint32_t)std::min<int64_t>(h->opt_samples_per_batch, 4096);
-		else {
-			K = std::max<uint32_t>(1u, (uint32_t)((8u << 20) / Npad));
-			const uint32_t pipes = (uint32_t)std::max(1, h->opt_overlap);
-			const uint32_t k_min = std::min<uint32_t>((uint32_t)(((4u << 20) + Npad - 1) / Npad), std::max(1u, (spp + 1) / 2));
-			K = std::min(K, std::max(std::max(1u, k_min), (spp + pipes - 1) / pipes));
-		}
+		else K = std::min<uint32_t>(std::max<uint32_t>(1u, (uint32_t)((32u << 20) / Npad)), std::max(1u, (spp + 1) / 2));
 		K = std::max<uint32_t>(1u, std::min(K, std::max(spp, 1u)));
 	}
 	const uint32_t n_batches = spp ? (spp + K - 1) / K : 0;
