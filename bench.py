@@ -286,8 +286,8 @@ def main() -> None:
                         traffic_source = "profiles/" + os.path.basename(tpath) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 1`, " \
                             "collected on the builder's MI355X lease; not re-measured in this run)"
                         break
-            names = {"intersect": "k_trace<false,16> (closest hit, bounce rays)", "intersect_packet": "k_trace_packet<false> (camera rays)",
-                     "occlusion": "k_trace<true,16> (any hit + NEE accumulate)", "shade": "k_shade + k_shade_wave (shadeHits, miss shading, compaction)",
+            names = {"intersect": "k_trace<false,...> (closest hit, bounce rays)", "intersect_packet": "k_trace_packet<false> (camera rays)",
+                     "occlusion": "k_trace<true,...> (any hit + NEE accumulate)", "shade": "k_shade + k_shade_wave (shadeHits, miss shading, compaction)",
                      "generate": "k_generate"}
             out["roofline"] = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
