@@ -884,7 +884,7 @@ __device__ __forceinline__ SceneT<LDS> stage_scene(const SceneDev &Sg, ShadeLds 
 template <bool LDS>
 __global__ __launch_bounds__(WG) void k_shade(Streams st, SceneDev Sg, ShadeArgs A) {
 	__shared__ uint32_t wave_ind[4], wave_occ[4];
-	__shared__ uint32_t blk_stats[3];
+	__shared__ uint32_t wave_stat[4][3];
 	__shared__ ShadeLds lds;
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const uint32_t cnt = st.cnt_ray[blockIdx.x];
@@ -893,7 +893,6 @@ __global__ __launch_bounds__(WG) void k_shade(Streams st, SceneDev Sg, ShadeArgs
 		return;
 	}
 	const SceneT<LDS> S = stage_scene<LDS>(Sg, lds);
-	if (tid < 3) blk_stats[tid] = 0;
 	const uint32_t s = blockIdx.x / (A.Npad / WG);
 	const size_t base = (size_t)blockIdx.x * WG;
 	ShadeOut R;
@@ -908,14 +907,12 @@ __global__ __launch_bounds__(WG) void k_shade(Streams st, SceneDev Sg, ShadeArgs
 	const unsigned long long m_ind = __ballot(R.emit_ind), m_occ = __ballot(R.emit_occ);
 	const unsigned long long below = (1ull << lane) - 1ull;
 	const uint32_t r_ind = __popcll(m_ind & below), r_occ = __popcll(m_occ & below);
-	if (lane == 0) { wave_ind[wave] = __popcll(m_ind); wave_occ[wave] = __popcll(m_occ); }
 	const unsigned long long mh = __ballot(R.hit != 0), mm = __ballot(R.miss != 0), me = __ballot(R.emit != 0);
-	__syncthreads(); // also orders every lane's stream loads before any lane's in-place stores
 	if (lane == 0) {
-		if (mh) atomicAdd(&blk_stats[0], (uint32_t)__popcll(mh));
-		if (mm) atomicAdd(&blk_stats[1], (uint32_t)__popcll(mm));
-		if (me) atomicAdd(&blk_stats[2], (uint32_t)__popcll(me));
+		wave_ind[wave] = __popcll(m_ind); wave_occ[wave] = __popcll(m_occ);
+		wave_stat[wave][0] = __popcll(mh); wave_stat[wave][1] = __popcll(mm); wave_stat[wave][2] = __popcll(me);
 	}
+	__syncthreads(); // the ONE barrier after shading: it also orders every lane's stream loads before any lane's in-place stores
 	uint32_t b_ind = 0, b_occ = 0, tot_ind = 0, tot_occ = 0;
 #pragma unroll
 	for (int w = 0; w < 4; w++) {
@@ -930,13 +927,15 @@ __global__ __launch_bounds__(WG) void k_shade(Streams st, SceneDev Sg, ShadeArgs
 		const size_t d = base + b_occ + r_occ;
 		st.occ_o[d] = R.oo; st.occ_d[d] = R.od; st.occ_e[d] = R.oe;
 	}
-	__syncthreads();
 	if (tid == 0) {
 		st.cnt_ray[blockIdx.x] = tot_ind;
 		st.cnt_occ[blockIdx.x] = tot_occ;
 		// no global atomics here: 32 Ki workgroups adding to three shared counters serialise at the
 		// memory side (~80 atomics/us on one address); k_scan sums these words instead
-		st.wg_stat[blockIdx.x] = blk_stats[0] | (blk_stats[1] << 10) | (blk_stats[2] << 20);
+		uint32_t nh = 0, nm = 0, ne = 0;
+#pragma unroll
+		for (int w = 0; w < 4; w++) { nh += wave_stat[w][0]; nm += wave_stat[w][1]; ne += wave_stat[w][2]; }
+		st.wg_stat[blockIdx.x] = nh | (nm << 10) | (ne << 20);
 	}
 }
 
