@@ -430,6 +430,10 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 				PairNode P;
 				if (TINY || (LDS_TOP && cur < kLdsTopNodes)) { P.lo0 = top[4 * cur]; P.hi0 = top[4 * cur + 1]; P.lo1 = top[4 * cur + 2]; P.hi1 = top[4 * cur + 3]; }
 				else P = B.pairs[cur];
+				// what a pop would deliver: read NOW, beside the node record (slot sp - 1; the push below writes slot sp), so the
+				// stack's LDS round trip is off the step's dependent chain
+				const int spm = sp > 0 ? sp - 1 : 0;
+				const int popped = read_ref(spm);
 				float t0 = slab_entry_hw(P.lo0, P.hi0, o, inv, maxDist);
 				float t1 = slab_entry_hw(P.lo1, P.hi1, o, inv, maxDist);
 				// closest hit: cull subtrees that start beyond the best hit (+inf factor = box does not bound its subtree)
@@ -440,8 +444,6 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 				const int c0 = fbits(P.lo0.w), c1 = fbits(P.lo1.w);
 				const int nearc = second_first ? c1 : c0, farc = second_first ? c0 : c1;
 				push_ref(sp, farc); // kept only when both children are hit (sp advances); otherwise the slot stays free
-				const int spm = sp > 0 ? sp - 1 : 0;
-				const int popped = read_ref(spm);
 				const bool both = h0 && h1, none = !(h0 || h1);
 				const int after_pop = (sp == 0 || (popped == kExitMarker && spm == 0)) ? kDone : popped;
 				cur = none ? after_pop : nearc;
