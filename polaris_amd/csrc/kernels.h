@@ -50,6 +50,11 @@ struct BvhDev {
 	const TriRec *tris;
 	const InstRec *insts;
 	int root_ref;
+	// Single-instance scenes (the top-level tree is ONE instance leaf): that instance's record travels by value, i.e. in
+	// scalar registers, and k_trace enters it when it sets a ray up instead of chasing LeafInfo -> InstRec through two
+	// dependent global loads per ray.  root_is_instance = 0 otherwise.
+	int root_is_instance;
+	InstRec root_inst;
 };
 
 struct Streams {
@@ -373,6 +378,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 	float best_t = 0.0f, best_u = 0.0f, best_v = 0.0f;
 	int best_tri = -1;
 	uint32_t best_irank = 0, best_trank = 0;
+	f3 nee = {0, 0, 0}, acc_old = {0, 0, 0}; // any hit: the NEE radiance of the shadow ray and its accumulator cell, both fetched at set-up
 
 	// next pending node of the lane's ray: the popped reference, or kDone when nothing is pending -- an instance's exit
 	// marker with nothing above it ends the ray too (no need to restore the world-space ray first)
@@ -409,10 +415,28 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 					o = xyz(o4); d = xyz(d4);
 					maxDist = o4.w;
 					cell = fbits(d4.w);
-					inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)}; // native_recip(ray.dir), intersect.cl:302
+					if (ANY_HIT) {
+						// what an unoccluded ray adds, and the cell it adds to (one path per cell and launch: nobody else touches it):
+						// fetched here, beside the ray, so that finishing a ray is a store and not two dependent round trips
+						const float4 e4 = st.occ_e[slot], a4 = acc[cell];
+						nee = xyz(e4); acc_old = xyz(a4);
+					}
 					sp = 0;
 					cur = B.root_ref;
 					irank = 0;
+					if (B.root_is_instance) { // enter the scene's one instance right away (intersect.cl:239-252; mul4x1 / mul3x1, util/transform.cl:9-26)
+						const InstRec &I = B.root_inst;
+						const f3 no = {I.r0.x * o.x + I.r0.y * o.y + I.r0.z * o.z + I.r0.w, I.r1.x * o.x + I.r1.y * o.y + I.r1.z * o.z + I.r1.w,
+						               I.r2.x * o.x + I.r2.y * o.y + I.r2.z * o.z + I.r2.w};
+						const f3 nd = {I.r0.x * d.x + I.r0.y * d.y + I.r0.z * d.z, I.r1.x * d.x + I.r1.y * d.y + I.r1.z * d.z,
+						               I.r2.x * d.x + I.r2.y * d.y + I.r2.z * d.z};
+						o = no; d = nd;
+						irank = (uint32_t)I.meta.y;
+						push_ref(0, kExitMarker); // (nothing is ever pending below it: popping it ends the ray without a restore)
+						sp = 1;
+						cur = I.meta.x;
+					}
+					inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)}; // native_recip(ray.dir), intersect.cl:302
 					best_t = maxDist; best_tri = -1; best_u = best_v = 0.0f; best_irank = best_trank = 0;
 				}
 				off += take;
@@ -452,11 +476,9 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 		} while (__popcll(__ballot(cur >= 0)) >= (ANY_HIT ? kStragglersAny : kStragglers));
 		// ---- phase 2: everything that is not an inner node ------------------------------------------------
 		if (cur == kDone) { // the ray is finished
-			if (ANY_HIT) { // unoccluded: accumulateEmissiveSamples, pt_integrator.cl:278-296
-				const float4 e = st.occ_e[slot];
-				float4 a = acc[cell]; // one path per cell and launch: plain read-modify-write
-				a.x += e.x; a.y += e.y; a.z += e.z;
-				acc[cell] = a;
+			if (ANY_HIT) { // unoccluded: accumulateEmissiveSamples, pt_integrator.cl:278-296 (both operands were fetched at set-up)
+				float *c = reinterpret_cast<float *>(acc + cell);
+				c[0] = acc_old.x + nee.x; c[1] = acc_old.y + nee.y; c[2] = acc_old.z + nee.z;
 				unocc++;
 			} else {
 				st.hit[slot] = make_float4(best_u, best_v, best_t, ibits(best_tri));
@@ -518,6 +540,8 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 			if (__ballot(tl) != 0ull) {
 				const uint32_t code = (uint32_t)~cur;
 				const uint32_t first = code >> 4, ntri = tl ? (code & 15u) : 0u;
+				const int spm = sp > 0 ? sp - 1 : 0;
+				const int popped = read_ref(spm); // what follows the leaf: read beside the triangles, not after them
 				bool occluded = false;
 				for (uint32_t i = 0; __ballot(i < ntri && !occluded) != 0ull; i++) {
 					if (i < ntri && !occluded) {
@@ -550,7 +574,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 				}
 				if (tl) {
 					if (ANY_HIT && occluded) cur = kIdle; // blocked: nothing to add
-					else pop();
+					else { cur = (sp == 0 || (popped == kExitMarker && spm == 0)) ? kDone : popped; sp = spm; }
 				}
 			}
 		}

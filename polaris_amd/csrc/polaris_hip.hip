@@ -514,7 +514,18 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 	rc |= dev_upload(h, h->scene_bufs, &tex_data, sc->texture_data, sc->texture_data_bytes);
 	if (rc) { free_pool(h->scene_bufs); return rc; }
 	HIP_TRY(h, hipStreamSynchronize(h->stream)); // host vectors in L die at return
-	h->bvh = BvhDev{pairs, (uint32_t)L.pairs.size(), leaves, tris, insts, L.root_ref};
+	h->bvh = BvhDev{pairs, (uint32_t)L.pairs.size(), leaves, tris, insts, L.root_ref, 0, InstRec{}};
+	if (L.root_ref < 0 && (((uint32_t)~L.root_ref) & 15u) == 0u) { // the top-level tree is a single leaf ...
+		const LeafInfoH &li = L.leaves[((uint32_t)~L.root_ref) >> 4];
+		if (li.rdata == 0 && (size_t)(-(int64_t)li.ldata) < L.insts.size()) { // ... and that leaf is an instance: its record goes with the kernel arguments
+			const InstH &I = L.insts[(size_t)(-(int64_t)li.ldata)];
+			h->bvh.root_is_instance = 1;
+			h->bvh.root_inst.r0 = make_float4(I.r0[0], I.r0[1], I.r0[2], I.r0[3]);
+			h->bvh.root_inst.r1 = make_float4(I.r1[0], I.r1[1], I.r1[2], I.r1[3]);
+			h->bvh.root_inst.r2 = make_float4(I.r2[0], I.r2[1], I.r2[2], I.r2[3]);
+			h->bvh.root_inst.meta = make_int4(I.root_ref, (int)I.rank, 0, 0);
+		}
+	}
 	h->scene = SceneDev{vertices, normals, uvs, mat_index, nodes, emissives, tex_meta, tex_data, sc->num_emissives,
 	                    sc->scene_diffuse_mat_index, sc->num_material_nodes, sc->num_textures};
 	h->max_stack = L.max_stack;
