@@ -806,11 +806,12 @@ __device__ __forceinline__ void shade_ray(const SceneT<LDS> &S, const ShadeArgs 
 		sf.uv = {bw * ua.x + bu * ub.x + bv * uc.x, bw * ua.y + bu * ub.y + bv * uc.y};
 	}
 	f3 tint = splat(1.0f);
-	const MatT<LDS> m = select_material(S.mat_index[tri], sf, flags, tint, rng, S);
+	MatT<LDS> m = select_material(S.mat_index[tri], sf, flags, tint, rng, S);
+	material_params(sf, m, S);
 	const float in_dot_n = dot(in_dir, sf.n);
 	if (m.type == POLARIS_BXDF_EMISSIVE) { // pt_integrator.cl:101-107 (indexed by pixel: SURVEY 5.8)
 		if (in_dot_n > 0.0f) {
-			f3 add = thr * m.nd->scale * mat_color(sf.uv, m.nd->k, m.nd->tex, S);
+			f3 add = thr * m.nd->scale * m.kcol;
 			float4 a = A.acc[cell];
 			a.x += add.x; a.y += add.y; a.z += add.z;
 			A.acc[cell] = a;
@@ -886,6 +887,9 @@ struct ShadeLds {
 	float4 texmeta[kLdsTextures];
 };
 // Ends in a __syncthreads() in both variants (k_shade_wave relies on it to publish its cursor).
+// The three tables are at most 256 + 80 + 16 float4s: every thread issues its (up to) three loads back to back and stores
+// them afterwards -- one memory round trip in front of the barrier, not one per table.
+static_assert(kLdsMatNodes * 4 <= WG && kLdsLights * 5 <= WG && kLdsTextures <= WG, "stage_scene copies each table in one pass");
 template <bool LDS>
 __device__ __forceinline__ SceneT<LDS> stage_scene(const SceneDev &Sg, ShadeLds &L) {
 	SceneT<LDS> S;
@@ -893,9 +897,14 @@ __device__ __forceinline__ SceneT<LDS> stage_scene(const SceneDev &Sg, ShadeLds 
 	S.num_emissives = Sg.num_emissives; S.bg_node = Sg.bg_node; S.num_nodes = Sg.num_nodes; S.num_textures = Sg.num_textures;
 	if constexpr (LDS) { // the host launches this variant only when all three tables fit
 		const uint32_t tid = threadIdx.x;
-		for (uint32_t i = tid; i < Sg.num_nodes * 4; i += WG) L.nodes[i] = reinterpret_cast<const float4 *>(Sg.nodes)[i];
-		for (uint32_t i = tid; i < Sg.num_emissives * 5; i += WG) L.lights[i] = reinterpret_cast<const float4 *>(Sg.emissives)[i];
-		for (uint32_t i = tid; i < Sg.num_textures; i += WG) L.texmeta[i] = reinterpret_cast<const float4 *>(Sg.tex_meta)[i];
+		const bool has_n = tid < Sg.num_nodes * 4, has_l = tid < Sg.num_emissives * 5, has_t = tid < Sg.num_textures;
+		float4 vn = make_float4(0, 0, 0, 0), vl = vn, vt = vn;
+		if (has_n) vn = reinterpret_cast<const float4 *>(Sg.nodes)[tid];
+		if (has_l) vl = reinterpret_cast<const float4 *>(Sg.emissives)[tid];
+		if (has_t) vt = reinterpret_cast<const float4 *>(Sg.tex_meta)[tid];
+		if (has_n) L.nodes[tid] = vn;
+		if (has_l) L.lights[tid] = vl;
+		if (has_t) L.texmeta[tid] = vt;
 		S.nodes = (typename Tbl<true>::Node)(L.nodes);
 		S.emissives = (typename Tbl<true>::Light)(L.lights);
 		S.tex_meta = (typename Tbl<true>::TexMeta)(L.texmeta);
@@ -907,8 +916,10 @@ __device__ __forceinline__ SceneT<LDS> stage_scene(const SceneDev &Sg, ShadeLds 
 }
 
 // k_shade: one workgroup per chunk, one lane per live ray, stable in-place compaction through LDS.
+// Occupancy: shade_ray needs ~106 VGPRs unconstrained (4 waves per SIMD); the kernel waits on memory for most of a wave's
+// life, so it is built for 5 waves (96 VGPRs, 7 spilled dwords outside the hot path): -8 % kernel time.
 template <bool LDS>
-__global__ __launch_bounds__(WG) void k_shade(Streams st, SceneDev Sg, ShadeArgs A) {
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_shade(Streams st, SceneDev Sg, ShadeArgs A) {
 	__shared__ uint32_t wave_ind[4], wave_occ[4];
 	__shared__ uint32_t wave_stat[4][3];
 	__shared__ ShadeLds lds;

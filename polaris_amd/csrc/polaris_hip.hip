@@ -511,7 +511,9 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 	rc |= dev_upload(h, h->scene_bufs, &nodes, sc->material_nodes, sc->num_material_nodes);
 	rc |= dev_upload(h, h->scene_bufs, &emissives, sc->emissives, sc->num_emissives);
 	rc |= dev_upload(h, h->scene_bufs, &tex_meta, sc->texture_meta, sc->num_textures);
-	rc |= dev_upload(h, h->scene_bufs, &tex_data, sc->texture_data, sc->texture_data_bytes);
+	// the texture blob, padded: texels are fetched as the three dwords at their address whatever the format (shading.h, tex_fetch)
+	rc |= dev_alloc(h, h->scene_bufs, &tex_data, (size_t)sc->texture_data_bytes + 16);
+	if (!rc && sc->texture_data_bytes) HIP_TRY(h, hipMemcpyAsync(tex_data, sc->texture_data, sc->texture_data_bytes, hipMemcpyHostToDevice, h->stream));
 	if (rc) { free_pool(h->scene_bufs); return rc; }
 	HIP_TRY(h, hipStreamSynchronize(h->stream)); // host vectors in L die at return
 	h->bvh = BvhDev{pairs, (uint32_t)L.pairs.size(), leaves, tris, insts, L.root_ref, 0, InstRec{}};

@@ -89,8 +89,9 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out, in
 		const uint64_t bpp = m.format == POLARIS_TEX_L8 ? 1 : (m.format == POLARIS_TEX_RGBA32F ? 16 : 4);
 		if ((uint64_t)m.data_offset + bpp * m.width * m.height > sc.texture_data_bytes)
 			return "texture " + std::to_string(t) + ": data outside the texture blob";
-		if ((m.format == POLARIS_TEX_L32F || m.format == POLARIS_TEX_RGBA32F) && (m.data_offset & 3u))
-			return "texture " + std::to_string(t) + ": float data not dword aligned";
+		// texels are fetched as whole words (the reference reads them through uchar4 / float / float4 pointers, texture_sampler.cl:42-91)
+		if (m.format != POLARIS_TEX_L8 && (m.data_offset & 3u))
+			return "texture " + std::to_string(t) + ": texel data not dword aligned";
 	}
 	auto tex_ok = [&](int32_t t) { return t == -1 || (t >= 0 && (uint32_t)t < sc.num_textures); };
 	for (uint32_t i = 0; i < sc.num_material_nodes; i++) {

@@ -116,74 +116,72 @@ PD float schlick(float etaI, float etaT, float iDotN) { // fresnelForDielectric,
 }
 
 // ---- textures: samplers/texture_sampler.cl --------------------------------------------
-struct Texel4 { float x, y, z, w; };
-struct TexFetch {
-	const uint8_t *base;
-	uint32_t fmt, w, i00, i10, i01, i11; // element indices of TL, TR(bx,ty), BL(tx,by), BR
+// One copy of the address arithmetic (:15-38) and of the texel loads serves the three fetch flavours: a TexQuad holds the
+// four texels of the bilinear footprint as un-normalised floats.  All four texels are fetched by the SAME instruction
+// sequence whatever the format -- the three dwords at the texel's (dword-aligned) address, decoded afterwards -- so the
+// twelve loads are in flight together and a texture sample is ONE memory round trip; a `switch` on the format per texel
+// compiled to four serialised load -> wait -> convert steps.  (Luminance-8 texels sit at any byte: the aligned dword that
+// holds them is fetched and shifted.  The upload pads the blob so the two spare dwords of the last texel are readable,
+// and checks that the other formats are dword aligned.)  texGetSample1f (:114-184) is, operation for operation, the red
+// channel of texGetSample3f (:14-110), so scalar parameters read `.x` of the same routine.
+struct TexQuad {
+	f3 tl, tr, bl, br; // texels (tx,ty) (bx,ty) (tx,by) (bx,by); luminance formats: x only
 	float cx, cy;
+	bool rgba, bytes;
 };
-template <bool LDS> PD TexFetch tex_setup(f2 uv, int tex, const SceneT<LDS> &S) { // texture_sampler.cl:15-38 (shared prologue)
-	PolarisTextureMetadata m; // field by field: the record may live in LDS
-	m.format = S.tex_meta[tex].format; m.width = S.tex_meta[tex].width; m.height = S.tex_meta[tex].height; m.data_offset = S.tex_meta[tex].data_offset;
-	TexFetch t;
-	float sx = (uv.x - pm_floor(uv.x)) * (float)m.width;
-	float sy = (uv.y - pm_floor(uv.y)) * (float)m.height;
-	uint32_t tx = pm_clampu((uint32_t)sx, 0u, m.width - 1), ty = pm_clampu((uint32_t)sy, 0u, m.height - 1);
-	uint32_t bx = pm_clampu(tx + 1, 0u, m.width - 1), by = pm_clampu(ty + 1, 0u, m.height - 1);
-	t.cx = sx - (float)tx;
-	t.cy = sy - (float)ty;
-	t.base = S.tex_data + m.data_offset;
-	t.fmt = m.format;
-	t.w = m.width;
-	t.i00 = ty * m.width + tx; t.i10 = ty * m.width + bx; t.i01 = by * m.width + tx; t.i11 = by * m.width + bx;
-	return t;
+struct RawTexel { uint32_t w0, w1, w2, shift; };
+PD RawTexel texel_load(const uint8_t *blob, uint32_t byte_off) {
+	const uint32_t *p = reinterpret_cast<const uint32_t *>(blob + (byte_off & ~3u));
+	return {p[0], p[1], p[2], (byte_off & 3u) * 8u};
+}
+PD f3 texel_decode(const RawTexel &r, uint32_t fmt) {
+	const bool bytes = fmt == POLARIS_TEX_RGBA8 || fmt == POLARIS_TEX_L8, rgba8 = fmt == POLARIS_TEX_RGBA8;
+	const uint32_t b0 = (r.w0 >> r.shift) & 255u; // (shift is 0 for every format but L8)
+	return {bytes ? (float)b0 : __uint_as_float(r.w0), rgba8 ? (float)((r.w0 >> 8) & 255u) : __uint_as_float(r.w1),
+	        rgba8 ? (float)((r.w0 >> 16) & 255u) : __uint_as_float(r.w2)};
+}
+template <bool LDS> PD TexQuad tex_fetch(f2 uv, int tex, const SceneT<LDS> &S) { // texture_sampler.cl:15-38 (shared prologue) + the texel loads
+	const uint32_t fmt = S.tex_meta[tex].format, w = S.tex_meta[tex].width, h = S.tex_meta[tex].height; // field by field: the record may live in LDS
+	const uint32_t off = S.tex_meta[tex].data_offset;
+	const uint32_t stride = fmt == POLARIS_TEX_L8 ? 1u : (fmt == POLARIS_TEX_RGBA32F ? 16u : 4u);
+	TexQuad q;
+	const float sx = (uv.x - pm_floor(uv.x)) * (float)w;
+	const float sy = (uv.y - pm_floor(uv.y)) * (float)h;
+	const uint32_t tx = pm_clampu((uint32_t)sx, 0u, w - 1), ty = pm_clampu((uint32_t)sy, 0u, h - 1);
+	const uint32_t bx = pm_clampu(tx + 1, 0u, w - 1), by = pm_clampu(ty + 1, 0u, h - 1);
+	q.cx = sx - (float)tx;
+	q.cy = sy - (float)ty;
+	q.rgba = fmt == POLARIS_TEX_RGBA8 || fmt == POLARIS_TEX_RGBA32F;
+	q.bytes = fmt == POLARIS_TEX_RGBA8 || fmt == POLARIS_TEX_L8;
+	const RawTexel r0 = texel_load(S.tex_data, off + (ty * w + tx) * stride), r1 = texel_load(S.tex_data, off + (ty * w + bx) * stride);
+	const RawTexel r2 = texel_load(S.tex_data, off + (by * w + tx) * stride), r3 = texel_load(S.tex_data, off + (by * w + bx) * stride);
+	q.tl = texel_decode(r0, fmt); q.tr = texel_decode(r1, fmt); q.bl = texel_decode(r2, fmt); q.br = texel_decode(r3, fmt);
+	return q;
 }
 PD float bilerp(float tl, float tr, float bl, float br, float cx, float cy) {
 	return pm_mix(pm_mix(tl, bl, cy), pm_mix(tr, br, cy), cx);
 }
-PD float tex_chan(const TexFetch &t, uint32_t i, uint32_t c) { // one channel of texel i as float (un-normalised)
-	switch (t.fmt) {
-	case POLARIS_TEX_RGBA8: return (float)t.base[4 * i + c];
-	case POLARIS_TEX_RGBA32F: return ((const float *)t.base)[4 * i + c];
-	case POLARIS_TEX_L8: return (float)t.base[i];
-	default: return ((const float *)t.base)[i];
-	}
-}
-template <bool LDS> PD f3 tex_sample3(f2 uv, int tex, const SceneT<LDS> &S) { // texGetSample3f, texture_sampler.cl:14-110
-	TexFetch t = tex_setup(uv, tex, S);
-	if (t.fmt > POLARIS_TEX_RGBA32F) return splat(0.0f);
-	bool rgba = t.fmt == POLARIS_TEX_RGBA8 || t.fmt == POLARIS_TEX_RGBA32F;
-	bool bytes = t.fmt == POLARIS_TEX_RGBA8 || t.fmt == POLARIS_TEX_L8;
+PD f3 quad_sample3(const TexQuad &q) { // texGetSample3f, texture_sampler.cl:40-107; .x = texGetSample1f, :140-184
 	f3 r;
-	r.x = bilerp(tex_chan(t, t.i00, 0), tex_chan(t, t.i10, 0), tex_chan(t, t.i01, 0), tex_chan(t, t.i11, 0), t.cx, t.cy);
-	if (rgba) {
-		r.y = bilerp(tex_chan(t, t.i00, 1), tex_chan(t, t.i10, 1), tex_chan(t, t.i01, 1), tex_chan(t, t.i11, 1), t.cx, t.cy);
-		r.z = bilerp(tex_chan(t, t.i00, 2), tex_chan(t, t.i10, 2), tex_chan(t, t.i01, 2), tex_chan(t, t.i11, 2), t.cx, t.cy);
-		if (bytes) r = r / 255.0f;
+	r.x = bilerp(q.tl.x, q.tr.x, q.bl.x, q.br.x, q.cx, q.cy);
+	if (q.rgba) {
+		r.y = bilerp(q.tl.y, q.tr.y, q.bl.y, q.br.y, q.cx, q.cy);
+		r.z = bilerp(q.tl.z, q.tr.z, q.bl.z, q.br.z, q.cx, q.cy);
+		if (q.bytes) r = r / 255.0f;
 	} else {
-		if (bytes) r.x = r.x / 255.0f;
+		if (q.bytes) r.x = r.x / 255.0f;
 		r.y = r.z = r.x;
 	}
 	return r;
 }
-template <bool LDS> PD float tex_sample1(f2 uv, int tex, const SceneT<LDS> &S) { // texGetSample1f, texture_sampler.cl:114-184 (red channel)
-	TexFetch t = tex_setup(uv, tex, S);
-	if (t.fmt > POLARIS_TEX_RGBA32F) return 0.0f;
-	float r = bilerp(tex_chan(t, t.i00, 0), tex_chan(t, t.i10, 0), tex_chan(t, t.i01, 0), tex_chan(t, t.i11, 0), t.cx, t.cy);
-	return (t.fmt == POLARIS_TEX_RGBA8 || t.fmt == POLARIS_TEX_L8) ? r / 255.0f : r;
-}
-template <bool LDS> PD f3 tex_bump3(f2 uv, int tex, const SceneT<LDS> &S) { // texGetBumpSample3f, texture_sampler.cl:187-252
-	TexFetch t = tex_setup(uv, tex, S);
-	if (t.fmt > POLARIS_TEX_RGBA32F) return splat(0.0f);
-	float s0 = tex_chan(t, t.i00, 0), s1 = tex_chan(t, t.i10, 0), s2 = tex_chan(t, t.i01, 0);
-	if (t.fmt == POLARIS_TEX_RGBA8 || t.fmt == POLARIS_TEX_L8) { s0 = s0 / 255.0f; s1 = s1 / 255.0f; s2 = s2 / 255.0f; }
+PD f3 quad_bump3(const TexQuad &q) { // texGetBumpSample3f, texture_sampler.cl:187-252
+	float s0 = q.tl.x, s1 = q.tr.x, s2 = q.bl.x;
+	if (q.bytes) { s0 = s0 / 255.0f; s1 = s1 / 255.0f; s2 = s2 / 255.0f; }
 	return splat(0.5f) + 0.5f * normalize(mk3(s1 - s0, s2 - s0, 1.0f));
 }
+template <bool LDS> PD f3 tex_sample3(f2 uv, int tex, const SceneT<LDS> &S) { return quad_sample3(tex_fetch(uv, tex, S)); }
 template <bool LDS> PD f3 mat_color(f2 uv, typename Tbl<LDS>::F def, int tex, const SceneT<LDS> &S) { // matGetSample3f, material_sampler.cl:97-104
 	return tex == -1 ? mk3(def[0], def[1], def[2]) : tex_sample3(uv, tex, S);
-}
-template <bool LDS> PD float mat_scalar(f2 uv, float def, int tex, const SceneT<LDS> &S) { // matGetSample1f, material_sampler.cl:108-114
-	return tex == -1 ? def : tex_sample1(uv, tex, S);
 }
 
 // ---- surface + selected material -----------------------------------------------------
@@ -192,6 +190,12 @@ template <bool LDS> struct MatT {  // the leaf selected by the material-tree wal
 	typename Tbl<LDS>::Node nd;    // read in place
 	uint32_t type;
 	float int_ior, ext_ior;        // after the dispersion override (material_sampler.cl:92-94)
+	// The leaf's textured parameters.  Every BxDF entry point of the reference re-samples them (sample, pdf and eval of one
+	// shaded hit fetch the same reflectance up to three times); they are pure functions of (uv, node), so material_params()
+	// evaluates each ONCE per ray and the BxDF code below reads these:
+	f3 kcol;                       // matGetSample3f(uv, nd->k, nd->tex): reflectance | specularity | radiance
+	f3 tcol;                       // matGetSample3f(uv, nd->t, nd->right_child): transmittance (dielectrics)
+	float alpha;                   // the "Disney remapping" of the roughness, rough_conductor.cl:11-13 (rough BxDFs)
 };
 
 // matSelectNode, samplers/material_sampler.cl:21-95.  `flags` are the path's dispersion
@@ -204,21 +208,24 @@ template <bool LDS> PD MatT<LDS> select_material(uint32_t root, Surf &sf, uint32
 		if (type == POLARIS_MAT_OP_MIX) {
 			f2 s = rng_next(rng);
 			nd = S.nodes + (s.x < nd->k[0] ? nd->left_child : (uint32_t)nd->right_child);
-		} else if (type == POLARIS_MAT_OP_MIX_MAP) {
-			f2 s = rng_next(rng);
-			float w = tex_sample1(sf.uv, nd->tex, S);
-			nd = S.nodes + (s.x < w ? nd->left_child : (uint32_t)nd->right_child);
-		} else if (type == POLARIS_MAT_OP_BUMP_MAP || type == POLARIS_MAT_OP_NORMAL_MAP) {
-			f3 u, v;
-			tangent_frame(sf.n, u, v);
-			if (type == POLARIS_MAT_OP_BUMP_MAP) { // matGetBumpSample3f, :124-131
-				f3 s = (tex_bump3(sf.uv, nd->tex, S) * 2.0f) - splat(1.0f);
-				sf.n = normalize(u * s.x + v * s.y + sf.n * s.z);
-			} else {                                // matGetNormalSample3f, :111-121
-				f3 s = (tex_sample3(sf.uv, nd->tex, S) * 2.0f) - splat(1.0f);
-				sf.n = normalize(u * s.x + v * s.y + 0.5f * sf.n * s.z);
+		} else if (type == POLARIS_MAT_OP_MIX_MAP || type == POLARIS_MAT_OP_BUMP_MAP || type == POLARIS_MAT_OP_NORMAL_MAP) {
+			const TexQuad q = tex_fetch(sf.uv, nd->tex, S); // the one texel fetch of the walk
+			if (type == POLARIS_MAT_OP_MIX_MAP) {
+				f2 s = rng_next(rng);
+				float w = quad_sample3(q).x; // texGetSample1f
+				nd = S.nodes + (s.x < w ? nd->left_child : (uint32_t)nd->right_child);
+			} else {
+				f3 u, v;
+				tangent_frame(sf.n, u, v);
+				if (type == POLARIS_MAT_OP_BUMP_MAP) { // matGetBumpSample3f, :124-131
+					f3 s = (quad_bump3(q) * 2.0f) - splat(1.0f);
+					sf.n = normalize(u * s.x + v * s.y + sf.n * s.z);
+				} else {                                // matGetNormalSample3f, :111-121
+					f3 s = (quad_sample3(q) * 2.0f) - splat(1.0f);
+					sf.n = normalize(u * s.x + v * s.y + 0.5f * sf.n * s.z);
+				}
+				nd = S.nodes + nd->left_child;
 			}
-			nd = S.nodes + nd->left_child;
 		} else if (type == POLARIS_MAT_OP_DISPERSE) {
 			int ch;
 			if (flags & 1u) ch = 0;
@@ -234,12 +241,39 @@ template <bool LDS> PD MatT<LDS> select_material(uint32_t root, Surf &sf, uint32
 			forceExt = nd->t[ch];
 			nd = S.nodes + nd->left_child;
 		} else {
-			return {nd, POLARIS_BXDF_INVALID, 0.0f, 0.0f};
+			return {nd, POLARIS_BXDF_INVALID, 0.0f, 0.0f, splat(0.0f), splat(0.0f), 0.0f};
 		}
 		type = nd->type;
 	}
 	if (type >= POLARIS_MAT_OP_MIX) type = POLARIS_BXDF_INVALID; // malformed tree (cycle): reject instead of spinning
-	return {nd, type, pm_max(nd->int_ior, forceInt), pm_max(nd->ext_ior, forceExt)};
+	return {nd, type, pm_max(nd->int_ior, forceInt), pm_max(nd->ext_ior, forceExt), splat(0.0f), splat(0.0f), 0.0f};
+}
+
+// The selected leaf's parameters (see MatT).  Untextured parameters are the node's constants; the textured ones go through
+// ONE copy of the sampling code (a three-trip loop that is not unrolled: shade kernels whose code does not fit the
+// instruction cache pay for every inlined copy of the texel arithmetic).
+template <bool LDS> PD void material_params(const Surf &sf, MatT<LDS> &m, const SceneT<LDS> &S) {
+	const bool rough = (m.type & (POLARIS_BXDF_ROUGH_CONDUCTOR | POLARIS_BXDF_ROUGH_DIELECTRIC)) != 0;
+	const bool transmits = (m.type & (POLARIS_BXDF_DIELECTRIC | POLARIS_BXDF_ROUGH_DIELECTRIC)) != 0;
+	const bool valid = m.type != POLARIS_BXDF_INVALID;
+	m.kcol = mk3(m.nd->k[0], m.nd->k[1], m.nd->k[2]);
+	m.tcol = mk3(m.nd->t[0], m.nd->t[1], m.nd->t[2]);
+	float r = m.nd->scale;
+	const int tk = valid ? m.nd->tex : -1, tt = transmits ? m.nd->right_child : -1, tr = rough ? m.nd->roughness_tex : -1;
+	if (tk != -1 || tt != -1 || tr != -1) {
+#pragma clang loop unroll(disable)
+		for (int which = 0; which < 3; which++) {
+			const int tex = which == 0 ? tk : (which == 1 ? tt : tr);
+			if (tex != -1) {
+				const f3 v = tex_sample3(sf.uv, tex, S);
+				if (which == 0) m.kcol = v;
+				else if (which == 1) m.tcol = v;
+				else r = v.x; // matGetSample1f, material_sampler.cl:108-114
+			}
+		}
+	}
+	r = pm_clamp(r, kMinRoughness, 1.0f);
+	m.alpha = r * r;
 }
 
 // ---- distributions: samplers/distribution_sampler.cl ----------------------------------
@@ -290,10 +324,6 @@ PD f3 cosine_hemisphere(f3 n, f2 rnd) { // cosWeightedHemisphereGetSample, :101-
 }
 
 // ---- BxDFs: bxdf/*.cl ------------------------------------------------------------------
-template <bool LDS> PD float alpha_of(const Surf &sf, const MatT<LDS> &m, const SceneT<LDS> &S) { // "Disney remapping", rough_conductor.cl:11-13
-	float r = pm_clamp(mat_scalar(sf.uv, m.nd->scale, m.nd->roughness_tex, S), kMinRoughness, 1.0f);
-	return r * r;
-}
 PD f3 specular_tail(const Surf &sf, float a, f3 ks, float f, f3 i, f3 o, f3 h) { // eq. 20: rough_conductor.cl:27-39
 	float iDotN = dot(i, sf.n), oDotN = dot(o, sf.n);
 	float d = ggx_d(a, sf.n, h);
@@ -310,12 +340,12 @@ template <bool LDS> PD f3 transmit_tail(const Surf &sf, const MatT<LDS> &m, cons
 	float focus = pm_fabs(etaT * etaT * iDotH * oDotH / fd);
 	float d = ggx_d(a, sf.n, h);
 	float g = ggx_g(a, i, o, sf.n, h);
-	f3 tf = mat_color(sf.uv, m.nd->t, m.nd->right_child, S);
+	const f3 tf = m.tcol;
 	return tf * (1.0f - f) * d * g * focus;
 }
 template <bool LDS> PD f3 mirror_value(const Surf &sf, const MatT<LDS> &m, const SceneT<LDS> &S, float iDotN) { // conductor.cl:23-29
 	float f = m.int_ior != 0.0f ? schlick(m.ext_ior, m.int_ior, iDotN) : 1.0f;
-	f3 ks = mat_color(sf.uv, m.nd->k, m.nd->tex, S);
+	const f3 ks = m.kcol;
 	return iDotN != 0.0f ? f * ks / iDotN : splat(0.0f);
 }
 
@@ -326,7 +356,7 @@ template <bool LDS> PD f3 bxdf_sample(const Surf &sf, const MatT<LDS> &m, const 
 	case POLARIS_BXDF_DIFFUSE: { // diffuse.cl:12-20
 		o = cosine_hemisphere(n, rnd);
 		pdf = dot(n, o) * kInvPi;
-		return mat_color(sf.uv, m.nd->k, m.nd->tex, S) * kInvPi;
+		return m.kcol * kInvPi;
 	}
 	case POLARIS_BXDF_CONDUCTOR: { // conductor.cl:12-30
 		float iDotN = dot(i, n);
@@ -344,18 +374,18 @@ template <bool LDS> PD f3 bxdf_sample(const Surf &sf, const MatT<LDS> &m, const 
 		float cosTSq = 1.0f + eta * (iDotN * iDotN - 1.0f);
 		if (cosTSq <= 0.0f || rnd.x <= f) {
 			o = -pm_sign(iDotN) * 2.0f * iDotN * n - i;
-			kVal = mat_color(sf.uv, m.nd->k, m.nd->tex, S);
+			kVal = m.kcol;
 			pdf = cosTSq <= 0.0f ? 1.0f : f;
 		} else {
 			o = (eta * iDotN - pm_sign(iDotN) * pm_sqrt(cosTSq)) * n - eta * i;
-			kVal = eta * eta * mat_color(sf.uv, m.nd->t, m.nd->right_child, S);
+			kVal = eta * eta * m.tcol;
 			pdf = 1.0f - f;
 		}
 		return iDotN != 0.0f ? pdf * kVal / pm_fabs(iDotN) : splat(0.0f);
 	}
 	case POLARIS_BXDF_ROUGH_CONDUCTOR: { // rough_conductor.cl:10-40
-		float a = alpha_of(sf, m, S);
-		f3 ks = mat_color(sf.uv, m.nd->k, m.nd->tex, S);
+		float a = m.alpha;
+		const f3 ks = m.kcol;
 		f3 h = ggx_sample(a, n, rnd);
 		o = 2.0f * dot(i, h) * h - i;
 		pdf = ggx_reflect_pdf(a, o, n, h);
@@ -366,7 +396,7 @@ template <bool LDS> PD f3 bxdf_sample(const Surf &sf, const MatT<LDS> &m, const 
 	}
 	case POLARIS_BXDF_ROUGH_DIELECTRIC: { // rough_dielectric.cl:10-94
 		float iDotN = dot(i, n);
-		float a = alpha_of(sf, m, S);
+		float a = m.alpha;
 		float etaI = m.ext_ior, etaT = m.int_ior;
 		if (iDotN < 0.0f) { float t = etaI; etaI = etaT; etaT = t; }
 		float eta = etaI / etaT;
@@ -375,7 +405,7 @@ template <bool LDS> PD f3 bxdf_sample(const Surf &sf, const MatT<LDS> &m, const 
 		float cosTSq = 1.0f + eta * (iDotN * iDotN - 1.0f);
 		if (cosTSq <= 0.0f || rnd.x <= f) {
 			o = 2.0f * dot(i, h) * h - i;
-			f3 ks = mat_color(sf.uv, m.nd->k, m.nd->tex, S);
+			const f3 ks = m.kcol;
 			h = normalize(i + o);
 			pdf = cosTSq <= 0.0f ? 1.0f : ggx_reflect_pdf(a, o, n, h);
 			return specular_tail(sf, a, ks, f, i, o, h);
@@ -398,7 +428,7 @@ template <bool LDS> PD void bxdf_pdf_eval(const Surf &sf, const MatT<LDS> &m, co
 	switch (m.type) {
 	case POLARIS_BXDF_DIFFUSE: // diffuse.cl:24-32
 		pdf = dot(n, o) * kInvPi;
-		if (want_eval) val = mat_color(sf.uv, m.nd->k, m.nd->tex, S) * kInvPi;
+		if (want_eval) val = m.kcol * kInvPi;
 		return;
 	case POLARIS_BXDF_CONDUCTOR: { // conductor.cl:33-62
 		float iDotN = dot(i, n);
@@ -412,11 +442,11 @@ template <bool LDS> PD void bxdf_pdf_eval(const Surf &sf, const MatT<LDS> &m, co
 	case POLARIS_BXDF_DIELECTRIC: // dielectric.cl:49-60: always 0
 		return;
 	case POLARIS_BXDF_ROUGH_CONDUCTOR: { // rough_conductor.cl:43-78
-		float a = alpha_of(sf, m, S);
+		float a = m.alpha;
 		f3 h = normalize(i + o);
 		pdf = ggx_reflect_pdf(a, o, n, h);
 		if (want_eval) {
-			f3 ks = mat_color(sf.uv, m.nd->k, m.nd->tex, S);
+			const f3 ks = m.kcol;
 			float iDotN = dot(i, n);
 			float f = m.int_ior != 0.0f ? schlick(m.ext_ior, m.int_ior, iDotN) : 1.0f;
 			val = specular_tail(sf, a, ks, f, i, o, h);
@@ -425,7 +455,7 @@ template <bool LDS> PD void bxdf_pdf_eval(const Surf &sf, const MatT<LDS> &m, co
 	}
 	case POLARIS_BXDF_ROUGH_DIELECTRIC: { // rough_dielectric.cl:97-166
 		float iDotN = dot(i, n);
-		float a = alpha_of(sf, m, S);
+		float a = m.alpha;
 		float etaI = m.ext_ior, etaT = m.int_ior;
 		if (iDotN < 0.0f) { float t = etaI; etaI = etaT; etaT = t; }
 		if (iDotN > 0.0f) {
@@ -433,7 +463,7 @@ template <bool LDS> PD void bxdf_pdf_eval(const Surf &sf, const MatT<LDS> &m, co
 			pdf = ggx_reflect_pdf(a, o, n, h);
 			if (want_eval) {
 				float f = schlick(etaI, etaT, iDotN);
-				f3 ks = mat_color(sf.uv, m.nd->k, m.nd->tex, S);
+				const f3 ks = m.kcol;
 				val = specular_tail(sf, a, ks, f, i, o, h);
 			}
 		} else {
@@ -455,40 +485,47 @@ struct LightSample { f3 radiance, dir; float pdf, dist; };
 template <bool LDS> PD LightSample light_sample(const Surf &sf, typename Tbl<LDS>::Light em, const SceneT<LDS> &S, f2 rnd) { // emissiveGetSample, :176-198
 	LightSample L;
 	typename Tbl<LDS>::Node mn = S.nodes + em->mat_node_index;
-	if (em->type == POLARIS_EMISSIVE_ENVIRONMENT) { // :16-37
+	const uint32_t ltype = em->type;
+	if (ltype != POLARIS_EMISSIVE_ENVIRONMENT && ltype != POLARIS_EMISSIVE_AREA) return {splat(0.0f), splat(0.0f), 0.0f, 0.0f};
+	// both light types end in matGetSample3f(uv, mn->k, mn->tex) for a uv of their own: computed per type, sampled in one place
+	f2 luv;
+	f3 en = splat(0.0f);
+	float d2 = 0.0f;
+	if (ltype == POLARIS_EMISSIVE_ENVIRONMENT) { // :16-37
 		L.dir = cosine_hemisphere(sf.n, rnd);
 		L.pdf = pm_max(0.0f, dot(sf.n, L.dir)) * kInvPi;
 		L.dist = kFltMax;
-		f2 uv = latlong_uv(L.dir);
-		L.radiance = mn->scale * mat_color(uv, mn->k, mn->tex, S) * kInvPi;
-		return L;
+		luv = latlong_uv(L.dir);
+	} else { // area light, :51-113 (normal goes through the point transform: quirk a-9(4) kept)
+		float r1 = pm_sqrt(rnd.x);
+		float ru = (1.0f - rnd.y) * r1, rv = rnd.y * r1;
+		float w0 = 1.0f - ru - rv;
+		uint32_t off = em->tri_index * 3;
+		float4 a = S.vertices[off], b = S.vertices[off + 1], c = S.vertices[off + 2];
+		f3 p = mk3(w0 * a.x + ru * b.x + rv * c.x, w0 * a.y + ru * b.y + rv * c.y, w0 * a.z + ru * b.z + rv * c.z);
+		f3 ep = xform_point(p, em->transform);
+		a = S.normals[off]; b = S.normals[off + 1]; c = S.normals[off + 2];
+		f3 nn = mk3(w0 * a.x + ru * b.x + rv * c.x, w0 * a.y + ru * b.y + rv * c.y, w0 * a.z + ru * b.z + rv * c.z);
+		en = xform_point(nn, em->transform);
+		float2 ua = S.uvs[off], ub = S.uvs[off + 1], uc = S.uvs[off + 2];
+		luv = {w0 * ua.x + ru * ub.x + rv * uc.x, w0 * ua.y + ru * ub.y + rv * uc.y};
+		f3 er = ep - sf.p;
+		d2 = dot(er, er);
+		L.dir = normalize(er);
+		L.dist = pm_sqrt(d2);
 	}
-	if (em->type != POLARIS_EMISSIVE_AREA) return {splat(0.0f), splat(0.0f), 0.0f, 0.0f};
-	// area light, :51-113 (normal goes through the point transform: quirk a-9(4) kept)
-	float r1 = pm_sqrt(rnd.x);
-	float ru = (1.0f - rnd.y) * r1, rv = rnd.y * r1;
-	float w0 = 1.0f - ru - rv;
-	uint32_t off = em->tri_index * 3;
-	float4 a = S.vertices[off], b = S.vertices[off + 1], c = S.vertices[off + 2];
-	f3 p = mk3(w0 * a.x + ru * b.x + rv * c.x, w0 * a.y + ru * b.y + rv * c.y, w0 * a.z + ru * b.z + rv * c.z);
-	f3 ep = xform_point(p, em->transform);
-	a = S.normals[off]; b = S.normals[off + 1]; c = S.normals[off + 2];
-	f3 nn = mk3(w0 * a.x + ru * b.x + rv * c.x, w0 * a.y + ru * b.y + rv * c.y, w0 * a.z + ru * b.z + rv * c.z);
-	f3 en = xform_point(nn, em->transform);
-	float2 ua = S.uvs[off], ub = S.uvs[off + 1], uc = S.uvs[off + 2];
-	f2 euv = {w0 * ua.x + ru * ub.x + rv * uc.x, w0 * ua.y + ru * ub.y + rv * uc.y};
-	f3 er = ep - sf.p;
-	float d2 = dot(er, er);
-	L.dir = normalize(er);
-	L.dist = pm_sqrt(d2);
-	float nDotOut = dot(en, -L.dir);
-	if (nDotOut > 0.0f) {
-		L.pdf = 1.0f / em->area;
-		f3 ke = mat_color(euv, mn->k, mn->tex, S);
-		L.radiance = mn->scale * ke * nDotOut / d2;
+	const f3 ke = mat_color(luv, mn->k, mn->tex, S);
+	if (ltype == POLARIS_EMISSIVE_ENVIRONMENT) {
+		L.radiance = mn->scale * ke * kInvPi;
 	} else {
-		L.pdf = 0.0f;
-		L.radiance = splat(0.0f);
+		float nDotOut = dot(en, -L.dir);
+		if (nDotOut > 0.0f) {
+			L.pdf = 1.0f / em->area;
+			L.radiance = mn->scale * ke * nDotOut / d2;
+		} else {
+			L.pdf = 0.0f;
+			L.radiance = splat(0.0f);
+		}
 	}
 	return L;
 }
