@@ -836,11 +836,13 @@ __device__ __forceinline__ void shade_ray(const SceneT<LDS> &S, const ShadeArgs 
 	f3 e_dir = splat(0.0f), e_rad = splat(0.0f);
 	float e_pdf = 0.0f, sel_pdf = 0.0f, e_weight = 0.0f, e_dist = 0.0f;
 	typename Tbl<LDS>::Light em = nullptr;
+	uint32_t e_index = 0;
 	if (S.num_emissives > 0) {
 		sel_pdf = pm_rcp((float)(int)S.num_emissives); // emissiveSelect, emissive_sampler.cl:226-237
 		const int ei = pm_clampi((int)(sample1.x * (int)S.num_emissives), 0, (int)S.num_emissives - 1);
 		em = S.emissives + ei;
-		const LightSample L = light_sample(sf, em, S, sample1);
+		e_index = (uint32_t)ei;
+		const LightSample L = light_sample(sf, em, (uint32_t)ei, S, sample1);
 		e_dir = L.dir; e_rad = L.radiance; e_pdf = L.pdf; e_dist = L.dist;
 	}
 	const float n_dot_e = pm_max(0.0f, dot(sf.n, e_dir));
@@ -850,7 +852,7 @@ __device__ __forceinline__ void shade_ray(const SceneT<LDS> &S, const ShadeArgs 
 		f3 bxdf_e_val;
 		bxdf_pdf_eval(sf, m, S, in_dir, e_dir, want_nee, bxdf_e_pdf, bxdf_e_val);
 		e_weight = (e_pdf * e_pdf) / (e_pdf * e_pdf + bxdf_e_pdf * bxdf_e_pdf);       // POWER_HEURISTIC, :149
-		const float e_bxdf_pdf = light_pdf(sf, em, S, out_dir);
+		const float e_bxdf_pdf = light_pdf(sf, em, e_index, S, out_dir);
 		bxdf_weight = (bxdf_pdf * bxdf_pdf) / (bxdf_pdf * bxdf_pdf + e_bxdf_pdf * e_bxdf_pdf); // :154
 		if (want_nee) {
 			e_rad = e_rad * (e_weight * bxdf_e_val * thr * n_dot_e / (e_pdf * sel_pdf)); // :160
@@ -884,12 +886,13 @@ constexpr uint32_t kLdsMatNodes = 64, kLdsLights = 16, kLdsTextures = 16;
 struct ShadeLds {
 	float4 nodes[kLdsMatNodes * 4];
 	float4 lights[kLdsLights * 5];
+	float4 light_geo[kLdsLights * (kLightGeoFloats / 4)];
 	float4 texmeta[kLdsTextures];
 };
 // Ends in a __syncthreads() in both variants (k_shade_wave relies on it to publish its cursor).
 // The three tables are at most 256 + 80 + 16 float4s: every thread issues its (up to) three loads back to back and stores
 // them afterwards -- one memory round trip in front of the barrier, not one per table.
-static_assert(kLdsMatNodes * 4 <= WG && kLdsLights * 5 <= WG && kLdsTextures <= WG, "stage_scene copies each table in one pass");
+static_assert(kLdsMatNodes * 4 <= WG && kLdsLights * 5 <= WG && kLdsTextures <= WG && kLdsLights * (kLightGeoFloats / 4) <= WG, "stage_scene copies each table in one pass");
 template <bool LDS>
 __device__ __forceinline__ SceneT<LDS> stage_scene(const SceneDev &Sg, ShadeLds &L) {
 	SceneT<LDS> S;
@@ -898,18 +901,22 @@ __device__ __forceinline__ SceneT<LDS> stage_scene(const SceneDev &Sg, ShadeLds 
 	if constexpr (LDS) { // the host launches this variant only when all three tables fit
 		const uint32_t tid = threadIdx.x;
 		const bool has_n = tid < Sg.num_nodes * 4, has_l = tid < Sg.num_emissives * 5, has_t = tid < Sg.num_textures;
-		float4 vn = make_float4(0, 0, 0, 0), vl = vn, vt = vn;
+		const bool has_g = tid < Sg.num_emissives * (kLightGeoFloats / 4);
+		float4 vn = make_float4(0, 0, 0, 0), vl = vn, vt = vn, vg = vn;
 		if (has_n) vn = reinterpret_cast<const float4 *>(Sg.nodes)[tid];
 		if (has_l) vl = reinterpret_cast<const float4 *>(Sg.emissives)[tid];
 		if (has_t) vt = reinterpret_cast<const float4 *>(Sg.tex_meta)[tid];
+		if (has_g) vg = reinterpret_cast<const float4 *>(Sg.light_geo)[tid];
 		if (has_n) L.nodes[tid] = vn;
 		if (has_l) L.lights[tid] = vl;
 		if (has_t) L.texmeta[tid] = vt;
+		if (has_g) L.light_geo[tid] = vg;
+		S.light_geo = (typename Tbl<true>::F)(reinterpret_cast<float *>(L.light_geo));
 		S.nodes = (typename Tbl<true>::Node)(L.nodes);
 		S.emissives = (typename Tbl<true>::Light)(L.lights);
 		S.tex_meta = (typename Tbl<true>::TexMeta)(L.texmeta);
 	} else {
-		S.nodes = Sg.nodes; S.emissives = Sg.emissives; S.tex_meta = Sg.tex_meta;
+		S.nodes = Sg.nodes; S.emissives = Sg.emissives; S.tex_meta = Sg.tex_meta; S.light_geo = Sg.light_geo;
 	}
 	__syncthreads();
 	return S;
@@ -929,16 +936,18 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5, 5))) void
 		if (tid == 0) { st.cnt_occ[blockIdx.x] = 0; st.wg_stat[blockIdx.x] = 0; }
 		return;
 	}
+	// the lane's ray is requested before the tables are staged: both round trips are in flight together
+	const size_t base = (size_t)blockIdx.x * WG;
+	const size_t my = base + (tid < cnt ? tid : 0u); // (idle lanes re-read slot 0: no select behind the loads, so nothing waits for them here)
+	const float4 d4 = st.ray_d[my], t4 = st.thr[my], h4 = st.hit[my];
 	const SceneT<LDS> S = stage_scene<LDS>(Sg, lds);
 	const uint32_t s = blockIdx.x / (A.Npad / WG);
-	const size_t base = (size_t)blockIdx.x * WG;
 	ShadeOut R;
 	R.emit_ind = R.emit_occ = false;
 	R.hit = R.miss = R.emit = 0;
 	if (tid < cnt) {
-		const size_t slot = base + tid;
 		const uint32_t seed = A.seeds[(size_t)(A.first_sample + s) * A.seed_stride + 1 + A.bounce];
-		shade_ray(S, A, s, seed, st.pfx[blockIdx.x] + tid, st.ray_d[slot], st.thr[slot], st.hit[slot], R);
+		shade_ray(S, A, s, seed, st.pfx[blockIdx.x] + tid, d4, t4, h4, R);
 	}
 	// ---- stable in-place compaction of the two output streams -----------------------------
 	const unsigned long long m_ind = __ballot(R.emit_ind), m_occ = __ballot(R.emit_occ);

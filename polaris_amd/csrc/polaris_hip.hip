@@ -502,7 +502,18 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 	rc |= dev_upload(h, h->scene_bufs, &tris, L.tris.data(), L.tris.size());
 	rc |= dev_upload(h, h->scene_bufs, &insts, L.insts.data(), L.insts.size());
 	float4 *vertices, *normals; float2 *uvs; uint32_t *mat_index;
-	PolarisMaterialNode *nodes; PolarisEmissive *emissives; PolarisTextureMetadata *tex_meta; uint8_t *tex_data;
+	PolarisMaterialNode *nodes; PolarisEmissive *emissives; PolarisTextureMetadata *tex_meta; uint8_t *tex_data; float *light_geo;
+	// the triangle of every area light, packed (shading.h, SceneT::light_geo; indices were range-checked by build_layout)
+	std::vector<float> geo((size_t)sc->num_emissives * kLightGeoFloats, 0.0f);
+	for (uint32_t e = 0; e < sc->num_emissives; e++) {
+		if (sc->emissives[e].type != POLARIS_EMISSIVE_AREA) continue;
+		const size_t off = (size_t)sc->emissives[e].tri_index * 3;
+		float *g = geo.data() + (size_t)e * kLightGeoFloats;
+		for (int v = 0; v < 3; v++) {
+			for (int k = 0; k < 3; k++) { g[4 * v + k] = sc->vertices[4 * (off + v) + k]; g[12 + 4 * v + k] = sc->normals[4 * (off + v) + k]; }
+			g[24 + 2 * v] = sc->uvs[2 * (off + v)]; g[25 + 2 * v] = sc->uvs[2 * (off + v) + 1];
+		}
+	}
 	const size_t nv = (size_t)sc->num_triangles * 3;
 	rc |= dev_upload(h, h->scene_bufs, &vertices, sc->vertices, nv);
 	rc |= dev_upload(h, h->scene_bufs, &normals, sc->normals, nv);
@@ -511,6 +522,7 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 	rc |= dev_upload(h, h->scene_bufs, &nodes, sc->material_nodes, sc->num_material_nodes);
 	rc |= dev_upload(h, h->scene_bufs, &emissives, sc->emissives, sc->num_emissives);
 	rc |= dev_upload(h, h->scene_bufs, &tex_meta, sc->texture_meta, sc->num_textures);
+	rc |= dev_upload(h, h->scene_bufs, &light_geo, geo.data(), geo.size());
 	// the texture blob, padded: texels are fetched as the three dwords at their address whatever the format (shading.h, tex_fetch)
 	rc |= dev_alloc(h, h->scene_bufs, &tex_data, (size_t)sc->texture_data_bytes + 16);
 	if (!rc && sc->texture_data_bytes) HIP_TRY(h, hipMemcpyAsync(tex_data, sc->texture_data, sc->texture_data_bytes, hipMemcpyHostToDevice, h->stream));
@@ -529,7 +541,7 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 		}
 	}
 	h->scene = SceneDev{vertices, normals, uvs, mat_index, nodes, emissives, tex_meta, tex_data, sc->num_emissives,
-	                    sc->scene_diffuse_mat_index, sc->num_material_nodes, sc->num_textures};
+	                    sc->scene_diffuse_mat_index, sc->num_material_nodes, sc->num_textures, light_geo};
 	h->max_stack = L.max_stack;
 	if (h->opt_packet_primary < 0) h->packet_primary = sc->num_triangles <= 262144u;
 	// node records: whole tree in LDS for tiny scenes, its top for small ones, global memory otherwise (kernels.h NodeMode)

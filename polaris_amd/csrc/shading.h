@@ -77,7 +77,13 @@ template <bool LDS> struct SceneT {
 	uint32_t num_emissives;
 	int32_t bg_node;                    // scene_diffuse_mat_index or -1
 	uint32_t num_nodes, num_textures;   // table sizes (LDS staging in k_shade)
+	// [num_emissives][kLightGeoFloats] the triangle of every area light, packed at upload (polaris_hip.hip, pack_light_geometry):
+	// v0 v1 v2 | n0 n1 n2 (xyz + pad each) | uv0 uv1 uv2 + pad.  light_sample / light_pdf read it instead of chasing
+	// emissive -> tri_index -> vertices / normals / uvs: with the table staged in LDS the light's geometry costs a shaded
+	// ray no memory round trip (it used to cost two dependent ones, one per function).
+	typename Tbl<LDS>::F light_geo;
 };
+constexpr uint32_t kLightGeoFloats = 32;
 typedef SceneT<false> SceneDev; // what the host fills in
 
 // ---- PRNG: samplers/random_sampler.cl:7-16 ---------------------------------------------
@@ -482,7 +488,7 @@ template <bool LDS> PD void bxdf_pdf_eval(const Surf &sf, const MatT<LDS> &m, co
 // ---- lights: samplers/emissive_sampler.cl ---------------------------------------------
 struct LightSample { f3 radiance, dir; float pdf, dist; };
 
-template <bool LDS> PD LightSample light_sample(const Surf &sf, typename Tbl<LDS>::Light em, const SceneT<LDS> &S, f2 rnd) { // emissiveGetSample, :176-198
+template <bool LDS> PD LightSample light_sample(const Surf &sf, typename Tbl<LDS>::Light em, uint32_t ei, const SceneT<LDS> &S, f2 rnd) { // emissiveGetSample, :176-198
 	LightSample L;
 	typename Tbl<LDS>::Node mn = S.nodes + em->mat_node_index;
 	const uint32_t ltype = em->type;
@@ -500,14 +506,14 @@ template <bool LDS> PD LightSample light_sample(const Surf &sf, typename Tbl<LDS
 		float r1 = pm_sqrt(rnd.x);
 		float ru = (1.0f - rnd.y) * r1, rv = rnd.y * r1;
 		float w0 = 1.0f - ru - rv;
-		uint32_t off = em->tri_index * 3;
-		float4 a = S.vertices[off], b = S.vertices[off + 1], c = S.vertices[off + 2];
+		typename Tbl<LDS>::F g = S.light_geo + ei * kLightGeoFloats; // the light's triangle (vertices, normals, uvs)
+		f3 a = mk3(g[0], g[1], g[2]), b = mk3(g[4], g[5], g[6]), c = mk3(g[8], g[9], g[10]);
 		f3 p = mk3(w0 * a.x + ru * b.x + rv * c.x, w0 * a.y + ru * b.y + rv * c.y, w0 * a.z + ru * b.z + rv * c.z);
 		f3 ep = xform_point(p, em->transform);
-		a = S.normals[off]; b = S.normals[off + 1]; c = S.normals[off + 2];
+		a = mk3(g[12], g[13], g[14]); b = mk3(g[16], g[17], g[18]); c = mk3(g[20], g[21], g[22]);
 		f3 nn = mk3(w0 * a.x + ru * b.x + rv * c.x, w0 * a.y + ru * b.y + rv * c.y, w0 * a.z + ru * b.z + rv * c.z);
 		en = xform_point(nn, em->transform);
-		float2 ua = S.uvs[off], ub = S.uvs[off + 1], uc = S.uvs[off + 2];
+		f2 ua = {g[24], g[25]}, ub = {g[26], g[27]}, uc = {g[28], g[29]};
 		luv = {w0 * ua.x + ru * ub.x + rv * uc.x, w0 * ua.y + ru * ub.y + rv * uc.y};
 		f3 er = ep - sf.p;
 		d2 = dot(er, er);
@@ -530,14 +536,14 @@ template <bool LDS> PD LightSample light_sample(const Surf &sf, typename Tbl<LDS
 	return L;
 }
 
-template <bool LDS> PD float light_pdf(const Surf &sf, typename Tbl<LDS>::Light em, const SceneT<LDS> &S, f3 o) { // emissiveGetPdf, :201-223
+template <bool LDS> PD float light_pdf(const Surf &sf, typename Tbl<LDS>::Light em, uint32_t ei, const SceneT<LDS> &S, f3 o) { // emissiveGetPdf, :201-223
 	if (em->type == POLARIS_EMISSIVE_ENVIRONMENT) return pm_max(0.0f, dot(sf.n, o) * kInvPi); // :39-47
 	if (em->type != POLARIS_EMISSIVE_AREA) return 0.0f;
 	// areaLightGetPdf, :117-173 (edges go through the point transform: quirk kept)
-	uint32_t off = em->tri_index * 3;
-	f3 v0 = xyz(S.vertices[off]);
-	f3 e1 = xyz(S.vertices[off + 1]) - v0;
-	f3 e2 = xyz(S.vertices[off + 2]) - v0;
+	typename Tbl<LDS>::F g = S.light_geo + ei * kLightGeoFloats;
+	f3 v0 = mk3(g[0], g[1], g[2]);
+	f3 e1 = mk3(g[4], g[5], g[6]) - v0;
+	f3 e2 = mk3(g[8], g[9], g[10]) - v0;
 	v0 = xform_point(v0, em->transform);
 	e1 = xform_point(e1, em->transform);
 	e2 = xform_point(e2, em->transform);
