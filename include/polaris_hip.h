@@ -143,6 +143,25 @@ int polaris_hip_read_accumulator(polaris_hip_tracer *h, int which, float *out, s
 int polaris_hip_tap_primary(polaris_hip_tracer *h, const PolarisBlockRequest *req, uint32_t seed,
                             float *rays, int32_t *hit, float *wuvt, int32_t *tri);
 
+/* Function-level test taps: the device-side samplers and BxDFs of the uploaded scene on caller-supplied
+ * inputs, one probe per row of `in`, through the same table staging the shade kernels use.
+ *   kind 0, BxDF of material LEAF node `index` (bxdf/bxdf.cl:31-105):
+ *        in [n][13] = normal[3] uv[2] in_dir[3] sample[2] eval_dir[3]
+ *        out[n][11] = bxdfGetSample value[3], sampled dir[3], pdf | bxdfGetPdf(eval_dir) | bxdfEval(eval_dir)[3]
+ *   kind 1, texture `index` (samplers/texture_sampler.cl:14-252):
+ *        in [n][2] = uv;  out[n][7] = texGetSample3f[3] | texGetSample1f | texGetBumpSample3f[3]
+ *   kind 2, emissive `index` (samplers/emissive_sampler.cl:176-223):
+ *        in [n][11] = point[3] normal[3] sample[2] pdf_dir[3]
+ *        out[n][9]  = emissiveGetSample radiance[3] dir[3] pdf dist | emissiveGetPdf(pdf_dir) */
+int polaris_hip_probe(polaris_hip_tracer *h, int kind, uint32_t index, uint32_t n, const float *in, float *out);
+
+/* rayIntersectionQuery (any_hit = 0, kernels/intersect.cl:184-347) or rayIntersectionTest (any_hit != 0, :26-180) over n
+ * arbitrary rays [n][8] = origin.xyz, maxDist, dir.xyz, unused, through the traversal kernel the options select
+ * ("traversal", "node_mode", "packet_primary" = 1 / "packet_shadow" > 0 for the wave-packet kernel): hit[n]; for closest
+ * hits also (w,u,v,t) [n][4] and the scene triangle index [n] (-1 = miss); either may be NULL. */
+int polaris_hip_probe_intersect(polaris_hip_tracer *h, const float *rays, uint32_t n, int any_hit, int32_t *hit,
+                                float *wuvt, int32_t *tri);
+
 /* With option time_kernels=1: accumulated device milliseconds and launch count of the named
  * kernel ("generate", "intersect", "shade", "occlusion", "scan", "resolve", ...) since the
  * last call for that name. */

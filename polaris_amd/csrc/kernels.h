@@ -1044,6 +1044,78 @@ __global__ __launch_bounds__(WG) void k_shade_wave(Streams st, SceneDev Sg, Shad
 }
 
 // ------------------------------------------------------------------------------------------
+// Function-level probes (test taps, polaris_hip_probe): the device functions of shading.h on caller-supplied inputs, one
+// lane per probe, through the SAME table staging the shade kernels use -- so the samplers and BxDFs are checked against
+// the CPU oracle on the GPU one function at a time, not only through whole traces.
+// ------------------------------------------------------------------------------------------
+enum ProbeKind { kProbeBxdf = 0, kProbeTexture = 1, kProbeEmissive = 2 };
+constexpr uint32_t kProbeIn[3] = {13, 2, 11}, kProbeOut[3] = {11, 7, 9};
+
+template <bool LDS>
+__global__ __launch_bounds__(WG) void k_probe(SceneDev Sg, int kind, uint32_t index, uint32_t n, const float *in, float *out) {
+	__shared__ ShadeLds lds;
+	const SceneT<LDS> S = stage_scene<LDS>(Sg, lds);
+	const uint32_t i = blockIdx.x * WG + threadIdx.x;
+	if (i >= n) return;
+	if (kind == kProbeBxdf) { // in: normal[3] uv[2] in_dir[3] sample[2] eval_dir[3]; out: bxdfGetSample value[3] dir[3] pdf | bxdfGetPdf | bxdfEval[3] (bxdf/bxdf.cl:31-105)
+		const float *p = in + (size_t)i * 13;
+		float *o = out + (size_t)i * 11;
+		Surf sf;
+		sf.p = splat(0.0f); sf.n = mk3(p[0], p[1], p[2]); sf.uv = {p[3], p[4]};
+		const f3 wi = mk3(p[5], p[6], p[7]), wo = mk3(p[10], p[11], p[12]);
+		MatT<LDS> m;
+		m.nd = S.nodes + index;
+		m.type = m.nd->type;
+		m.int_ior = m.nd->int_ior; m.ext_ior = m.nd->ext_ior;
+		material_params(sf, m, S);
+		f3 dir = splat(0.0f);
+		float pdf = 0.0f;
+		const f3 v = bxdf_sample(sf, m, S, f2{p[8], p[9]}, wi, dir, pdf);
+		float pdf2;
+		f3 ev;
+		bxdf_pdf_eval(sf, m, S, wi, wo, true, pdf2, ev);
+		o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = dir.x; o[4] = dir.y; o[5] = dir.z; o[6] = pdf;
+		o[7] = pdf2; o[8] = ev.x; o[9] = ev.y; o[10] = ev.z;
+	} else if (kind == kProbeTexture) { // in: uv[2]; out: texGetSample3f[3] | texGetSample1f | texGetBumpSample3f[3] (texture_sampler.cl:14-252)
+		const float *p = in + (size_t)i * 2;
+		float *o = out + (size_t)i * 7;
+		const TexQuad q = tex_fetch(f2{p[0], p[1]}, (int)index, S);
+		const f3 c = quad_sample3(q), b = quad_bump3(q);
+		o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = c.x; o[4] = b.x; o[5] = b.y; o[6] = b.z;
+	} else { // in: point[3] normal[3] sample[2] pdf_dir[3]; out: emissiveGetSample radiance[3] dir[3] pdf dist | emissiveGetPdf (emissive_sampler.cl:176-223)
+		const float *p = in + (size_t)i * 11;
+		float *o = out + (size_t)i * 9;
+		Surf sf;
+		sf.p = mk3(p[0], p[1], p[2]); sf.n = mk3(p[3], p[4], p[5]); sf.uv = {0.0f, 0.0f};
+		typename Tbl<LDS>::Light em = S.emissives + index;
+		const LightSample L = light_sample(sf, em, index, S, f2{p[6], p[7]});
+		o[0] = L.radiance.x; o[1] = L.radiance.y; o[2] = L.radiance.z; o[3] = L.dir.x; o[4] = L.dir.y; o[5] = L.dir.z;
+		o[6] = L.pdf; o[7] = L.dist;
+		o[8] = light_pdf(sf, em, index, S, mk3(p[8], p[9], p[10]));
+	}
+}
+
+// Arbitrary rays into the stream layout of the traversal kernels (polaris_hip_probe_intersect): slot i = ray i.
+__global__ __launch_bounds__(WG) void k_probe_rays(Streams st, const float *rays, uint32_t n, int any_hit) {
+	const uint32_t i = blockIdx.x * WG + threadIdx.x;
+	if (threadIdx.x == 0) {
+		const uint32_t live = blockIdx.x * WG < n ? min((uint32_t)WG, n - blockIdx.x * WG) : 0u;
+		st.cnt_ray[blockIdx.x] = any_hit ? 0u : live;
+		st.cnt_occ[blockIdx.x] = any_hit ? live : 0u;
+	}
+	if (i >= n) return;
+	const float *r = rays + (size_t)i * 8;
+	const float4 o = make_float4(r[0], r[1], r[2], r[3]), d = make_float4(r[4], r[5], r[6], ibits((int)i));
+	if (any_hit) {
+		st.occ_o[i] = o; st.occ_d[i] = d; st.occ_e[i] = make_float4(1.0f, 0.0f, 0.0f, 0.0f); // an unoccluded ray adds 1 to lsum[i].x
+		st.lsum[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	} else {
+		st.ray_o[i] = o; st.ray_d[i] = d;
+		st.hit[i] = make_float4(0.0f, 0.0f, 0.0f, ibits(-1));
+	}
+}
+
+// ------------------------------------------------------------------------------------------
 // Segmented exclusive scan of the per-workgroup live-ray counts, one workgroup per sample:
 // pfx[wg] = number of live rays in earlier workgroups of the same sample = position of this
 // workgroup's first ray in the reference's compacted buffer.  Also books the ray counters.

@@ -855,6 +855,84 @@ int polaris_hip_tap_primary(polaris_hip_tracer *h, const PolarisBlockRequest *r,
 	return POLARIS_OK;
 }
 
+int polaris_hip_probe(polaris_hip_tracer *h, int kind, uint32_t index, uint32_t n, const float *in, float *out) {
+	if (!h) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "handle is null");
+	std::lock_guard<std::mutex> lk(h->mu);
+	if (!h->have_scene) return fail(h, POLARIS_E_NO_SCENE_DATA, "no scene data uploaded");
+	if (kind < 0 || kind > 2 || (n && (!in || !out))) return fail(h, POLARIS_E_BAD_ARGUMENT, "probe: bad kind or null buffers");
+	const uint32_t limit = kind == kProbeBxdf ? h->scene.num_nodes : (kind == kProbeTexture ? h->scene.num_textures : h->scene.num_emissives);
+	if (index >= limit) return fail(h, POLARIS_E_BAD_ARGUMENT, "probe: index %u out of range (%u)", index, limit);
+	if (n == 0) return POLARIS_OK;
+	HIP_TRY(h, hipSetDevice(h->device));
+	const size_t nin = (size_t)n * kProbeIn[kind], nout = (size_t)n * kProbeOut[kind];
+	float *d_in = nullptr, *d_out = nullptr;
+	HIP_TRY(h, hipMalloc((void **)&d_in, nin * sizeof(float)));
+	if (hipMalloc((void **)&d_out, nout * sizeof(float)) != hipSuccess) { (void)hipFree(d_in); return fail(h, POLARIS_E_DEVICE, "probe: out of device memory"); }
+	hipStream_t q = h->stream;
+	hipError_t e = hipMemcpyAsync(d_in, in, nin * sizeof(float), hipMemcpyHostToDevice, q);
+	const bool staged = h->opt_stage_lds && h->scene.num_nodes <= kLdsMatNodes && h->scene.num_emissives <= kLdsLights &&
+	                    h->scene.num_textures <= kLdsTextures;
+	if (e == hipSuccess) {
+		if (staged) hipLaunchKernelGGL(k_probe<true>, dim3(grid_for(n)), dim3(WG), 0, q, h->scene, kind, index, n, d_in, d_out);
+		else hipLaunchKernelGGL(k_probe<false>, dim3(grid_for(n)), dim3(WG), 0, q, h->scene, kind, index, n, d_in, d_out);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, nout * sizeof(float), hipMemcpyDeviceToHost, q);
+	if (e == hipSuccess) e = hipStreamSynchronize(q);
+	else (void)hipStreamSynchronize(q);
+	(void)hipFree(d_in);
+	(void)hipFree(d_out);
+	if (e != hipSuccess) return fail(h, POLARIS_E_DEVICE, "probe: %s", hipGetErrorString(e));
+	return POLARIS_OK;
+}
+
+int polaris_hip_probe_intersect(polaris_hip_tracer *h, const float *rays, uint32_t n, int any_hit, int32_t *hit, float *wuvt, int32_t *tri) {
+	if (!h) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "handle is null");
+	std::lock_guard<std::mutex> lk(h->mu);
+	if (!h->have_scene) return fail(h, POLARIS_E_NO_SCENE_DATA, "no scene data uploaded");
+	if (n && (!rays || !hit)) return fail(h, POLARIS_E_BAD_ARGUMENT, "probe_intersect: null buffers");
+	if (n > (1u << 24)) return fail(h, POLARIS_E_BAD_ARGUMENT, "probe_intersect: at most 2^24 rays per call");
+	if (n == 0) return POLARIS_OK;
+	HIP_TRY(h, hipSetDevice(h->device));
+	const uint32_t npad = (n + WG - 1) / WG * WG, wgs = npad / WG;
+	if (int rc = ensure_streams(h, 0, std::max<size_t>(h->pipe[0].slots, npad), false)) return rc;
+	polaris_hip_tracer::Pipe &P = h->pipe[0];
+	hipStream_t q = P.q;
+	float *d_rays = nullptr;
+	HIP_TRY(h, hipMalloc((void **)&d_rays, (size_t)n * 8 * sizeof(float)));
+	hipError_t e = hipMemcpyAsync(d_rays, rays, (size_t)n * 8 * sizeof(float), hipMemcpyHostToDevice, q);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_probe_rays, dim3(wgs), dim3(WG), 0, q, P.st, d_rays, n, any_hit ? 1 : 0);
+		// the traversal kernel the options select for bounce rays (any_hit: shadow rays); packet_primary=1 sends closest-hit
+		// probes through the wave-packet kernel instead
+		if (any_hit) {
+			if (h->opt_packet_shadow > 0) hipLaunchKernelGGL(k_trace_packet<true>, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, P.st.lsum, h->d_stats);
+			else if (h->opt_traversal) launch_trace<true>(h, P, std::min<uint32_t>(wgs, (uint32_t)h->num_cus * (uint32_t)std::max(1, h->occl_resident_per_cu)), wgs, P.st.lsum);
+			else hipLaunchKernelGGL(k_occlusion, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, P.st.lsum, h->d_stats);
+		} else {
+			if (h->opt_packet_primary == 1) hipLaunchKernelGGL(k_trace_packet<false>, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, (float4 *)nullptr, h->d_stats);
+			else if (h->opt_traversal) launch_trace<false>(h, P, std::min<uint32_t>(wgs, (uint32_t)h->num_cus * (uint32_t)std::max(1, h->trace_resident_per_cu)), wgs, nullptr);
+			else hipLaunchKernelGGL(k_intersect, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh);
+		}
+		e = hipGetLastError();
+	}
+	std::vector<float4> res(n);
+	if (e == hipSuccess) e = hipMemcpyAsync(res.data(), any_hit ? P.st.lsum : P.st.hit, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, q);
+	const hipError_t e2 = hipStreamSynchronize(q);
+	(void)hipFree(d_rays);
+	if (e == hipSuccess) e = e2;
+	if (e != hipSuccess) return fail(h, POLARIS_E_DEVICE, "probe_intersect: %s", hipGetErrorString(e));
+	for (uint32_t i = 0; i < n; i++) {
+		if (any_hit) { hit[i] = res[i].x == 0.0f ? 1 : 0; continue; } // occluded rays leave their cell untouched
+		int t;
+		memcpy(&t, &res[i].w, 4);
+		hit[i] = t >= 0 ? 1 : 0;
+		if (t >= 0 && wuvt) { float *o = wuvt + 4 * (size_t)i; o[0] = 1.0f - (res[i].x + res[i].y); o[1] = res[i].x; o[2] = res[i].y; o[3] = res[i].z; } // intersect.cl:283-288
+		if (tri) tri[i] = t;
+	}
+	return POLARIS_OK;
+}
+
 int polaris_hip_kernel_ms(polaris_hip_tracer *h, const char *kernel, double *ms, uint64_t *launches) {
 	if (!h) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "handle is null");
 	std::lock_guard<std::mutex> lk(h->mu);

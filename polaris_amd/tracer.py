@@ -159,6 +159,28 @@ class HipTracer:
                                                       taps["primary_tri"].ctypes.data), self._h)
         return taps
 
+    PROBE_BXDF, PROBE_TEXTURE, PROBE_EMISSIVE = 0, 1, 2
+    _PROBE_SHAPES = {0: (13, 11), 1: (2, 7), 2: (11, 9)}
+
+    def probe(self, kind: int, index: int, inputs) -> np.ndarray:
+        """Function-level test tap (polaris_hip_probe): rows of `inputs` through the device-side BxDF / texture / light
+        functions of the uploaded scene; returns one row of outputs per probe."""
+        n_in, n_out = self._PROBE_SHAPES[kind]
+        a = np.ascontiguousarray(inputs, dtype=np.float32).reshape(-1, n_in)
+        out = np.zeros((a.shape[0], n_out), np.float32)
+        self._check(self._lib.polaris_hip_probe(self._h, kind, index, a.shape[0], a.ctypes.data, out.ctypes.data), self._h)
+        return out
+
+    def probe_intersect(self, rays, any_hit: bool = False):
+        """Arbitrary rays (n, 8) = origin, maxDist, dir, unused through the selected traversal kernel
+        (polaris_hip_probe_intersect).  Returns (hit (n,), wuvt (n, 4), triangle (n,))."""
+        r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = r.shape[0]
+        hit, wuvt, tri = np.zeros(n, np.int32), np.zeros((n, 4), np.float32), np.full(n, -1, np.int32)
+        self._check(self._lib.polaris_hip_probe_intersect(self._h, r.ctypes.data, n, int(any_hit), hit.ctypes.data,
+                                                          wuvt.ctypes.data, tri.ctypes.data), self._h)
+        return hit, wuvt, tri
+
     def kernel_ms(self, name: str) -> tuple[float, int]:
         ms, n = C.c_double(), C.c_uint64()
         self._check(self._lib.polaris_hip_kernel_ms(self._h, name.encode(), C.byref(ms), C.byref(n)), self._h)
