@@ -267,3 +267,20 @@ def test_texture_index_of_mix_and_disperse_nodes_is_range_checked(harness):
     sc.material_nodes = mn
     rc, msg = _layout_error(harness, sc)
     assert rc != 0 and "texture out of range" in msg, msg
+
+
+def test_multi_byte_texels_must_be_dword_aligned(harness):
+    """The shade kernels fetch texels as whole dwords (the reference reads them through uchar4 / float / float4 pointers,
+    texture_sampler.cl:42-91): RGBA8 / L32F / RGBA32F data at an unaligned offset is rejected at upload; 1-byte L8 texels
+    may start anywhere."""
+    sc = scenes.textured_materials_scene()
+    assert _layout_error(harness, sc)[0] == 0
+    for fmt, ok in ((T.TEX_RGBA8, False), (T.TEX_L32F, False), (T.TEX_RGBA32F, False), (T.TEX_L8, True)):
+        s2 = scenes.textured_materials_scene()
+        t = int(np.nonzero(s2.texture_meta["format"] == fmt)[0][0])
+        meta = s2.texture_meta.copy()
+        s2.texture_data = np.concatenate([s2.texture_data, np.zeros(1, np.uint8), s2.texture_data])  # a copy of the blob, one byte off
+        meta[t]["data_offset"] = int(meta[t]["data_offset"]) + len(sc.texture_data) + 1
+        s2.texture_meta = meta
+        rc, msg = _layout_error(harness, s2)
+        assert (rc == 0) == ok and (ok or "not dword aligned" in msg), (fmt, rc, msg)
