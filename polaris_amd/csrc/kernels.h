@@ -775,8 +775,9 @@ __device__ __forceinline__ void shade_ray(const SceneT<LDS> &S, const ShadeArgs 
 	const uint32_t pixel_index = A.blockY * A.W + path_index; // camera.cl:32-33
 	const uint32_t cell = A.exact ? pixel_index : (uint32_t)(sample * A.Npad + path_index);
 	f3 thr = xyz(t4);
-	const int tri = fbits(h4.w);
-	if (tri < 0) {
+	const int tri_word = fbits(h4.w);
+	const int tri = tri_word & (int)((1u << S.tri_bits) - 1u); // (the shading class rides above the index)
+	if (tri_word < 0) {
 		if (S.bg_node >= 0) { // pt_integrator.cl:214-275 (throughput is exactly 1 for primaries)
 			typename Tbl<LDS>::Node bg = S.nodes + S.bg_node;
 			f2 uv = latlong_uv(xyz(d4));
@@ -898,6 +899,7 @@ __device__ __forceinline__ SceneT<LDS> stage_scene(const SceneDev &Sg, ShadeLds 
 	SceneT<LDS> S;
 	S.vertices = Sg.vertices; S.normals = Sg.normals; S.uvs = Sg.uvs; S.mat_index = Sg.mat_index; S.tex_data = Sg.tex_data;
 	S.num_emissives = Sg.num_emissives; S.bg_node = Sg.bg_node; S.num_nodes = Sg.num_nodes; S.num_textures = Sg.num_textures;
+	S.tri_bits = Sg.tri_bits;
 	if constexpr (LDS) { // the host launches this variant only when all three tables fit
 		const uint32_t tid = threadIdx.x;
 		const bool has_n = tid < Sg.num_nodes * 4, has_l = tid < Sg.num_emissives * 5, has_t = tid < Sg.num_textures;
@@ -924,12 +926,28 @@ __device__ __forceinline__ SceneT<LDS> stage_scene(const SceneDev &Sg, ShadeLds 
 
 // k_shade: one workgroup per chunk, one lane per live ray, stable in-place compaction through LDS.
 // Occupancy: shade_ray needs ~106 VGPRs unconstrained (4 waves per SIMD); the kernel waits on memory for most of a wave's
-// life, so it is built for 5 waves (96 VGPRs, 7 spilled dwords outside the hot path): -8 % kernel time.
-template <bool LDS>
+// life, so it is built for 5 waves (-8 % kernel time).
+//
+// SORT (the bounces after the first): the chunk's rays are shaded in the order of their material's SHADING CLASS
+// (scene_layout.h, shading_classes: which BxDF leaves and texture operators the material tree can reach; it rides in the
+// hit record above the triangle index) instead of their slot order.  A wave of bounce rays holds diffuse walls, glass,
+// metal and misses side by side and executes the union of their code paths: 25 % of the lanes of a VALU instruction were
+// live there (PMC), and the same Cornell box with diffuse materials only shades in half the time.  Which lane shades which
+// ray is free: a ray's PRNG stream is keyed by its position in the REFERENCE's compacted buffer (pfx + its slot index)
+// and its outputs go to the rank it has among the emitting rays in slot order -- both follow from the ray's slot `src`,
+// whatever lane holds it.  Counting sort over <= 16 classes: per-wave ballots, the 64 (class, wave) counts scanned by
+// every wave with shuffles, the rays themselves (already in registers) moved to their lane through LDS -- no memory
+// round trip is added; the emit flags go into LDS bit masks indexed by `src`, from which every lane reads its rank.
+// Results are bit-identical to slot order.
+template <bool LDS, bool SORT>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_shade(Streams st, SceneDev Sg, ShadeArgs A) {
 	__shared__ uint32_t wave_ind[4], wave_occ[4];
 	__shared__ uint32_t wave_stat[4][3];
 	__shared__ ShadeLds lds;
+	__shared__ uint32_t s_cnt[SORT ? 4 : 1][16];       // rays per (wave, class)
+	__shared__ float4 x_d[SORT ? WG : 1], x_t[SORT ? WG : 1], x_h[SORT ? WG : 1]; // the rays in class order
+	__shared__ uint16_t x_src[SORT ? WG : 1];          // ... and the slot each came from
+	__shared__ uint32_t s_emit[2][8];                  // indirect / shadow ray emitted by the ray of slot i: bit i % 32 of word i / 32
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const uint32_t cnt = st.cnt_ray[blockIdx.x];
 	if (cnt == 0) { // uniform exit: nothing live in this workgroup
@@ -939,38 +957,84 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5, 5))) void
 	// the lane's ray is requested before the tables are staged: both round trips are in flight together
 	const size_t base = (size_t)blockIdx.x * WG;
 	const size_t my = base + (tid < cnt ? tid : 0u); // (idle lanes re-read slot 0: no select behind the loads, so nothing waits for them here)
-	const float4 d4 = st.ray_d[my], t4 = st.thr[my], h4 = st.hit[my];
+	float4 d4 = st.ray_d[my], t4 = st.thr[my], h4 = st.hit[my];
+	if (SORT && tid < 16) s_emit[tid >> 3][tid & 7] = 0; // (published by the barrier that ends stage_scene)
 	const SceneT<LDS> S = stage_scene<LDS>(Sg, lds);
 	const uint32_t s = blockIdx.x / (A.Npad / WG);
+	const unsigned long long below = (1ull << lane) - 1ull;
+	uint32_t src = tid; // slot (within the chunk) of the ray this lane shades
+	if (SORT) {
+		uint32_t key = 16; // no ray
+		if (tid < cnt) {
+			const int w = fbits(h4.w);
+			key = w < 0 ? 0u : min((uint32_t)w >> S.tri_bits, 15u);
+		}
+		if (lane < 16) s_cnt[wave][lane] = 0; // (LDS operations of one wave execute in order)
+		uint32_t rank_in = 0;
+		unsigned long long todo = __ballot(key < 16);
+		while (todo != 0ull) { // one round per class present in this wave
+			const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, __ffsll((long long)todo) - 1);
+			const unsigned long long m = __ballot(key == k);
+			if (key == k) rank_in = __popcll(m & below);
+			if (lane == 0) s_cnt[wave][k] = __popcll(m);
+			todo &= ~m;
+		}
+		__syncthreads();
+		// exclusive scan of the 64 counts in (class, wave) order, by every wave for itself
+		const uint32_t mine = s_cnt[lane & 3][lane >> 2];
+		uint32_t incl = mine;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t up = __shfl_up(incl, d);
+			if ((int)lane >= d) incl += up;
+		}
+		const uint32_t dest = __shfl(incl - mine, (int)((key & 15u) * 4 + wave)) + rank_in;
+		if (key < 16) { x_d[dest] = d4; x_t[dest] = t4; x_h[dest] = h4; x_src[dest] = (uint16_t)tid; }
+		__syncthreads();
+		if (tid < cnt) { d4 = x_d[tid]; t4 = x_t[tid]; h4 = x_h[tid]; src = x_src[tid]; }
+	}
 	ShadeOut R;
 	R.emit_ind = R.emit_occ = false;
 	R.hit = R.miss = R.emit = 0;
 	if (tid < cnt) {
 		const uint32_t seed = A.seeds[(size_t)(A.first_sample + s) * A.seed_stride + 1 + A.bounce];
-		shade_ray(S, A, s, seed, st.pfx[blockIdx.x] + tid, d4, t4, h4, R);
+		shade_ray(S, A, s, seed, st.pfx[blockIdx.x] + src, d4, t4, h4, R);
 	}
 	// ---- stable in-place compaction of the two output streams -----------------------------
 	const unsigned long long m_ind = __ballot(R.emit_ind), m_occ = __ballot(R.emit_occ);
-	const unsigned long long below = (1ull << lane) - 1ull;
-	const uint32_t r_ind = __popcll(m_ind & below), r_occ = __popcll(m_occ & below);
 	const unsigned long long mh = __ballot(R.hit != 0), mm = __ballot(R.miss != 0), me = __ballot(R.emit != 0);
 	if (lane == 0) {
 		wave_ind[wave] = __popcll(m_ind); wave_occ[wave] = __popcll(m_occ);
 		wave_stat[wave][0] = __popcll(mh); wave_stat[wave][1] = __popcll(mm); wave_stat[wave][2] = __popcll(me);
 	}
-	__syncthreads(); // the ONE barrier after shading: it also orders every lane's stream loads before any lane's in-place stores
-	uint32_t b_ind = 0, b_occ = 0, tot_ind = 0, tot_occ = 0;
-#pragma unroll
-	for (int w = 0; w < 4; w++) {
-		if (w < (int)wave) { b_ind += wave_ind[w]; b_occ += wave_occ[w]; }
-		tot_ind += wave_ind[w]; tot_occ += wave_occ[w];
+	if (SORT) {
+		if (R.emit_ind) atomicOr(&s_emit[0][src >> 5], 1u << (src & 31));
+		if (R.emit_occ) atomicOr(&s_emit[1][src >> 5], 1u << (src & 31));
 	}
+	__syncthreads(); // the ONE barrier after shading: it also orders every lane's stream loads before any lane's in-place stores
+	uint32_t d_ind = 0, d_occ = 0, tot_ind = 0, tot_occ = 0; // this ray's rank among the emitting rays of the chunk, in slot order
+	if (SORT) {
+		const uint32_t word = src >> 5, lower = (1u << (src & 31)) - 1u;
+#pragma unroll
+		for (uint32_t w = 0; w < 8; w++) {
+			const uint32_t wi = s_emit[0][w], wo = s_emit[1][w];
+			d_ind += w < word ? __popc(wi) : (w == word ? __popc(wi & lower) : 0);
+			d_occ += w < word ? __popc(wo) : (w == word ? __popc(wo & lower) : 0);
+		}
+	} else {
+		d_ind = __popcll(m_ind & below); d_occ = __popcll(m_occ & below);
+#pragma unroll
+		for (int w = 0; w < 4; w++)
+			if (w < (int)wave) { d_ind += wave_ind[w]; d_occ += wave_occ[w]; }
+	}
+#pragma unroll
+	for (int w = 0; w < 4; w++) { tot_ind += wave_ind[w]; tot_occ += wave_occ[w]; }
 	if (R.emit_ind) {
-		const size_t d = base + b_ind + r_ind;
+		const size_t d = base + d_ind;
 		st.ray_o[d] = R.ro; st.ray_d[d] = R.rd; st.thr[d] = R.thr;
 	}
 	if (R.emit_occ) {
-		const size_t d = base + b_occ + r_occ;
+		const size_t d = base + d_occ;
 		st.occ_o[d] = R.oo; st.occ_d[d] = R.od; st.occ_e[d] = R.oe;
 	}
 	if (tid == 0) {

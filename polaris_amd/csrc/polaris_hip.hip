@@ -99,6 +99,7 @@ struct polaris_hip_tracer {
 	int opt_shade_wgs_per_cu = 8;
 	int opt_shade_wave_from = -1; // first bounce shaded by k_shade_wave; -1 = the bounce AFTER Russian roulette starts thinning the
 	                              // chunks (min_bounces_for_rr + 1: the RR bounce itself still shades dense chunks); earlier bounces use k_shade
+	int opt_shade_sort = -1; // first bounce whose rays k_shade groups by shading class; -1 = default (1), POLARIS_MAX_BOUNCES = never
 	int opt_traversal = 1; // 1 = persistent waves with lane refill (k_trace), 0 = one ray per lane (k_intersect/k_occlusion)
 
 	// per-kernel timing (option time_kernels)
@@ -325,8 +326,16 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 				if (staged) hipLaunchKernelGGL(k_shade_wave<true>, dim3(grid), dim3(WG), 0, q, P.st, h->scene, A, wgs);
 				else hipLaunchKernelGGL(k_shade_wave<false>, dim3(grid), dim3(WG), 0, q, P.st, h->scene, A, wgs);
 			} else {
-				if (staged) hipLaunchKernelGGL(k_shade<true>, dim3(wgs), dim3(WG), 0, q, P.st, h->scene, A);
-				else hipLaunchKernelGGL(k_shade<false>, dim3(wgs), dim3(WG), 0, q, P.st, h->scene, A);
+				// bounce rays are shaded in the order of their material's shading class (kernels.h, k_shade SORT); camera rays are
+				// coherent as they come (64 neighbouring pixels per wave)
+				const bool sorted = h->scene.tri_bits < 31 && (int)b >= (h->opt_shade_sort >= 0 ? h->opt_shade_sort : 1);
+				if (staged) {
+					if (sorted) hipLaunchKernelGGL((k_shade<true, true>), dim3(wgs), dim3(WG), 0, q, P.st, h->scene, A);
+					else hipLaunchKernelGGL((k_shade<true, false>), dim3(wgs), dim3(WG), 0, q, P.st, h->scene, A);
+				} else {
+					if (sorted) hipLaunchKernelGGL((k_shade<false, true>), dim3(wgs), dim3(WG), 0, q, P.st, h->scene, A);
+					else hipLaunchKernelGGL((k_shade<false, false>), dim3(wgs), dim3(WG), 0, q, P.st, h->scene, A);
+				}
 			}
 		}
 		{
@@ -541,7 +550,7 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 		}
 	}
 	h->scene = SceneDev{vertices, normals, uvs, mat_index, nodes, emissives, tex_meta, tex_data, sc->num_emissives,
-	                    sc->scene_diffuse_mat_index, sc->num_material_nodes, sc->num_textures, light_geo};
+	                    sc->scene_diffuse_mat_index, sc->num_material_nodes, sc->num_textures, light_geo, L.tri_bits};
 	h->max_stack = L.max_stack;
 	if (h->opt_packet_primary < 0) h->packet_primary = sc->num_triangles <= 262144u;
 	// node records: whole tree in LDS for tiny scenes, its top for small ones, global memory otherwise (kernels.h NodeMode)
@@ -583,6 +592,7 @@ int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value
 	else if (k == "shade_wave_from") h->opt_shade_wave_from = (int)std::max<int64_t>(-1, std::min<int64_t>(value, POLARIS_MAX_BOUNCES));
 	else if (k == "shade_wgs_per_cu") h->opt_shade_wgs_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(value, 64));
 	else if (k == "stage_lds") h->opt_stage_lds = value != 0;
+	else if (k == "shade_sort") h->opt_shade_sort = (int)std::max<int64_t>(-1, std::min<int64_t>(value, POLARIS_MAX_BOUNCES));
 	else if (k == "overlap") h->opt_overlap = (int)std::max<int64_t>(1, std::min<int64_t>(value, polaris_hip_tracer::kMaxPipes));
 	else if (k == "trace_wgs_per_cu") h->opt_trace_wgs_per_cu = (int)std::max<int64_t>(0, std::min<int64_t>(value, 64));
 	else if (k == "max_leaf_tris") h->opt_max_leaf_tris = (int)std::max<int64_t>(-1, std::min<int64_t>(value, 1 << 20)); // next upload
@@ -844,6 +854,7 @@ int polaris_hip_tap_primary(polaris_hip_tracer *h, const PolarisBlockRequest *r,
 			o[4] = rd[i].x; o[5] = rd[i].y; o[6] = rd[i].z; o[7] = (float)(pw & 0xFFFFFF); // util/ray.cl:11
 		}
 		if (hit) hit[i] = t >= 0 ? 1 : 0;
+		if (t >= 0) t &= (int)((1u << h->scene.tri_bits) - 1u); // (the shading class rides above the triangle index)
 		if (t >= 0) {
 			if (wuvt) {
 				float *o = wuvt + 4 * (size_t)i;
@@ -927,6 +938,7 @@ int polaris_hip_probe_intersect(polaris_hip_tracer *h, const float *rays, uint32
 		int t;
 		memcpy(&t, &res[i].w, 4);
 		hit[i] = t >= 0 ? 1 : 0;
+		if (t >= 0) t &= (int)((1u << h->scene.tri_bits) - 1u);
 		if (t >= 0 && wuvt) { float *o = wuvt + 4 * (size_t)i; o[0] = 1.0f - (res[i].x + res[i].y); o[1] = res[i].x; o[2] = res[i].y; o[3] = res[i].z; } // intersect.cl:283-288
 		if (tri) tri[i] = t;
 	}

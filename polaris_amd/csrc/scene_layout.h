@@ -55,7 +55,64 @@ struct SceneLayout {
 	int32_t root_ref = 0;
 	int max_stack = 0;
 	uint32_t unbounded_boxes = 0;   // inner nodes with a child whose box does not contain its subtree (never culled by distance)
+	// A triangle record's `orig` word = scene triangle index | shading class << tri_bits (24 when the scene has at most 2^24
+	// triangles, else 31 = no class).  The traversal kernels hand the word through to the hit record untouched; k_shade
+	// sorts a workgroup's rays by the class and masks it off.
+	uint32_t tri_bits = 31;
 };
+
+// Shading class of every material node = which BxDF leaves and texture operators the tree rooted at it can reach.  k_shade
+// groups the rays of a workgroup by the class of the triangle's material root before shading them (rays of one class run
+// the same code, so a wave is no longer the union of five BxDF paths).  A sort key, nothing else: results do not depend on
+// it.  Classes 1..15 (0 is "the ray missed"); scenes with more distinct reach sets share class 15.
+inline void shading_classes(const PolarisSceneView &sc, std::vector<uint8_t> &cls) {
+	const uint32_t n = sc.num_material_nodes;
+	std::vector<uint32_t> reach(n, 0);
+	std::vector<uint8_t> state(n, 0); // 0 new, 1 on the walk, 2 done
+	auto leaf_bit = [](uint32_t type) -> uint32_t {
+		switch (type) {
+		case POLARIS_BXDF_EMISSIVE: return 1u;
+		case POLARIS_BXDF_DIFFUSE: return 2u;
+		case POLARIS_BXDF_CONDUCTOR: return 4u;
+		case POLARIS_BXDF_ROUGH_CONDUCTOR: return 8u;
+		case POLARIS_BXDF_DIELECTRIC: return 16u;
+		case POLARIS_BXDF_ROUGH_DIELECTRIC: return 32u;
+		default: return 64u; // invalid: the path ends
+		}
+	};
+	for (uint32_t root = 0; root < n; root++) { // iterative post-order walk (trees may be deep, and a malformed one may loop)
+		if (state[root] == 2) continue;
+		std::vector<std::pair<uint32_t, int>> stack{{root, 0}};
+		state[root] = 1;
+		while (!stack.empty()) {
+			const uint32_t i = stack.back().first;
+			const int step = stack.back().second++;
+			const PolarisMaterialNode &m = sc.material_nodes[i];
+			if (m.type < POLARIS_MAT_OP_MIX) { reach[i] = leaf_bit(m.type); state[i] = 2; stack.pop_back(); continue; }
+			const bool two = m.type == POLARIS_MAT_OP_MIX || m.type == POLARIS_MAT_OP_MIX_MAP;
+			const uint32_t kids[2] = {m.left_child, two ? (uint32_t)m.right_child : m.left_child};
+			if (step < (two ? 2 : 1)) {
+				const uint32_t c = kids[step];
+				if (c < n && state[c] == 0) { state[c] = 1; stack.push_back({c, 0}); }
+				continue;
+			}
+			uint32_t r = m.type == POLARIS_MAT_OP_MIX ? 0u : (m.type == POLARIS_MAT_OP_DISPERSE ? 256u : 128u); // textured operators / dispersion
+			for (int k = 0; k < (two ? 2 : 1); k++) r |= kids[k] < n && state[kids[k]] == 2 ? reach[kids[k]] : 64u; // a child still on the walk = a cycle
+			reach[i] = r;
+			state[i] = 2;
+			stack.pop_back();
+		}
+	}
+	std::vector<uint32_t> distinct(reach.begin(), reach.end());
+	std::sort(distinct.begin(), distinct.end());
+	distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+	cls.resize(n);
+	for (uint32_t i = 0; i < n; i++) {
+		const size_t k = (size_t)(std::lower_bound(distinct.begin(), distinct.end(), reach[i]) - distinct.begin());
+		cls[i] = (uint8_t)std::min<size_t>(1 + k, 15);
+	}
+}
+
 
 inline bool is_leaf(const PolarisBvhNode &n) { return n.ldata <= 0; }
 
@@ -566,6 +623,9 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out, in
 		for (uint32_t i = 0; i < NI; i++) out.insts[i].root_ref = remap(out.insts[i].root_ref);
 	}
 
+	std::vector<uint8_t> node_class;
+	shading_classes(sc, node_class);
+	out.tri_bits = NT <= (1u << 24) ? 24 : 31;
 	out.tris.assign(n_slots, TriH{});
 	for (uint32_t s = 0; s < n_slots; s++) {
 		const uint32_t t = slot_src[s];
@@ -573,7 +633,7 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out, in
 		TriH &d = out.tris[s];
 		for (int k = 0; k < 3; k++) { d.v0[k] = v0[k]; d.e1[k] = v1[k] - v0[k]; d.e2[k] = v2[k] - v0[k]; }
 		d.rank = tri_rank[t] == 0xFFFFFFFFu ? t : tri_rank[t];
-		d.orig = t;
+		d.orig = out.tri_bits < 31 ? (t | (uint32_t)node_class[sc.material_index[t]] << out.tri_bits) : t;
 	}
 	return "";
 }

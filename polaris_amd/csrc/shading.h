@@ -82,6 +82,8 @@ template <bool LDS> struct SceneT {
 	// emissive -> tri_index -> vertices / normals / uvs: with the table staged in LDS the light's geometry costs a shaded
 	// ray no memory round trip (it used to cost two dependent ones, one per function).
 	typename Tbl<LDS>::F light_geo;
+	// a hit record's last word = scene triangle index | shading class << tri_bits (scene_layout.h; 31 = scenes too big to carry a class)
+	uint32_t tri_bits;
 };
 constexpr uint32_t kLightGeoFloats = 32;
 typedef SceneT<false> SceneDev; // what the host fills in

@@ -120,7 +120,7 @@ int layout_check_traverse(const PolarisSceneView *sc, int max_leaf_tris, const f
 					} else if (tt > kEps) {
 						const bool closer = tt < bt;
 						const bool tie = tt == bt && btri >= 0 && (irank < birank || (irank == birank && T.rank < btrank));
-						if (closer || tie) { bt = tt; bu = u; bv = v; btri = (int)T.orig; binst = inst; birank = irank; btrank = T.rank; }
+						if (closer || tie) { bt = tt; bu = u; bv = v; btri = (int)(T.orig & ((1u << L.tri_bits) - 1u)); /* the shading class rides in the bits above (scene_layout.h) */ binst = inst; birank = irank; btrank = T.rank; }
 					}
 				}
 				if (found) break;
