@@ -63,6 +63,11 @@ struct Streams {
 	float4 *lsum;
 	uint32_t *cnt_ray, *cnt_occ, *pfx;
 	uint32_t *wg_stat; // per workgroup, written by shade: hits | misses << 10 | emitter hits << 20 (summed by k_scan)
+	// Canonical order (see k_shade).  Rays sit in their chunk in ANY order; what the reference's stable compaction would
+	// have made of them is carried as data: every indirect ray holds its PARENT's canonical index (position within the
+	// chunk in reference order) in thr.w, and emask[bounce parity][chunk][8] has bit c set when the parent with canonical
+	// index c emitted a ray -- so a ray's own canonical index is the number of set bits below its parent's.
+	uint32_t *emask[2];
 	int *hit_inst; // optional (test tap): instance id per slot, may be null
 };
 
@@ -754,6 +759,8 @@ struct ShadeArgs {
 	int last_bounce;   // no closest-hit query follows (pipeline.go:203): do not emit indirect rays
 	int exact;         // accumulate into acc[pixelIndex] (trace accumulator) instead of lsum[path slot]
 	float4 *acc;       // trace accumulator (exact) or lsum (batched)
+	const uint32_t *emask_in; // emit masks of the previous shade step (null at bounce 0: canonical index = slot index)
+	uint32_t *emask_out;      // ... of this one
 };
 
 struct ShadeOut {
@@ -894,8 +901,10 @@ struct ShadeLds {
 // The three tables are at most 256 + 80 + 16 float4s: every thread issues its (up to) three loads back to back and stores
 // them afterwards -- one memory round trip in front of the barrier, not one per table.
 static_assert(kLdsMatNodes * 4 <= WG && kLdsLights * 5 <= WG && kLdsTextures <= WG && kLdsLights * (kLightGeoFloats / 4) <= WG, "stage_scene copies each table in one pass");
-template <bool LDS>
-__device__ __forceinline__ SceneT<LDS> stage_scene(const SceneDev &Sg, ShadeLds &L) {
+// `before_barrier` runs after the staging loads are issued and before the barrier (k_shade pins its ray loads there).
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+template <bool LDS, class Hook = NoHook>
+__device__ __forceinline__ SceneT<LDS> stage_scene(const SceneDev &Sg, ShadeLds &L, Hook before_barrier = Hook()) {
 	SceneT<LDS> S;
 	S.vertices = Sg.vertices; S.normals = Sg.normals; S.uvs = Sg.uvs; S.mat_index = Sg.mat_index; S.tex_data = Sg.tex_data;
 	S.num_emissives = Sg.num_emissives; S.bg_node = Sg.bg_node; S.num_nodes = Sg.num_nodes; S.num_textures = Sg.num_textures;
@@ -920,49 +929,72 @@ __device__ __forceinline__ SceneT<LDS> stage_scene(const SceneDev &Sg, ShadeLds 
 	} else {
 		S.nodes = Sg.nodes; S.emissives = Sg.emissives; S.tex_meta = Sg.tex_meta; S.light_geo = Sg.light_geo;
 	}
+	before_barrier();
 	__syncthreads();
 	return S;
 }
 
-// k_shade: one workgroup per chunk, one lane per live ray, stable in-place compaction through LDS.
-// Occupancy: shade_ray needs ~106 VGPRs unconstrained (4 waves per SIMD); the kernel waits on memory for most of a wave's
-// life, so it is built for 5 waves (-8 % kernel time).
+// Canonical index of a ray within its chunk = its position in the reference's compacted buffer relative to the chunk's
+// first ray: the number of emitting parents (bits of the previous step's emit mask) below its own parent.
+__device__ __forceinline__ uint32_t canonical_index(const uint32_t (&mask)[8], uint32_t parent) {
+	const uint32_t word = parent >> 5, lower = (1u << (parent & 31)) - 1u;
+	uint32_t c = 0;
+#pragma unroll
+	for (uint32_t w = 0; w < 8; w++) c += w < word ? __popc(mask[w]) : (w == word ? __popc(mask[w] & lower) : 0);
+	return c;
+}
+
+// k_shade: one workgroup per chunk, one lane per live ray.
 //
-// SORT (the bounces after the first): the chunk's rays are shaded in the order of their material's SHADING CLASS
-// (scene_layout.h, shading_classes: which BxDF leaves and texture operators the material tree can reach; it rides in the
-// hit record above the triangle index) instead of their slot order.  A wave of bounce rays holds diffuse walls, glass,
-// metal and misses side by side and executes the union of their code paths: 25 % of the lanes of a VALU instruction were
-// live there (PMC), and the same Cornell box with diffuse materials only shades in half the time.  Which lane shades which
-// ray is free: a ray's PRNG stream is keyed by its position in the REFERENCE's compacted buffer (pfx + its slot index)
-// and its outputs go to the rank it has among the emitting rays in slot order -- both follow from the ray's slot `src`,
-// whatever lane holds it.  Counting sort over <= 16 classes: per-wave ballots, the 64 (class, wave) counts scanned by
-// every wave with shuffles, the rays themselves (already in registers) moved to their lane through LDS -- no memory
-// round trip is added; the emit flags go into LDS bit masks indexed by `src`, from which every lane reads its rank.
-// Results are bit-identical to slot order.
-template <bool LDS, bool SORT>
+// What the reference fixes is the ORDER of a sample's live rays (its PRNG stream is keyed by a ray's position in the
+// compacted buffer, pt_integrator.cl:81, and compaction is stable in work-item order) -- not where a ray physically sits.
+// Round 1 kept the physical order equal to the reference order (stable in-place compaction: ranks from ballots, wave
+// totals through LDS, one barrier).  In-kernel stamps showed what that barrier costs: a wave spent 25-30 % of its life
+// waiting there for the slowest wave of its workgroup (the one holding the rough-dielectric rays), wave slots and
+// registers held all the while.  Now the order is DATA (Streams::emask): a ray carries its parent's canonical index, the
+// chunk's emit mask turns it into the ray's own, and the rays themselves are appended to the chunk in whatever order the
+// waves finish (one LDS atomic per wave and stream reserves the slots).  No barrier after shading: a wave stores its rays
+// and retires; the last wave of the workgroup to finish publishes the chunk's counts and mask.
+//
+// SORT (the bounces after the first): with the physical order free, the chunk's rays are also shaded in the order of their
+// material's SHADING CLASS (scene_layout.h, shading_classes: which BxDF leaves and texture operators the material tree can
+// reach; it rides in the hit record above the triangle index).  A wave of bounce rays holds diffuse walls, glass, metal
+// and misses side by side and executes the union of their code paths: 25 % of the lanes of a VALU instruction were live
+// there (PMC), and the same box with diffuse materials only shades in half the time.  Counting sort over <= 16 classes:
+// per-wave ballots, the 64 (class, wave) counts scanned by every wave with shuffles, the rays (already in registers)
+// moved to their lane through LDS -- no memory round trip is added.  Most waves then run ONE short path and retire early.
+//
+// In-place safety: a chunk's input streams (ray_d, thr, hit) are overwritten by its own outputs.  Every wave's inputs are
+// in registers before the workgroup's last barrier (SORT: the exchange barrier; otherwise the staging barrier, in front
+// of which every wave waits for its loads), and no wave stores before that barrier.
+//
+// Occupancy: shade_ray needs ~106 VGPRs unconstrained (4 waves per SIMD); built for 5 waves (-8 % kernel time).
+template <bool LDS, bool SORT, bool FIRST>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_shade(Streams st, SceneDev Sg, ShadeArgs A) {
-	__shared__ uint32_t wave_ind[4], wave_occ[4];
-	__shared__ uint32_t wave_stat[4][3];
 	__shared__ ShadeLds lds;
 	__shared__ uint32_t s_cnt[SORT ? 4 : 1][16];       // rays per (wave, class)
 	__shared__ float4 x_d[SORT ? WG : 1], x_t[SORT ? WG : 1], x_h[SORT ? WG : 1]; // the rays in class order
-	__shared__ uint16_t x_src[SORT ? WG : 1];          // ... and the slot each came from
-	__shared__ uint32_t s_emit[2][8];                  // indirect / shadow ray emitted by the ray of slot i: bit i % 32 of word i / 32
+	__shared__ uint32_t s_emit[8];                     // this step's emit mask: bit c = the ray with canonical index c emitted an indirect ray
+	__shared__ uint32_t s_tot[6];                      // indirect rays, shadow rays, hits, misses, emitter hits of the chunk; waves finished
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const uint32_t cnt = st.cnt_ray[blockIdx.x];
 	if (cnt == 0) { // uniform exit: nothing live in this workgroup
-		if (tid == 0) { st.cnt_occ[blockIdx.x] = 0; st.wg_stat[blockIdx.x] = 0; }
+		if (tid == 0) { st.cnt_occ[blockIdx.x] = 0; st.wg_stat[blockIdx.x] = 0; } // (no rays come out of it: its emit mask will not be read)
 		return;
 	}
 	// the lane's ray is requested before the tables are staged: both round trips are in flight together
 	const size_t base = (size_t)blockIdx.x * WG;
 	const size_t my = base + (tid < cnt ? tid : 0u); // (idle lanes re-read slot 0: no select behind the loads, so nothing waits for them here)
 	float4 d4 = st.ray_d[my], t4 = st.thr[my], h4 = st.hit[my];
-	if (SORT && tid < 16) s_emit[tid >> 3][tid & 7] = 0; // (published by the barrier that ends stage_scene)
-	const SceneT<LDS> S = stage_scene<LDS>(Sg, lds);
+	uint32_t pmask[8]; // the previous step's emit mask of this chunk (uniform)
+#pragma unroll
+	for (int w = 0; w < 8; w++) pmask[w] = FIRST ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)A.emask_in[(size_t)blockIdx.x * 8 + w]); // (kept in scalar registers)
+	if (tid < 8) s_emit[tid] = 0; // (published by the barrier that ends stage_scene)
+	if (tid < 6) s_tot[tid] = 0;
+	// in-place safety without SORT: this wave's rays are in registers before the staging barrier (the empty asm consumes them)
+	const SceneT<LDS> S = stage_scene<LDS>(Sg, lds, [&]() { if (!SORT) asm volatile("" ::"v"(d4.w), "v"(t4.w), "v"(h4.w)); });
 	const uint32_t s = blockIdx.x / (A.Npad / WG);
 	const unsigned long long below = (1ull << lane) - 1ull;
-	uint32_t src = tid; // slot (within the chunk) of the ray this lane shades
 	if (SORT) {
 		uint32_t key = 16; // no ray
 		if (tid < cnt) {
@@ -989,63 +1021,58 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5, 5))) void
 			if ((int)lane >= d) incl += up;
 		}
 		const uint32_t dest = __shfl(incl - mine, (int)((key & 15u) * 4 + wave)) + rank_in;
-		if (key < 16) { x_d[dest] = d4; x_t[dest] = t4; x_h[dest] = h4; x_src[dest] = (uint16_t)tid; }
+		if (key < 16) { x_d[dest] = d4; x_t[dest] = t4; x_h[dest] = h4; }
 		__syncthreads();
-		if (tid < cnt) { d4 = x_d[tid]; t4 = x_t[tid]; h4 = x_h[tid]; src = x_src[tid]; }
+		if (tid < cnt) { d4 = x_d[tid]; t4 = x_t[tid]; h4 = x_h[tid]; }
 	}
-	ShadeOut R;
-	R.emit_ind = R.emit_occ = false;
-	R.hit = R.miss = R.emit = 0;
-	if (tid < cnt) {
-		const uint32_t seed = A.seeds[(size_t)(A.first_sample + s) * A.seed_stride + 1 + A.bounce];
-		shade_ray(S, A, s, seed, st.pfx[blockIdx.x] + src, d4, t4, h4, R);
-	}
-	// ---- stable in-place compaction of the two output streams -----------------------------
-	const unsigned long long m_ind = __ballot(R.emit_ind), m_occ = __ballot(R.emit_occ);
-	const unsigned long long mh = __ballot(R.hit != 0), mm = __ballot(R.miss != 0), me = __ballot(R.emit != 0);
-	if (lane == 0) {
-		wave_ind[wave] = __popcll(m_ind); wave_occ[wave] = __popcll(m_occ);
-		wave_stat[wave][0] = __popcll(mh); wave_stat[wave][1] = __popcll(mm); wave_stat[wave][2] = __popcll(me);
-	}
-	if (SORT) {
-		if (R.emit_ind) atomicOr(&s_emit[0][src >> 5], 1u << (src & 31));
-		if (R.emit_occ) atomicOr(&s_emit[1][src >> 5], 1u << (src & 31));
-	}
-	__syncthreads(); // the ONE barrier after shading: it also orders every lane's stream loads before any lane's in-place stores
-	uint32_t d_ind = 0, d_occ = 0, tot_ind = 0, tot_occ = 0; // this ray's rank among the emitting rays of the chunk, in slot order
-	if (SORT) {
-		const uint32_t word = src >> 5, lower = (1u << (src & 31)) - 1u;
-#pragma unroll
-		for (uint32_t w = 0; w < 8; w++) {
-			const uint32_t wi = s_emit[0][w], wo = s_emit[1][w];
-			d_ind += w < word ? __popc(wi) : (w == word ? __popc(wi & lower) : 0);
-			d_occ += w < word ? __popc(wo) : (w == word ? __popc(wo & lower) : 0);
+	if (wave * 64 < cnt) { // (uniform per wave)
+		ShadeOut R;
+		R.emit_ind = R.emit_occ = false;
+		R.hit = R.miss = R.emit = 0;
+		uint32_t canon = 0;
+		if (tid < cnt) {
+			canon = FIRST ? tid : canonical_index(pmask, (uint32_t)fbits(t4.w));
+			const uint32_t seed = A.seeds[(size_t)(A.first_sample + s) * A.seed_stride + 1 + A.bounce];
+			shade_ray(S, A, s, seed, st.pfx[blockIdx.x] + canon, d4, t4, h4, R);
 		}
-	} else {
-		d_ind = __popcll(m_ind & below); d_occ = __popcll(m_occ & below);
-#pragma unroll
-		for (int w = 0; w < 4; w++)
-			if (w < (int)wave) { d_ind += wave_ind[w]; d_occ += wave_occ[w]; }
+		// ---- append the wave's rays to the chunk ------------------------------------------------
+		const unsigned long long m_ind = __ballot(R.emit_ind), m_occ = __ballot(R.emit_occ);
+		const unsigned long long mh = __ballot(R.hit != 0), mm = __ballot(R.miss != 0), me = __ballot(R.emit != 0);
+		uint32_t at_ind = 0, at_occ = 0;
+		if (lane == 0) {
+			if (m_ind) at_ind = atomicAdd(&s_tot[0], (uint32_t)__popcll(m_ind));
+			if (m_occ) at_occ = atomicAdd(&s_tot[1], (uint32_t)__popcll(m_occ));
+			if (mh) atomicAdd(&s_tot[2], (uint32_t)__popcll(mh));
+			if (mm) atomicAdd(&s_tot[3], (uint32_t)__popcll(mm));
+			if (me) atomicAdd(&s_tot[4], (uint32_t)__popcll(me));
+		}
+		at_ind = __builtin_amdgcn_readfirstlane(at_ind);
+		at_occ = __builtin_amdgcn_readfirstlane(at_occ);
+		if (R.emit_ind) {
+			atomicOr(&s_emit[canon >> 5], 1u << (canon & 31));
+			const size_t d = base + at_ind + __popcll(m_ind & below);
+			R.thr.w = ibits((int)canon); // the child's parent, in canonical order
+			st.ray_o[d] = R.ro; st.ray_d[d] = R.rd; st.thr[d] = R.thr;
+		}
+		if (R.emit_occ) {
+			const size_t d = base + at_occ + __popcll(m_occ & below);
+			st.occ_o[d] = R.oo; st.occ_d[d] = R.od; st.occ_e[d] = R.oe;
+		}
 	}
-#pragma unroll
-	for (int w = 0; w < 4; w++) { tot_ind += wave_ind[w]; tot_occ += wave_occ[w]; }
-	if (R.emit_ind) {
-		const size_t d = base + d_ind;
-		st.ray_o[d] = R.ro; st.ray_d[d] = R.rd; st.thr[d] = R.thr;
-	}
-	if (R.emit_occ) {
-		const size_t d = base + d_occ;
-		st.occ_o[d] = R.oo; st.occ_d[d] = R.od; st.occ_e[d] = R.oe;
-	}
-	if (tid == 0) {
-		st.cnt_ray[blockIdx.x] = tot_ind;
-		st.cnt_occ[blockIdx.x] = tot_occ;
-		// no global atomics here: 32 Ki workgroups adding to three shared counters serialise at the
-		// memory side (~80 atomics/us on one address); k_scan sums these words instead
-		uint32_t nh = 0, nm = 0, ne = 0;
-#pragma unroll
-		for (int w = 0; w < 4; w++) { nh += wave_stat[w][0]; nm += wave_stat[w][1]; ne += wave_stat[w][2]; }
-		st.wg_stat[blockIdx.x] = nh | (nm << 10) | (ne << 20);
+	// ---- the last wave to get here publishes the chunk's counts and emit mask -------------------
+	__threadfence_block();
+	uint32_t arrived = 0;
+	if (lane == 0) arrived = atomicAdd(&s_tot[5], 1u);
+	if (__builtin_amdgcn_readfirstlane(arrived) == 3u) {
+		__threadfence_block();
+		if (lane == 0) {
+			st.cnt_ray[blockIdx.x] = s_tot[0];
+			st.cnt_occ[blockIdx.x] = s_tot[1];
+			// no global atomics here: 32 Ki workgroups adding to three shared counters serialise at the
+			// memory side (~80 atomics/us on one address); k_scan sums these words instead
+			st.wg_stat[blockIdx.x] = s_tot[2] | (s_tot[3] << 10) | (s_tot[4] << 20);
+		}
+		if (lane < 8) A.emask_out[(size_t)blockIdx.x * 8 + lane] = s_emit[lane];
 	}
 }
 
@@ -1056,13 +1083,16 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5, 5))) void
 // rays 64 at a time: a chunk with <= 64 survivors costs one pass of one wave instead of a
 // four-wave workgroup, and no __syncthreads is needed.  In-place safety: pass j reads slots
 // [64j, 64j+64) and writes at positions <= 64j + lane, i.e. only where this wave has already read.
+// Same canonical-order protocol as k_shade (never the first bounce).
 template <bool LDS>
 __global__ __launch_bounds__(WG) void k_shade_wave(Streams st, SceneDev Sg, ShadeArgs A, uint32_t num_chunks) {
 	__shared__ ShadeLds lds;
 	__shared__ uint32_t wg_cursor;
+	__shared__ uint32_t w_emit[4][8]; // per wave: the emit mask of the chunk it is working on
 	if (threadIdx.x == 0) wg_cursor = 0;
+	if (threadIdx.x < 32) w_emit[threadIdx.x >> 3][threadIdx.x & 7] = 0;
 	const SceneT<LDS> S = stage_scene<LDS>(Sg, lds); // (ends in the __syncthreads that also publishes wg_cursor)
-	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const unsigned long long below = (1ull << lane) - 1ull;
 	const uint32_t wgs_per_sample = A.Npad / WG;
 	for (;;) {
@@ -1077,15 +1107,25 @@ __global__ __launch_bounds__(WG) void k_shade_wave(Streams st, SceneDev Sg, Shad
 			const uint32_t seed = A.seeds[(size_t)(A.first_sample + s) * A.seed_stride + 1 + A.bounce];
 			const uint32_t pfx = st.pfx[chunk];
 			const size_t base = (size_t)chunk * WG;
+			uint32_t pmask[8];
+#pragma unroll
+			for (int w = 0; w < 8; w++) pmask[w] = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.emask_in[(size_t)chunk * 8 + w]);
 			for (uint32_t j = 0; j < cnt; j += 64) {
 				const uint32_t idx = j + lane;
 				ShadeOut R;
 				R.emit_ind = R.emit_occ = false;
 				R.hit = R.miss = R.emit = 0;
-				if (idx < cnt) shade_ray(S, A, s, seed, pfx + idx, st.ray_d[base + idx], st.thr[base + idx], st.hit[base + idx], R);
+				uint32_t canon = 0;
+				if (idx < cnt) {
+					const float4 t4 = st.thr[base + idx];
+					canon = canonical_index(pmask, (uint32_t)fbits(t4.w));
+					shade_ray(S, A, s, seed, pfx + canon, st.ray_d[base + idx], t4, st.hit[base + idx], R);
+				}
 				const unsigned long long m_ind = __ballot(R.emit_ind), m_occ = __ballot(R.emit_occ);
 				if (R.emit_ind) {
+					atomicOr(&w_emit[wave][canon >> 5], 1u << (canon & 31));
 					const size_t d = base + out_ind + __popcll(m_ind & below);
+					R.thr.w = ibits((int)canon);
 					st.ray_o[d] = R.ro; st.ray_d[d] = R.rd; st.thr[d] = R.thr;
 				}
 				if (R.emit_occ) {
@@ -1103,6 +1143,10 @@ __global__ __launch_bounds__(WG) void k_shade_wave(Streams st, SceneDev Sg, Shad
 			st.cnt_ray[chunk] = out_ind;
 			st.cnt_occ[chunk] = out_occ;
 			st.wg_stat[chunk] = n_hit | (n_miss << 10) | (n_emit << 20);
+		}
+		if (lane < 8) { // (LDS operations of one wave execute in order: the atomics above are done)
+			A.emask_out[(size_t)chunk * 8 + lane] = w_emit[wave][lane];
+			w_emit[wave][lane] = 0;
 		}
 	}
 }

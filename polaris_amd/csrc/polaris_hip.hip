@@ -222,6 +222,8 @@ int ensure_streams(polaris_hip_tracer *h, int p, size_t slots, bool want_inst) {
 	rc |= dev_alloc(h, P.bufs, &P.st.cnt_occ, wgs);
 	rc |= dev_alloc(h, P.bufs, &P.st.pfx, wgs);
 	rc |= dev_alloc(h, P.bufs, &P.st.wg_stat, wgs);
+	rc |= dev_alloc(h, P.bufs, &P.st.emask[0], wgs * 8);
+	rc |= dev_alloc(h, P.bufs, &P.st.emask[1], wgs * 8);
 	if (want_inst) rc |= dev_alloc(h, P.bufs, &P.st.hit_inst, slots);
 	if (rc) { free_pool(P.bufs); P.st = Streams{}; return rc; }
 	P.slots = slots;
@@ -319,23 +321,24 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 		}
 		A.bounce = b;
 		A.last_bounce = (b + 1 == B) ? 1 : 0;
+		A.emask_in = b == 0 ? nullptr : P.st.emask[(b + 1) & 1]; // the masks the previous step wrote
+		A.emask_out = P.st.emask[b & 1];
 		{
 			Timed t(h, "shade", q);
-			if (h->opt_shade_wave && (int)b >= (h->opt_shade_wave_from >= 0 ? h->opt_shade_wave_from : (int)r->min_bounces_for_rr + 1)) {
+			if (h->opt_shade_wave && b > 0 && (int)b >= (h->opt_shade_wave_from >= 0 ? h->opt_shade_wave_from : (int)r->min_bounces_for_rr + 1)) { // (never the first bounce: k_shade_wave reads the previous step's emit masks)
 				const uint32_t grid = std::min<uint32_t>(wgs, (uint32_t)h->num_cus * (uint32_t)std::max(1, h->opt_shade_wgs_per_cu));
 				if (staged) hipLaunchKernelGGL(k_shade_wave<true>, dim3(grid), dim3(WG), 0, q, P.st, h->scene, A, wgs);
 				else hipLaunchKernelGGL(k_shade_wave<false>, dim3(grid), dim3(WG), 0, q, P.st, h->scene, A, wgs);
 			} else {
 				// bounce rays are shaded in the order of their material's shading class (kernels.h, k_shade SORT); camera rays are
 				// coherent as they come (64 neighbouring pixels per wave)
-				const bool sorted = h->scene.tri_bits < 31 && (int)b >= (h->opt_shade_sort >= 0 ? h->opt_shade_sort : 1);
-				if (staged) {
-					if (sorted) hipLaunchKernelGGL((k_shade<true, true>), dim3(wgs), dim3(WG), 0, q, P.st, h->scene, A);
-					else hipLaunchKernelGGL((k_shade<true, false>), dim3(wgs), dim3(WG), 0, q, P.st, h->scene, A);
-				} else {
-					if (sorted) hipLaunchKernelGGL((k_shade<false, true>), dim3(wgs), dim3(WG), 0, q, P.st, h->scene, A);
-					else hipLaunchKernelGGL((k_shade<false, false>), dim3(wgs), dim3(WG), 0, q, P.st, h->scene, A);
-				}
+				const bool sorted = b > 0 && h->scene.tri_bits < 31 && (int)b >= (h->opt_shade_sort >= 0 ? h->opt_shade_sort : 1);
+				const void *fn;
+				if (b == 0) fn = staged ? (const void *)k_shade<true, false, true> : (const void *)k_shade<false, false, true>;
+				else if (sorted) fn = staged ? (const void *)k_shade<true, true, false> : (const void *)k_shade<false, true, false>;
+				else fn = staged ? (const void *)k_shade<true, false, false> : (const void *)k_shade<false, false, false>;
+				void *args[] = {(void *)&P.st, (void *)&h->scene, (void *)&A};
+				(void)hipLaunchKernel(fn, dim3(wgs), dim3(WG), args, 0, q);
 			}
 		}
 		{
