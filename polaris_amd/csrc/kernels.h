@@ -764,17 +764,19 @@ struct ShadeArgs {
 };
 
 struct ShadeOut {
-	bool emit_ind, emit_occ;
-	float4 ro, rd, thr, oo, od, oe; // new indirect ray (origin|maxDist, dir|path word, throughput), shadow ray, NEE radiance
+	bool emit_ind;
+	float4 ro, rd, thr;             // new indirect ray (origin|maxDist, dir|path word, throughput)
 	uint32_t hit, miss, emit;       // event flags for the counters
 };
 
 // One ray through shadeHits / shade*RayMisses.  `gid_ref` is the ray's position in the reference's
 // compacted buffer (PRNG state, pt_integrator.cl:81), `sample` the sample the workgroup belongs to.
-template <bool LDS>
+// The shadow ray (origin|maxDist, dir|accumulator cell, NEE radiance) is handed to `occ_sink` the moment it exists -- the
+// kernels store it right there (shadow rays have no order to keep), so its 11 registers are free for the rest of the ray.
+template <bool LDS, class OccSink>
 __device__ __forceinline__ void shade_ray(const SceneT<LDS> &S, const ShadeArgs &A, uint32_t sample, uint32_t seed, uint32_t gid_ref,
-                                          float4 d4, float4 t4, float4 h4, ShadeOut &R) {
-	R.emit_ind = R.emit_occ = false;
+                                          float4 d4, float4 t4, float4 h4, ShadeOut &R, OccSink occ_sink) {
+	R.emit_ind = false;
 	R.hit = R.miss = R.emit = 0;
 	const uint32_t pword = (uint32_t)fbits(d4.w);
 	const uint32_t path_index = pword & 0xFFFFFFu;
@@ -865,10 +867,8 @@ __device__ __forceinline__ void shade_ray(const SceneT<LDS> &S, const ShadeArgs 
 		if (want_nee) {
 			e_rad = e_rad * (e_weight * bxdf_e_val * thr * n_dot_e / (e_pdf * sel_pdf)); // :160
 			if (maxcomp(e_rad) > 0.0f) {
-				R.emit_occ = true;
-				R.oo = make_float4(occ_origin.x, occ_origin.y, occ_origin.z, e_dist - kLightEps); // :203
-				R.od = make_float4(e_dir.x, e_dir.y, e_dir.z, ibits((int)cell));
-				R.oe = make_float4(e_rad.x, e_rad.y, e_rad.z, 0.0f);
+				occ_sink(make_float4(occ_origin.x, occ_origin.y, occ_origin.z, e_dist - kLightEps), // :203
+				         make_float4(e_dir.x, e_dir.y, e_dir.z, ibits((int)cell)), make_float4(e_rad.x, e_rad.y, e_rad.z, 0.0f));
 			}
 		}
 	}
@@ -1027,36 +1027,38 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5, 5))) void
 	}
 	if (wave * 64 < cnt) { // (uniform per wave)
 		ShadeOut R;
-		R.emit_ind = R.emit_occ = false;
+		R.emit_ind = false;
 		R.hit = R.miss = R.emit = 0;
 		uint32_t canon = 0;
 		if (tid < cnt) {
 			canon = FIRST ? tid : canonical_index(pmask, (uint32_t)fbits(t4.w));
 			const uint32_t seed = A.seeds[(size_t)(A.first_sample + s) * A.seed_stride + 1 + A.bounce];
-			shade_ray(S, A, s, seed, st.pfx[blockIdx.x] + canon, d4, t4, h4, R);
+			shade_ray(S, A, s, seed, st.pfx[blockIdx.x] + canon, d4, t4, h4, R, [&](float4 oo, float4 od, float4 oe) {
+				// the lanes that get here emit a shadow ray: one of them reserves their slots, all store at once
+				const unsigned long long m = __ballot(true);
+				const int first = __ffsll((long long)m) - 1;
+				uint32_t at = 0;
+				if ((int)lane == first) at = atomicAdd(&s_tot[1], (uint32_t)__popcll(m));
+				const size_t d = base + (uint32_t)__builtin_amdgcn_readlane((int)at, first) + __popcll(m & below);
+				st.occ_o[d] = oo; st.occ_d[d] = od; st.occ_e[d] = oe;
+			});
 		}
 		// ---- append the wave's rays to the chunk ------------------------------------------------
-		const unsigned long long m_ind = __ballot(R.emit_ind), m_occ = __ballot(R.emit_occ);
+		const unsigned long long m_ind = __ballot(R.emit_ind);
 		const unsigned long long mh = __ballot(R.hit != 0), mm = __ballot(R.miss != 0), me = __ballot(R.emit != 0);
-		uint32_t at_ind = 0, at_occ = 0;
+		uint32_t at_ind = 0;
 		if (lane == 0) {
 			if (m_ind) at_ind = atomicAdd(&s_tot[0], (uint32_t)__popcll(m_ind));
-			if (m_occ) at_occ = atomicAdd(&s_tot[1], (uint32_t)__popcll(m_occ));
 			if (mh) atomicAdd(&s_tot[2], (uint32_t)__popcll(mh));
 			if (mm) atomicAdd(&s_tot[3], (uint32_t)__popcll(mm));
 			if (me) atomicAdd(&s_tot[4], (uint32_t)__popcll(me));
 		}
 		at_ind = __builtin_amdgcn_readfirstlane(at_ind);
-		at_occ = __builtin_amdgcn_readfirstlane(at_occ);
 		if (R.emit_ind) {
 			atomicOr(&s_emit[canon >> 5], 1u << (canon & 31));
 			const size_t d = base + at_ind + __popcll(m_ind & below);
 			R.thr.w = ibits((int)canon); // the child's parent, in canonical order
 			st.ray_o[d] = R.ro; st.ray_d[d] = R.rd; st.thr[d] = R.thr;
-		}
-		if (R.emit_occ) {
-			const size_t d = base + at_occ + __popcll(m_occ & below);
-			st.occ_o[d] = R.oo; st.occ_d[d] = R.od; st.occ_e[d] = R.oe;
 		}
 	}
 	// ---- the last wave to get here publishes the chunk's counts and emit mask -------------------
@@ -1089,7 +1091,9 @@ __global__ __launch_bounds__(WG) void k_shade_wave(Streams st, SceneDev Sg, Shad
 	__shared__ ShadeLds lds;
 	__shared__ uint32_t wg_cursor;
 	__shared__ uint32_t w_emit[4][8]; // per wave: the emit mask of the chunk it is working on
+	__shared__ uint32_t w_occ[4];     // ... and its shadow rays so far
 	if (threadIdx.x == 0) wg_cursor = 0;
+	if (threadIdx.x < 4) w_occ[threadIdx.x] = 0;
 	if (threadIdx.x < 32) w_emit[threadIdx.x >> 3][threadIdx.x & 7] = 0;
 	const SceneT<LDS> S = stage_scene<LDS>(Sg, lds); // (ends in the __syncthreads that also publishes wg_cursor)
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1101,7 +1105,7 @@ __global__ __launch_bounds__(WG) void k_shade_wave(Streams st, SceneDev Sg, Shad
 		const uint32_t chunk = blockIdx.x + __builtin_amdgcn_readfirstlane(c) * gridDim.x;
 		if (chunk >= num_chunks) break;
 		const uint32_t cnt = st.cnt_ray[chunk];
-		uint32_t out_ind = 0, out_occ = 0, n_hit = 0, n_miss = 0, n_emit = 0;
+		uint32_t out_ind = 0, n_hit = 0, n_miss = 0, n_emit = 0;
 		if (cnt != 0) {
 			const uint32_t s = chunk / wgs_per_sample;
 			const uint32_t seed = A.seeds[(size_t)(A.first_sample + s) * A.seed_stride + 1 + A.bounce];
@@ -1113,35 +1117,38 @@ __global__ __launch_bounds__(WG) void k_shade_wave(Streams st, SceneDev Sg, Shad
 			for (uint32_t j = 0; j < cnt; j += 64) {
 				const uint32_t idx = j + lane;
 				ShadeOut R;
-				R.emit_ind = R.emit_occ = false;
+				R.emit_ind = false;
 				R.hit = R.miss = R.emit = 0;
 				uint32_t canon = 0;
 				if (idx < cnt) {
 					const float4 t4 = st.thr[base + idx];
 					canon = canonical_index(pmask, (uint32_t)fbits(t4.w));
-					shade_ray(S, A, s, seed, pfx + canon, st.ray_d[base + idx], t4, st.hit[base + idx], R);
+					shade_ray(S, A, s, seed, pfx + canon, st.ray_d[base + idx], t4, st.hit[base + idx], R, [&](float4 oo, float4 od, float4 oe) {
+						const unsigned long long m = __ballot(true);
+						const int first = __ffsll((long long)m) - 1;
+						uint32_t at = 0;
+						if ((int)lane == first) at = atomicAdd(&w_occ[wave], (uint32_t)__popcll(m));
+						const size_t d = base + (uint32_t)__builtin_amdgcn_readlane((int)at, first) + __popcll(m & below);
+						st.occ_o[d] = oo; st.occ_d[d] = od; st.occ_e[d] = oe;
+					});
 				}
-				const unsigned long long m_ind = __ballot(R.emit_ind), m_occ = __ballot(R.emit_occ);
+				const unsigned long long m_ind = __ballot(R.emit_ind);
 				if (R.emit_ind) {
 					atomicOr(&w_emit[wave][canon >> 5], 1u << (canon & 31));
 					const size_t d = base + out_ind + __popcll(m_ind & below);
 					R.thr.w = ibits((int)canon);
 					st.ray_o[d] = R.ro; st.ray_d[d] = R.rd; st.thr[d] = R.thr;
 				}
-				if (R.emit_occ) {
-					const size_t d = base + out_occ + __popcll(m_occ & below);
-					st.occ_o[d] = R.oo; st.occ_d[d] = R.od; st.occ_e[d] = R.oe;
-				}
 				out_ind += __popcll(m_ind);
-				out_occ += __popcll(m_occ);
 				n_hit += __popcll(__ballot(R.hit != 0));
 				n_miss += __popcll(__ballot(R.miss != 0));
 				n_emit += __popcll(__ballot(R.emit != 0));
 			}
 		}
-		if (lane == 0) {
+		if (lane == 0) { // (LDS operations of one wave execute in order: the atomics above are done)
 			st.cnt_ray[chunk] = out_ind;
-			st.cnt_occ[chunk] = out_occ;
+			st.cnt_occ[chunk] = w_occ[wave];
+			w_occ[wave] = 0;
 			st.wg_stat[chunk] = n_hit | (n_miss << 10) | (n_emit << 20);
 		}
 		if (lane < 8) { // (LDS operations of one wave execute in order: the atomics above are done)
