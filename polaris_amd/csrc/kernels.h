@@ -1078,82 +1078,93 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5, 5))) void
 	}
 }
 
-// k_shade_wave: the same shading with a WAVE as the unit of work.  k_shade's launch time is
-// (#chunks / resident workgroups) x (latency chain of one workgroup) however few rays a chunk
-// still holds, so the sparse late bounces cost as much as the dense first one.  Here persistent
-// waves pull chunks (dealt round-robin to workgroups, LDS cursor inside) and walk a chunk's live
-// rays 64 at a time: a chunk with <= 64 survivors costs one pass of one wave instead of a
-// four-wave workgroup, and no __syncthreads is needed.  In-place safety: pass j reads slots
-// [64j, 64j+64) and writes at positions <= 64j + lane, i.e. only where this wave has already read.
-// Same canonical-order protocol as k_shade (never the first bounce).
+// k_shade_wave: the same shading with a WAVE as the unit of work, for the sparse late bounces.  k_shade's launch time is
+// (#chunks / resident workgroups) x (latency chain of one workgroup) however few rays a chunk still holds, so the sparse
+// bounces cost as much as the dense first one.  Here persistent waves pull GROUPS of kSparseGroup consecutive chunks
+// (dealt round-robin to workgroups, LDS cursor inside) and walk the group's live rays 64 at a time, chunk after chunk:
+// after Russian roulette a chunk holds ~20 rays, so one pass shades the survivors of about three chunks with full lanes
+// (round 1 walked one chunk per pass: 11 % of the lanes of a VALU instruction were live).  Every lane knows its ray's
+// chunk (its sample, seed, reference position and emit mask are per lane); outputs go to the ray's own chunk through
+// per-chunk LDS counters (same canonical-order protocol as k_shade; never the first bounce).
+// In-place safety: a chunk's rays are read in slot order, a pass's reads precede its writes (program order of one wave),
+// and a chunk never holds more emitted rays than rays already read from it.
+constexpr int kSparseGroup = 8;
 template <bool LDS>
 __global__ __launch_bounds__(WG) void k_shade_wave(Streams st, SceneDev Sg, ShadeArgs A, uint32_t num_chunks) {
+	constexpr int G = kSparseGroup;
 	__shared__ ShadeLds lds;
 	__shared__ uint32_t wg_cursor;
-	__shared__ uint32_t w_emit[4][8]; // per wave: the emit mask of the chunk it is working on
-	__shared__ uint32_t w_occ[4];     // ... and its shadow rays so far
+	__shared__ uint32_t w_emit[4][G][8]; // per wave and chunk of its group: the emit mask
+	__shared__ uint32_t w_cnt[4][G][3];  // ... indirect rays, shadow rays, event counters (hits | misses << 10 | emitter hits << 20)
 	if (threadIdx.x == 0) wg_cursor = 0;
-	if (threadIdx.x < 4) w_occ[threadIdx.x] = 0;
-	if (threadIdx.x < 32) w_emit[threadIdx.x >> 3][threadIdx.x & 7] = 0;
-	const SceneT<LDS> S = stage_scene<LDS>(Sg, lds); // (ends in the __syncthreads that also publishes wg_cursor)
+	for (uint32_t i = threadIdx.x; i < 4 * G * 8; i += WG) (&w_emit[0][0][0])[i] = 0;
+	for (uint32_t i = threadIdx.x; i < 4 * G * 3; i += WG) (&w_cnt[0][0][0])[i] = 0;
+	const SceneT<LDS> S = stage_scene<LDS>(Sg, lds); // (ends in the __syncthreads that also publishes the LDS words above)
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const unsigned long long below = (1ull << lane) - 1ull;
 	const uint32_t wgs_per_sample = A.Npad / WG;
+	const uint32_t num_groups = (num_chunks + G - 1) / G;
 	for (;;) {
 		uint32_t c = 0;
 		if (lane == 0) c = atomicAdd(&wg_cursor, 1u);
-		const uint32_t chunk = blockIdx.x + __builtin_amdgcn_readfirstlane(c) * gridDim.x;
-		if (chunk >= num_chunks) break;
-		const uint32_t cnt = st.cnt_ray[chunk];
-		uint32_t out_ind = 0, n_hit = 0, n_miss = 0, n_emit = 0;
-		if (cnt != 0) {
-			const uint32_t s = chunk / wgs_per_sample;
-			const uint32_t seed = A.seeds[(size_t)(A.first_sample + s) * A.seed_stride + 1 + A.bounce];
-			const uint32_t pfx = st.pfx[chunk];
-			const size_t base = (size_t)chunk * WG;
-			uint32_t pmask[8];
+		const uint32_t group = blockIdx.x + __builtin_amdgcn_readfirstlane(c) * gridDim.x;
+		if (group >= num_groups) break;
+		const uint32_t chunk0 = group * G;
+		// lane k < G holds chunk k's live count and the group's exclusive prefix over them
+		const uint32_t my_cnt = (lane < (uint32_t)G && chunk0 + lane < num_chunks) ? st.cnt_ray[chunk0 + lane] : 0u;
+		uint32_t incl = my_cnt;
 #pragma unroll
-			for (int w = 0; w < 8; w++) pmask[w] = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.emask_in[(size_t)chunk * 8 + w]);
-			for (uint32_t j = 0; j < cnt; j += 64) {
-				const uint32_t idx = j + lane;
-				ShadeOut R;
-				R.emit_ind = false;
-				R.hit = R.miss = R.emit = 0;
-				uint32_t canon = 0;
-				if (idx < cnt) {
-					const float4 t4 = st.thr[base + idx];
-					canon = canonical_index(pmask, (uint32_t)fbits(t4.w));
-					shade_ray(S, A, s, seed, pfx + canon, st.ray_d[base + idx], t4, st.hit[base + idx], R, [&](float4 oo, float4 od, float4 oe) {
-						const unsigned long long m = __ballot(true);
-						const int first = __ffsll((long long)m) - 1;
-						uint32_t at = 0;
-						if ((int)lane == first) at = atomicAdd(&w_occ[wave], (uint32_t)__popcll(m));
-						const size_t d = base + (uint32_t)__builtin_amdgcn_readlane((int)at, first) + __popcll(m & below);
-						st.occ_o[d] = oo; st.occ_d[d] = od; st.occ_e[d] = oe;
-					});
-				}
-				const unsigned long long m_ind = __ballot(R.emit_ind);
-				if (R.emit_ind) {
-					atomicOr(&w_emit[wave][canon >> 5], 1u << (canon & 31));
-					const size_t d = base + out_ind + __popcll(m_ind & below);
-					R.thr.w = ibits((int)canon);
-					st.ray_o[d] = R.ro; st.ray_d[d] = R.rd; st.thr[d] = R.thr;
-				}
-				out_ind += __popcll(m_ind);
-				n_hit += __popcll(__ballot(R.hit != 0));
-				n_miss += __popcll(__ballot(R.miss != 0));
-				n_emit += __popcll(__ballot(R.emit != 0));
+		for (int d = 1; d < G; d <<= 1) {
+			const uint32_t up = __shfl_up(incl, d);
+			if ((int)lane >= d) incl += up;
+		}
+		const uint32_t excl = incl - my_cnt;
+		const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, G - 1);
+		for (uint32_t j = 0; j < total; j += 64) {
+			const uint32_t r = j + lane; // the group's r-th live ray
+			const bool live = r < total;
+			uint32_t k = 0, first = 0; // its chunk within the group, and the rays of the group before that chunk
+#pragma unroll
+			for (int q = 1; q < G; q++) {
+				const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)excl, q);
+				if (r >= e) { k = q; first = e; }
 			}
+			ShadeOut R;
+			R.emit_ind = false;
+			R.hit = R.miss = R.emit = 0;
+			uint32_t canon = 0;
+			const uint32_t chunk = chunk0 + k;
+			const size_t base = (size_t)chunk * WG;
+			if (live) {
+				const uint32_t idx = r - first;
+				const float4 t4 = st.thr[base + idx];
+				const uint4 m0 = reinterpret_cast<const uint4 *>(A.emask_in)[(size_t)chunk * 2], m1 = reinterpret_cast<const uint4 *>(A.emask_in)[(size_t)chunk * 2 + 1];
+				const uint32_t pmask[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+				canon = canonical_index(pmask, (uint32_t)fbits(t4.w));
+				const uint32_t s = chunk / wgs_per_sample;
+				const uint32_t seed = A.seeds[(size_t)(A.first_sample + s) * A.seed_stride + 1 + A.bounce];
+				shade_ray(S, A, s, seed, st.pfx[chunk] + canon, st.ray_d[base + idx], t4, st.hit[base + idx], R, [&](float4 oo, float4 od, float4 oe) {
+					const size_t d = base + atomicAdd(&w_cnt[wave][k][1], 1u); // (shadow rays have no order to keep)
+					st.occ_o[d] = oo; st.occ_d[d] = od; st.occ_e[d] = oe;
+				});
+			}
+			if (R.emit_ind) {
+				atomicOr(&w_emit[wave][k][canon >> 5], 1u << (canon & 31));
+				const size_t d = base + atomicAdd(&w_cnt[wave][k][0], 1u); // any free slot of the ray's chunk: the order is in thr.w
+				R.thr.w = ibits((int)canon);
+				st.ray_o[d] = R.ro; st.ray_d[d] = R.rd; st.thr[d] = R.thr;
+			}
+			if (live && (R.hit | R.miss | R.emit) != 0) atomicAdd(&w_cnt[wave][k][2], R.hit | (R.miss << 10) | (R.emit << 20));
 		}
-		if (lane == 0) { // (LDS operations of one wave execute in order: the atomics above are done)
-			st.cnt_ray[chunk] = out_ind;
-			st.cnt_occ[chunk] = w_occ[wave];
-			w_occ[wave] = 0;
-			st.wg_stat[chunk] = n_hit | (n_miss << 10) | (n_emit << 20);
+		// publish the group's chunks (LDS operations of one wave execute in order: the atomics above are done) and clear the wave's words
+		if (lane < (uint32_t)G && chunk0 + lane < num_chunks) {
+			st.cnt_ray[chunk0 + lane] = w_cnt[wave][lane][0];
+			st.cnt_occ[chunk0 + lane] = w_cnt[wave][lane][1];
+			st.wg_stat[chunk0 + lane] = w_cnt[wave][lane][2];
+			w_cnt[wave][lane][0] = 0; w_cnt[wave][lane][1] = 0; w_cnt[wave][lane][2] = 0;
 		}
-		if (lane < 8) { // (LDS operations of one wave execute in order: the atomics above are done)
-			A.emask_out[(size_t)chunk * 8 + lane] = w_emit[wave][lane];
-			w_emit[wave][lane] = 0;
+		for (uint32_t i = lane; i < (uint32_t)G * 8; i += 64) {
+			if (chunk0 + i / 8 < num_chunks) A.emask_out[(size_t)chunk0 * 8 + i] = (&w_emit[wave][0][0])[i];
+			(&w_emit[wave][0][0])[i] = 0;
 		}
 	}
 }
