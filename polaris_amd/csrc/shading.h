@@ -357,30 +357,43 @@ template <bool LDS> PD f3 mirror_value(const Surf &sf, const MatT<LDS> &m, const
 	return iDotN != 0.0f ? f * ks / iDotN : splat(0.0f);
 }
 
-// bxdfGetSample, bxdf/bxdf.cl:31-55
+// bxdfGetSample, bxdf/bxdf.cl:31-55.
+// The five BxDFs of the reference are five separate functions; a wave that holds several of them executes each one's code in
+// turn.  Where two of them perform the SAME operations on the same operands -- the Fresnel / total-reflection prologue of
+// the two dielectrics, the GGX half-vector sample, and the whole reflection branch of the two rough BxDFs (mirror the
+// incoming direction about the sampled half vector, re-derive the half vector, pdf, equation 20) -- the code exists once and
+// the lanes of both types run it together; every lane still performs exactly its own BxDF's operation sequence.
 template <bool LDS> PD f3 bxdf_sample(const Surf &sf, const MatT<LDS> &m, const SceneT<LDS> &S, f2 rnd, f3 i, f3 &o, float &pdf) {
 	const f3 n = sf.n;
-	switch (m.type) {
-	case POLARIS_BXDF_DIFFUSE: { // diffuse.cl:12-20
+	if (m.type == POLARIS_BXDF_DIFFUSE) { // diffuse.cl:12-20
 		o = cosine_hemisphere(n, rnd);
 		pdf = dot(n, o) * kInvPi;
 		return m.kcol * kInvPi;
 	}
-	case POLARIS_BXDF_CONDUCTOR: { // conductor.cl:12-30
-		float iDotN = dot(i, n);
+	const float iDotN = dot(i, n);
+	if (m.type == POLARIS_BXDF_CONDUCTOR) { // conductor.cl:12-30
 		o = 2.0f * iDotN * n - i;
 		pdf = 1.0f;
 		return mirror_value(sf, m, S, iDotN);
 	}
-	case POLARIS_BXDF_DIELECTRIC: { // dielectric.cl:12-45 (cosTSq uses eta, not eta^2: quirk kept)
-		float iDotN = dot(i, n);
-		float etaI = m.ext_ior, etaT = m.int_ior;
+	const bool rough = (m.type & (POLARIS_BXDF_ROUGH_CONDUCTOR | POLARIS_BXDF_ROUGH_DIELECTRIC)) != 0;
+	const bool diel = (m.type & (POLARIS_BXDF_DIELECTRIC | POLARIS_BXDF_ROUGH_DIELECTRIC)) != 0;
+	if (!rough && !diel) return splat(0.0f); // emissive / invalid leaves have no BxDF (bxdf.cl:53)
+	// dielectric.cl:13-27 == rough_dielectric.cl:11-30: orient the interface, Fresnel term, total internal reflection
+	// (cosTSq uses eta, not eta^2: quirk kept); rough_conductor.cl:22-24: Fresnel term of the conductor
+	float etaI = m.ext_ior, etaT = m.int_ior, eta = 0.0f, f, cosTSq = 1.0f;
+	if (diel) {
 		if (iDotN < 0.0f) { float t = etaI; etaI = etaT; etaT = t; }
-		float eta = etaI / etaT;
-		float f = schlick(etaI, etaT, iDotN);
+		eta = etaI / etaT;
+		f = schlick(etaI, etaT, iDotN);
+		cosTSq = 1.0f + eta * (iDotN * iDotN - 1.0f);
+	} else {
+		f = m.int_ior != 0.0f ? schlick(m.ext_ior, m.int_ior, iDotN) : 1.0f;
+	}
+	const bool reflects = !diel || cosTSq <= 0.0f || rnd.x <= f;
+	if (!rough) { // dielectric.cl:28-45
 		f3 kVal;
-		float cosTSq = 1.0f + eta * (iDotN * iDotN - 1.0f);
-		if (cosTSq <= 0.0f || rnd.x <= f) {
+		if (reflects) {
 			o = -pm_sign(iDotN) * 2.0f * iDotN * n - i;
 			kVal = m.kcol;
 			pdf = cosTSq <= 0.0f ? 1.0f : f;
@@ -391,55 +404,39 @@ template <bool LDS> PD f3 bxdf_sample(const Surf &sf, const MatT<LDS> &m, const 
 		}
 		return iDotN != 0.0f ? pdf * kVal / pm_fabs(iDotN) : splat(0.0f);
 	}
-	case POLARIS_BXDF_ROUGH_CONDUCTOR: { // rough_conductor.cl:10-40
-		float a = m.alpha;
-		const f3 ks = m.kcol;
-		f3 h = ggx_sample(a, n, rnd);
-		o = 2.0f * dot(i, h) * h - i;
-		pdf = ggx_reflect_pdf(a, o, n, h);
-		float iDotN = dot(i, n);
-		h = normalize(i + o);
-		float f = m.int_ior != 0.0f ? schlick(m.ext_ior, m.int_ior, iDotN) : 1.0f;
-		return specular_tail(sf, a, ks, f, i, o, h);
+	const float a = m.alpha;
+	const f3 hs = ggx_sample(a, n, rnd); // rough_conductor.cl:14, rough_dielectric.cl:24
+	if (reflects) { // rough_conductor.cl:15-39 and the reflection branch of rough_dielectric.cl:32-56
+		o = 2.0f * dot(i, hs) * hs - i;
+		const f3 h = normalize(i + o);
+		// the conductor's pdf is taken about the SAMPLED half vector, the dielectric's about the re-derived one
+		const bool conductor = m.type == POLARIS_BXDF_ROUGH_CONDUCTOR;
+		const f3 hp = {conductor ? hs.x : h.x, conductor ? hs.y : h.y, conductor ? hs.z : h.z};
+		const float p = ggx_reflect_pdf(a, o, n, hp);
+		pdf = (!conductor && cosTSq <= 0.0f) ? 1.0f : p;
+		return specular_tail(sf, a, m.kcol, f, i, o, h);
 	}
-	case POLARIS_BXDF_ROUGH_DIELECTRIC: { // rough_dielectric.cl:10-94
-		float iDotN = dot(i, n);
-		float a = m.alpha;
-		float etaI = m.ext_ior, etaT = m.int_ior;
-		if (iDotN < 0.0f) { float t = etaI; etaI = etaT; etaT = t; }
-		float eta = etaI / etaT;
-		f3 h = ggx_sample(a, n, rnd);
-		float f = schlick(etaI, etaT, iDotN);
-		float cosTSq = 1.0f + eta * (iDotN * iDotN - 1.0f);
-		if (cosTSq <= 0.0f || rnd.x <= f) {
-			o = 2.0f * dot(i, h) * h - i;
-			const f3 ks = m.kcol;
-			h = normalize(i + o);
-			pdf = cosTSq <= 0.0f ? 1.0f : ggx_reflect_pdf(a, o, n, h);
-			return specular_tail(sf, a, ks, f, i, o, h);
-		}
-		o = (eta * iDotN - pm_sign(iDotN) * pm_sqrt(cosTSq)) * h - eta * i;
-		h = normalize(-(etaI * i + etaT * o));
-		pdf = ggx_refract_pdf(a, etaI, etaT, i, o, n, h);
-		return transmit_tail(sf, m, S, a, etaI, etaT, f, iDotN, i, o, h);
-	}
-	}
-	return splat(0.0f);
+	// refraction branch of rough_dielectric.cl:58-93
+	o = (eta * iDotN - pm_sign(iDotN) * pm_sqrt(cosTSq)) * hs - eta * i;
+	const f3 h = normalize(-(etaI * i + etaT * o));
+	pdf = ggx_refract_pdf(a, etaI, etaT, i, o, n, h);
+	return transmit_tail(sf, m, S, a, etaI, etaT, f, iDotN, i, o, h);
 }
 
 // bxdfGetPdf (bxdf.cl:58-78) and bxdfEval (bxdf.cl:82-105) for a given outgoing direction,
-// evaluated together (the NEE path of shadeHits needs both for the same direction).
+// evaluated together (the NEE path of shadeHits needs both for the same direction).  The reflection side of the rough
+// dielectric is, operation for operation, the rough conductor: one copy (see bxdf_sample).
 template <bool LDS> PD void bxdf_pdf_eval(const Surf &sf, const MatT<LDS> &m, const SceneT<LDS> &S, f3 i, f3 o, bool want_eval, float &pdf, f3 &val) {
 	const f3 n = sf.n;
 	pdf = 0.0f;
 	val = splat(0.0f);
-	switch (m.type) {
-	case POLARIS_BXDF_DIFFUSE: // diffuse.cl:24-32
+	if (m.type == POLARIS_BXDF_DIFFUSE) { // diffuse.cl:24-32
 		pdf = dot(n, o) * kInvPi;
 		if (want_eval) val = m.kcol * kInvPi;
 		return;
-	case POLARIS_BXDF_CONDUCTOR: { // conductor.cl:33-62
-		float iDotN = dot(i, n);
+	}
+	const float iDotN = dot(i, n);
+	if (m.type == POLARIS_BXDF_CONDUCTOR) { // conductor.cl:33-62
 		f3 e = 2.0f * iDotN * n - i;
 		float ed = dot(e, o);
 		bool match = ed >= 0.0f && ed <= 0.001f;
@@ -447,43 +444,26 @@ template <bool LDS> PD void bxdf_pdf_eval(const Surf &sf, const MatT<LDS> &m, co
 		if (want_eval && match) val = mirror_value(sf, m, S, iDotN);
 		return;
 	}
-	case POLARIS_BXDF_DIELECTRIC: // dielectric.cl:49-60: always 0
-		return;
-	case POLARIS_BXDF_ROUGH_CONDUCTOR: { // rough_conductor.cl:43-78
-		float a = m.alpha;
-		f3 h = normalize(i + o);
+	if ((m.type & (POLARIS_BXDF_ROUGH_CONDUCTOR | POLARIS_BXDF_ROUGH_DIELECTRIC)) == 0) return; // dielectric.cl:49-60: always 0
+	const float a = m.alpha;
+	const bool conductor = m.type == POLARIS_BXDF_ROUGH_CONDUCTOR;
+	if (conductor || iDotN > 0.0f) { // rough_conductor.cl:43-78; rough_dielectric.cl:97-166, incoming direction on the outside
+		const f3 h = normalize(i + o);
 		pdf = ggx_reflect_pdf(a, o, n, h);
 		if (want_eval) {
-			const f3 ks = m.kcol;
-			float iDotN = dot(i, n);
-			float f = m.int_ior != 0.0f ? schlick(m.ext_ior, m.int_ior, iDotN) : 1.0f;
-			val = specular_tail(sf, a, ks, f, i, o, h);
+			// (the dielectric's interface is not flipped on this side: its Fresnel term is the conductor's expression)
+			const float f = (conductor && m.int_ior == 0.0f) ? 1.0f : schlick(m.ext_ior, m.int_ior, iDotN);
+			val = specular_tail(sf, a, m.kcol, f, i, o, h);
 		}
 		return;
 	}
-	case POLARIS_BXDF_ROUGH_DIELECTRIC: { // rough_dielectric.cl:97-166
-		float iDotN = dot(i, n);
-		float a = m.alpha;
-		float etaI = m.ext_ior, etaT = m.int_ior;
-		if (iDotN < 0.0f) { float t = etaI; etaI = etaT; etaT = t; }
-		if (iDotN > 0.0f) {
-			f3 h = normalize(i + o);
-			pdf = ggx_reflect_pdf(a, o, n, h);
-			if (want_eval) {
-				float f = schlick(etaI, etaT, iDotN);
-				const f3 ks = m.kcol;
-				val = specular_tail(sf, a, ks, f, i, o, h);
-			}
-		} else {
-			f3 h = normalize(-(etaI * i + etaT * o));
-			pdf = ggx_refract_pdf(a, etaI, etaT, i, o, n, h);
-			if (want_eval) {
-				float f = schlick(etaI, etaT, iDotN);
-				val = transmit_tail(sf, m, S, a, etaI, etaT, f, iDotN, i, o, h);
-			}
-		}
-		return;
-	}
+	float etaI = m.ext_ior, etaT = m.int_ior;
+	if (iDotN < 0.0f) { float t = etaI; etaI = etaT; etaT = t; }
+	const f3 h = normalize(-(etaI * i + etaT * o));
+	pdf = ggx_refract_pdf(a, etaI, etaT, i, o, n, h);
+	if (want_eval) {
+		const float f = schlick(etaI, etaT, iDotN);
+		val = transmit_tail(sf, m, S, a, etaI, etaT, f, iDotN, i, o, h);
 	}
 }
 
