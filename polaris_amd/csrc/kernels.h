@@ -68,11 +68,6 @@ struct Streams {
 	// chunk in reference order) in thr.w, and emask[bounce parity][chunk][8] has bit c set when the parent with canonical
 	// index c emitted a ray -- so a ray's own canonical index is the number of set bits below its parent's.
 	uint32_t *emask[2];
-	// Rays of shading classes too rare in their chunk to fill a wave are shaded by k_shade_rare, gathered across chunks:
-	// q_rec[(class * kQShards + shard) * q_cap + i] = {ray_d, thr, hit, (chunk, reference position, canonical index, -)},
-	// q_cnt[class * kQShards + shard] = records queued (shard = chunk % kQShards keeps the appends off one counter).
-	float4 *q_rec;
-	uint32_t *q_cnt;
 	int *hit_inst; // optional (test tap): instance id per slot, may be null
 };
 
@@ -764,8 +759,6 @@ struct ShadeArgs {
 	int last_bounce;   // no closest-hit query follows (pipeline.go:203): do not emit indirect rays
 	int exact;         // accumulate into acc[pixelIndex] (trace accumulator) instead of lsum[path slot]
 	float4 *acc;       // trace accumulator (exact) or lsum (batched)
-	uint32_t q_cap;           // records per (class, shard) queue: kDeferBelow x chunks per shard, so a queue cannot overflow
-	uint32_t defer_mask;      // bit c: rays of shading class c may be deferred to k_shade_rare (0 = nothing is deferred)
 	const uint32_t *emask_in; // emit masks of the previous shade step (null at bounce 0: canonical index = slot index)
 	uint32_t *emask_out;      // ... of this one
 };
@@ -941,9 +934,6 @@ __device__ __forceinline__ SceneT<LDS> stage_scene(const SceneDev &Sg, ShadeLds 
 	return S;
 }
 
-constexpr uint32_t kQShards = 256;   // queues per shading class (k_shade_rare)
-constexpr uint32_t kDeferBelow = 32; // a class with fewer rays than this in a chunk is shaded across chunks instead
-
 // Canonical index of a ray within its chunk = its position in the reference's compacted buffer relative to the chunk's
 // first ray: the number of emitting parents (bits of the previous step's emit mask) below its own parent.
 __device__ __forceinline__ uint32_t canonical_index(const uint32_t (&mask)[8], uint32_t parent) {
@@ -1005,7 +995,6 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5, 5))) void
 	const SceneT<LDS> S = stage_scene<LDS>(Sg, lds, [&]() { if (!SORT) asm volatile("" ::"v"(d4.w), "v"(t4.w), "v"(h4.w)); });
 	const uint32_t s = blockIdx.x / (A.Npad / WG);
 	const unsigned long long below = (1ull << lane) - 1ull;
-	uint32_t live_rays = cnt; // rays this workgroup shades itself
 	if (SORT) {
 		uint32_t key = 16; // no ray
 		if (tid < cnt) {
@@ -1014,58 +1003,34 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5, 5))) void
 		}
 		if (lane < 16) s_cnt[wave][lane] = 0; // (LDS operations of one wave execute in order)
 		uint32_t rank_in = 0;
-		int lead = 0; // the wave's first lane that holds a ray of this lane's class
 		unsigned long long todo = __ballot(key < 16);
 		while (todo != 0ull) { // one round per class present in this wave
 			const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, __ffsll((long long)todo) - 1);
 			const unsigned long long m = __ballot(key == k);
-			if (key == k) { rank_in = __popcll(m & below); lead = __ffsll((long long)m) - 1; }
+			if (key == k) rank_in = __popcll(m & below);
 			if (lane == 0) s_cnt[wave][k] = __popcll(m);
 			todo &= ~m;
 		}
 		__syncthreads();
-		// lane l holds the count of (class l / 4, wave l % 4).  A class with fewer than kDeferBelow rays in this chunk cannot
-		// fill a wave here: its rays are DEFERRED -- queued for k_shade_rare, which shades each class in full waves gathered
-		// across chunks -- instead of forming this chunk's "mixed bag" wave, the one wave that executes every BxDF's code
-		// for a handful of rays each (after the sort it was 60 % of the workgroup's VALU instructions).
+		// exclusive scan of the 64 counts in (class, wave) order, by every wave for itself
 		const uint32_t mine = s_cnt[lane & 3][lane >> 2];
-		uint32_t ctot = mine;
-		ctot += __shfl_xor(ctot, 1);
-		ctot += __shfl_xor(ctot, 2); // the class's rays in the chunk
-		const bool cdef = ctot != 0 && ctot < kDeferBelow && ((A.defer_mask >> (lane >> 2)) & 1u) != 0;
-		const unsigned long long defm = __ballot(cdef); // bits 4c..4c+3: class c is deferred
-		// exclusive scan of the kept counts in (class, wave) order, by every wave for itself
-		const uint32_t kept = cdef ? 0u : mine;
-		uint32_t incl = kept;
+		uint32_t incl = mine;
 #pragma unroll
 		for (int d = 1; d < 64; d <<= 1) {
 			const uint32_t up = __shfl_up(incl, d);
 			if ((int)lane >= d) incl += up;
 		}
-		const uint32_t dest = __shfl(incl - kept, (int)((key & 15u) * 4 + wave)) + rank_in;
-		live_rays = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-		const bool deferred = key < 16 && ((defm >> ((key & 15u) * 4)) & 1ull) != 0;
-		if (key < 16 && !deferred) { x_d[dest] = d4; x_t[dest] = t4; x_h[dest] = h4; }
-		const uint32_t q = (key & 15u) * kQShards + blockIdx.x % kQShards;
-		uint32_t qbase = 0;
-		if (deferred && rank_in == 0) qbase = atomicAdd(&st.q_cnt[q], s_cnt[wave][key]); // the wave's rays of a class go out together
-		qbase = (uint32_t)__shfl((int)qbase, lead);
-		if (deferred) {
-			const uint32_t at = qbase + rank_in;
-			const uint32_t canon = canonical_index(pmask, (uint32_t)fbits(t4.w));
-			float4 *rec = st.q_rec + ((size_t)q * A.q_cap + at) * 4;
-			rec[0] = d4; rec[1] = t4; rec[2] = h4;
-			rec[3] = make_float4(ibits((int)blockIdx.x), ibits((int)(st.pfx[blockIdx.x] + canon)), ibits((int)canon), 0.0f);
-		}
+		const uint32_t dest = __shfl(incl - mine, (int)((key & 15u) * 4 + wave)) + rank_in;
+		if (key < 16) { x_d[dest] = d4; x_t[dest] = t4; x_h[dest] = h4; }
 		__syncthreads();
-		if (tid < live_rays) { d4 = x_d[tid]; t4 = x_t[tid]; h4 = x_h[tid]; }
+		if (tid < cnt) { d4 = x_d[tid]; t4 = x_t[tid]; h4 = x_h[tid]; }
 	}
-	if (wave * 64 < live_rays) { // (uniform per wave)
+	if (wave * 64 < cnt) { // (uniform per wave)
 		ShadeOut R;
 		R.emit_ind = false;
 		R.hit = R.miss = R.emit = 0;
 		uint32_t canon = 0;
-		if (tid < live_rays) {
+		if (tid < cnt) {
 			canon = FIRST ? tid : canonical_index(pmask, (uint32_t)fbits(t4.w));
 			const uint32_t seed = A.seeds[(size_t)(A.first_sample + s) * A.seed_stride + 1 + A.bounce];
 			shade_ray(S, A, s, seed, st.pfx[blockIdx.x] + canon, d4, t4, h4, R, [&](float4 oo, float4 od, float4 oe) {
@@ -1110,78 +1075,6 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5, 5))) void
 			st.wg_stat[blockIdx.x] = s_tot[2] | (s_tot[3] << 10) | (s_tot[4] << 20);
 		}
 		if (lane < 8) A.emask_out[(size_t)blockIdx.x * 8 + lane] = s_emit[lane];
-	}
-}
-
-// k_shade_rare: the rays k_shade deferred (classes too rare in their chunk to fill a wave), one shading class at a time
-// in full waves gathered across chunks.  Runs after k_shade of the same bounce (same stream) and before k_scan: k_shade's
-// last waves have published every chunk's counts and emit mask; a deferred ray's outputs are appended to ITS chunk on
-// top of those -- slots through returning atomics on the chunk's counters, the emit-mask bit through an atomic OR (its
-// canonical index travelled with it).  All inputs of a chunk were consumed by k_shade (the deferred rays were copied into
-// the queue), so every slot of the chunk is free to write.  A queue's records come in runs of one chunk (a wave of
-// k_shade appends its rays of a class together): the lanes of a run share one atomic per counter.
-struct LaneRun { unsigned long long lanes; int head; }; // the active lanes that hold records of this lane's chunk, and the first of them
-__device__ __forceinline__ LaneRun lane_run(uint32_t chunk, uint32_t lane) {
-	const unsigned long long act = __ballot(true);
-	const unsigned long long lower = act & ((1ull << lane) - 1ull);
-	const int prev = lower ? 63 - __clzll((long long)lower) : (int)lane; // the active lane before this one
-	const uint32_t before = (uint32_t)__shfl((int)chunk, prev); // (every active lane takes part: a lane that sat the shuffle out would not be readable)
-	const bool is_head = lower == 0ull || before != chunk;
-	const unsigned long long heads = __ballot(is_head);
-	const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
-	LaneRun r;
-	r.head = 63 - __clzll((long long)(heads & upto));
-	const unsigned long long after = r.head == 63 ? 0ull : (heads & ~((2ull << r.head) - 1ull));
-	const unsigned long long to_next = after ? ((1ull << (__ffsll((long long)after) - 1)) - 1ull) : ~0ull;
-	r.lanes = to_next & ~((1ull << r.head) - 1ull) & act;
-	return r;
-}
-// The lanes of a run that `emit` get consecutive slots from the run's chunk counter: one returning atomic per run.
-__device__ __forceinline__ uint32_t run_append(uint32_t *counter, bool emit, const LaneRun &run, uint32_t lane) {
-	const unsigned long long em = __ballot(emit) & run.lanes;
-	uint32_t base = 0;
-	if ((int)lane == run.head && em) base = atomicAdd(counter, (uint32_t)__popcll(em));
-	return (uint32_t)__shfl((int)base, run.head) + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
-}
-
-template <bool LDS>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_shade_rare(Streams st, SceneDev Sg, ShadeArgs A) {
-	__shared__ ShadeLds lds;
-	const SceneT<LDS> S = stage_scene<LDS>(Sg, lds);
-	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const uint32_t wgs_per_sample = A.Npad / WG;
-	// queue q (one shading class, one shard) belongs to workgroup q % gridDim.x; its four waves take its 64-record slices in turn
-	for (uint32_t q = kQShards + blockIdx.x; q < 16 * kQShards; q += gridDim.x) { // (class 0 = misses: never deferred)
-		const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.q_cnt[q]);
-		for (uint32_t off = wave * 64; off < n; off += 4 * 64) {
-			const uint32_t r = off + lane;
-			if (r >= n) continue; // (the tail of a queue: the wave-level operations below see the active lanes only)
-			const float4 *rec = st.q_rec + ((size_t)q * A.q_cap + r) * 4;
-			const float4 d4 = rec[0], t4 = rec[1], h4 = rec[2], m4 = rec[3];
-			const uint32_t chunk = (uint32_t)fbits(m4.x), gid = (uint32_t)fbits(m4.y), canon = (uint32_t)fbits(m4.z);
-			const LaneRun run = lane_run(chunk, lane);
-			const uint32_t s = chunk / wgs_per_sample;
-			const uint32_t seed = A.seeds[(size_t)(A.first_sample + s) * A.seed_stride + 1 + A.bounce];
-			const size_t base = (size_t)chunk * WG;
-			ShadeOut R;
-			R.emit_ind = false;
-			R.hit = R.miss = R.emit = 0;
-			bool emit_occ = false;
-			float4 oo = make_float4(0, 0, 0, 0), od = oo, oe = oo;
-			shade_ray(S, A, s, seed, gid, d4, t4, h4, R, [&](float4 a, float4 b, float4 c) { emit_occ = true; oo = a; od = b; oe = c; });
-			const uint32_t at_occ = run_append(&st.cnt_occ[chunk], emit_occ, run, lane);
-			if (emit_occ) { st.occ_o[base + at_occ] = oo; st.occ_d[base + at_occ] = od; st.occ_e[base + at_occ] = oe; }
-			const uint32_t at_ind = run_append(&st.cnt_ray[chunk], R.emit_ind, run, lane);
-			if (R.emit_ind) {
-				atomicOr(&A.emask_out[(size_t)chunk * 8 + (canon >> 5)], 1u << (canon & 31));
-				R.thr.w = ibits((int)canon);
-				st.ray_o[base + at_ind] = R.ro; st.ray_d[base + at_ind] = R.rd; st.thr[base + at_ind] = R.thr;
-			}
-			// the run's event counters, one atomic per run
-			const uint32_t ev = (uint32_t)__popcll(__ballot(R.hit != 0) & run.lanes) | ((uint32_t)__popcll(__ballot(R.miss != 0) & run.lanes) << 10) |
-			                    ((uint32_t)__popcll(__ballot(R.emit != 0) & run.lanes) << 20);
-			if ((int)lane == run.head && ev) atomicAdd(&st.wg_stat[chunk], ev);
-		}
 	}
 }
 

@@ -71,7 +71,6 @@ struct polaris_hip_tracer {
 	struct Pipe {
 		hipStream_t q = nullptr;
 		size_t slots = 0; // capacity in slots
-		uint32_t q_cap = 0; // records per (class, shard) queue of k_shade_rare
 		Streams st{};
 		std::vector<DevBuf> bufs;
 		hipEvent_t done = nullptr; // recorded after the pipe's last resolve
@@ -100,8 +99,6 @@ struct polaris_hip_tracer {
 	int opt_shade_wgs_per_cu = 3;
 	int opt_shade_wave_from = -1; // first bounce shaded by k_shade_wave; -1 = the bounce AFTER Russian roulette starts thinning the
 	                              // chunks (min_bounces_for_rr + 1: the RR bounce itself still shades dense chunks); earlier bounces use k_shade
-	int opt_shade_defer = 1; // 1 = shading classes too rare in a chunk to fill a wave are shaded across chunks (k_shade_rare)
-	uint32_t defer_mask = 0; // classes that may be deferred (resolved at upload)
 	int opt_shade_sort = -1; // first bounce whose rays k_shade groups by shading class; -1 = default (1), POLARIS_MAX_BOUNCES = never
 	int opt_traversal = 1; // 1 = persistent waves with lane refill (k_trace), 0 = one ray per lane (k_intersect/k_occlusion)
 
@@ -227,11 +224,6 @@ int ensure_streams(polaris_hip_tracer *h, int p, size_t slots, bool want_inst) {
 	rc |= dev_alloc(h, P.bufs, &P.st.wg_stat, wgs);
 	rc |= dev_alloc(h, P.bufs, &P.st.emask[0], wgs * 8);
 	rc |= dev_alloc(h, P.bufs, &P.st.emask[1], wgs * 8);
-	// the queues of k_shade_rare: kDeferBelow records per class and chunk bound what a (class, shard) queue can receive
-	P.q_cap = kDeferBelow * (uint32_t)((wgs + kQShards - 1) / kQShards);
-	rc |= dev_alloc(h, P.bufs, &P.st.q_rec, (size_t)16 * kQShards * P.q_cap * 4);
-	rc |= dev_alloc(h, P.bufs, &P.st.q_cnt, (size_t)16 * kQShards);
-	if (!rc && hipMemsetAsync(P.st.q_cnt, 0, 16 * kQShards * sizeof(uint32_t), P.q) != hipSuccess) rc = POLARIS_E_DEVICE;
 	if (want_inst) rc |= dev_alloc(h, P.bufs, &P.st.hit_inst, slots);
 	if (rc) { free_pool(P.bufs); P.st = Streams{}; return rc; }
 	P.slots = slots;
@@ -331,8 +323,6 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 		A.last_bounce = (b + 1 == B) ? 1 : 0;
 		A.emask_in = b == 0 ? nullptr : P.st.emask[(b + 1) & 1]; // the masks the previous step wrote
 		A.emask_out = P.st.emask[b & 1];
-		A.q_cap = P.q_cap;
-		A.defer_mask = 0;
 		{
 			Timed t(h, "shade", q);
 			if (h->opt_shade_wave && b > 0 && (int)b >= (h->opt_shade_wave_from >= 0 ? h->opt_shade_wave_from : (int)r->min_bounces_for_rr + 1)) { // (never the first bounce: k_shade_wave reads the previous step's emit masks)
@@ -346,20 +336,12 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 				// bounce rays are shaded in the order of their material's shading class (kernels.h, k_shade SORT); camera rays are
 				// coherent as they come (64 neighbouring pixels per wave)
 				const bool sorted = b > 0 && h->scene.tri_bits < 31 && (int)b >= (h->opt_shade_sort >= 0 ? h->opt_shade_sort : 1);
-				const bool defer = sorted && h->opt_shade_defer && h->defer_mask != 0;
-				if (defer) A.defer_mask = h->defer_mask;
 				const void *fn;
 				if (b == 0) fn = staged ? (const void *)k_shade<true, false, true> : (const void *)k_shade<false, false, true>;
 				else if (sorted) fn = staged ? (const void *)k_shade<true, true, false> : (const void *)k_shade<false, true, false>;
 				else fn = staged ? (const void *)k_shade<true, false, false> : (const void *)k_shade<false, false, false>;
 				void *args[] = {(void *)&P.st, (void *)&h->scene, (void *)&A};
 				(void)hipLaunchKernel(fn, dim3(wgs), dim3(WG), args, 0, q);
-				if (defer) { // the rays k_shade left to be shaded across chunks (kernels.h, k_shade_rare), then the queues are emptied
-					const uint32_t grid = (uint32_t)h->num_cus * 4u; // persistent: what the GPU holds at once (4 workgroups per CU at its register count)
-					if (staged) hipLaunchKernelGGL(k_shade_rare<true>, dim3(grid), dim3(WG), 0, q, P.st, h->scene, A);
-					else hipLaunchKernelGGL(k_shade_rare<false>, dim3(grid), dim3(WG), 0, q, P.st, h->scene, A);
-					(void)hipMemsetAsync(P.st.q_cnt, 0, 16 * kQShards * sizeof(uint32_t), q);
-				}
 			}
 		}
 		{
@@ -576,9 +558,6 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 	h->scene = SceneDev{vertices, normals, uvs, mat_index, nodes, emissives, tex_meta, tex_data, sc->num_emissives,
 	                    sc->scene_diffuse_mat_index, sc->num_material_nodes, sc->num_textures, light_geo, L.tri_bits};
 	h->max_stack = L.max_stack;
-	h->defer_mask = 0; // every class that reaches a BxDF (classes of emissive-only trees and the miss class are cheap where they are)
-	for (int c = 1; c < 16; c++)
-		if (L.class_reach[c] & ~1u) h->defer_mask |= 1u << c;
 	if (h->opt_packet_primary < 0) h->packet_primary = sc->num_triangles <= 262144u;
 	// node records: whole tree in LDS for tiny scenes, its top for small ones, global memory otherwise (kernels.h NodeMode)
 	const bool tiny_ok = L.pairs.size() <= (size_t)kTinyPairs && L.tris.size() <= kTinyMaxIndex && L.leaves.size() <= kTinyMaxIndex && L.max_stack <= 16;
@@ -619,7 +598,6 @@ int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value
 	else if (k == "shade_wave_from") h->opt_shade_wave_from = (int)std::max<int64_t>(-1, std::min<int64_t>(value, POLARIS_MAX_BOUNCES));
 	else if (k == "shade_wgs_per_cu") h->opt_shade_wgs_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(value, 64));
 	else if (k == "stage_lds") h->opt_stage_lds = value != 0;
-	else if (k == "shade_defer") h->opt_shade_defer = value != 0;
 	else if (k == "shade_sort") h->opt_shade_sort = (int)std::max<int64_t>(-1, std::min<int64_t>(value, POLARIS_MAX_BOUNCES));
 	else if (k == "overlap") h->opt_overlap = (int)std::max<int64_t>(1, std::min<int64_t>(value, polaris_hip_tracer::kMaxPipes));
 	else if (k == "trace_wgs_per_cu") h->opt_trace_wgs_per_cu = (int)std::max<int64_t>(0, std::min<int64_t>(value, 64));

@@ -59,15 +59,13 @@ struct SceneLayout {
 	// triangles, else 31 = no class).  The traversal kernels hand the word through to the hit record untouched; k_shade
 	// sorts a workgroup's rays by the class and masks it off.
 	uint32_t tri_bits = 31;
-	uint32_t class_reach[16] = {0}; // per shading class: the reach set it stands for (bit 0 emissive, 1 diffuse, 2 conductor, 3 rough
-	                                // conductor, 4 dielectric, 5 rough dielectric, 6 invalid, 7 textured operator, 8 dispersion)
 };
 
 // Shading class of every material node = which BxDF leaves and texture operators the tree rooted at it can reach.  k_shade
 // groups the rays of a workgroup by the class of the triangle's material root before shading them (rays of one class run
 // the same code, so a wave is no longer the union of five BxDF paths).  A sort key, nothing else: results do not depend on
 // it.  Classes 1..15 (0 is "the ray missed"); scenes with more distinct reach sets share class 15.
-inline void shading_classes(const PolarisSceneView &sc, std::vector<uint8_t> &cls, uint32_t class_reach[16]) {
+inline void shading_classes(const PolarisSceneView &sc, std::vector<uint8_t> &cls) {
 	const uint32_t n = sc.num_material_nodes;
 	std::vector<uint32_t> reach(n, 0);
 	std::vector<uint8_t> state(n, 0); // 0 new, 1 on the walk, 2 done
@@ -112,7 +110,6 @@ inline void shading_classes(const PolarisSceneView &sc, std::vector<uint8_t> &cl
 	for (uint32_t i = 0; i < n; i++) {
 		const size_t k = (size_t)(std::lower_bound(distinct.begin(), distinct.end(), reach[i]) - distinct.begin());
 		cls[i] = (uint8_t)std::min<size_t>(1 + k, 15);
-		class_reach[cls[i]] |= reach[i];
 	}
 }
 
@@ -627,7 +624,7 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out, in
 	}
 
 	std::vector<uint8_t> node_class;
-	shading_classes(sc, node_class, out.class_reach);
+	shading_classes(sc, node_class);
 	out.tri_bits = NT <= (1u << 24) ? 24 : 31;
 	out.tris.assign(n_slots, TriH{});
 	for (uint32_t s = 0; s < n_slots; s++) {
