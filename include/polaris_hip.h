@@ -152,7 +152,11 @@ int polaris_hip_tap_primary(polaris_hip_tracer *h, const PolarisBlockRequest *re
  *        in [n][2] = uv;  out[n][7] = texGetSample3f[3] | texGetSample1f | texGetBumpSample3f[3]
  *   kind 2, emissive `index` (samplers/emissive_sampler.cl:176-223):
  *        in [n][11] = point[3] normal[3] sample[2] pdf_dir[3]
- *        out[n][9]  = emissiveGetSample radiance[3] dir[3] pdf dist | emissiveGetPdf(pdf_dir) */
+ *        out[n][9]  = emissiveGetSample radiance[3] dir[3] pdf dist | emissiveGetPdf(pdf_dir)
+ *   kind 3, material tree rooted at node `index` (matSelectNode, samplers/material_sampler.cl:21-95):
+ *        in [n][8]  = normal[3] uv[2] | shading PRNG state[2] and path dispersion flags as bit patterns
+ *        out[n][18] = selected leaf type (bits), int / ext IOR after the dispersion override | normal after bump / normal
+ *                     maps[3] | tint[3] | path flags (bits) | PRNG state[2] (bits) | the leaf's k[3] and t[3] */
 int polaris_hip_probe(polaris_hip_tracer *h, int kind, uint32_t index, uint32_t n, const float *in, float *out);
 
 /* rayIntersectionQuery (any_hit = 0, kernels/intersect.cl:184-347) or rayIntersectionTest (any_hit != 0, :26-180) over n

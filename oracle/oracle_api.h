@@ -76,6 +76,12 @@ typedef struct PolarisOracleTaps {
 	void prefix##_emissive_probe(const PolarisSceneView *scene, uint32_t emissive_index,      \
 	                             const float point[3], const float normal[3],                 \
 	                             const float sample[2], const float pdf_dir[3], float out[9]); \
+	/* matSelectNode (samplers/material_sampler.cl:21-95) from material node `root` of the scene, with the path's dispersion    \
+	 * flags and the shading PRNG state as they stand: out[0] = type of the selected leaf (bits), out[1..2] = its int / ext IOR \
+	 * after the dispersion override, out[3..5] = surface normal after bump / normal maps, out[6..8] = tint, out[9] = path      \
+	 * flags (bits), out[10..11] = PRNG state (bits), out[12..14] / [15..17] = the leaf's k / t vectors (which leaf was chosen) */ \
+	void prefix##_material_probe(const PolarisSceneView *scene, uint32_t root, const float normal[3], const float uv[2],      \
+	                             const uint32_t rng_state[2], uint32_t path_flags, float out[18]);                           \
 	/* rayIntersectionQuery (any_hit = 0, intersect.cl:184-347) or rayIntersectionTest (any_hit \
 	 * != 0, :26-180) over n arbitrary rays [n][8] = origin.xyz, maxDist, dir.xyz, unused:       \
 	 * hit[n]; for closest hits also wuvt[n][4] and inst_tri[n][2] (either may be NULL) */       \

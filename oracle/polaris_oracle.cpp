@@ -1231,6 +1231,25 @@ extern "C" void polaris_oracle_emissive_probe(const PolarisSceneView *sc, uint32
 	out[8] = emissiveGetPdf(&sf, em, R, ld3(pdf_dir));
 }
 
+extern "C" void polaris_oracle_material_probe(const PolarisSceneView *sc, uint32_t root, const float normal[3], const float uv[2],
+                                              const uint32_t rng_state[2], uint32_t path_flags, float out[18]) {
+	Path path;
+	memset(&path, 0, sizeof path);
+	path.flags = path_flags;
+	Surface sf{zero3(), ld3(normal), ld2(uv), root};
+	MatNode m;
+	V3 tint = v3(1.0f, 1.0f, 1.0f);
+	uint32_t rnd[2] = {rng_state[0], rng_state[1]};
+	matSelectNode(&path, &sf, zero3(), &m, &tint, sc->material_nodes, rnd, sc->texture_meta, sc->texture_data);
+	memcpy(&out[0], &m.type, 4);
+	out[1] = m.int_ior; out[2] = m.ext_ior;
+	out[3] = sf.normal.x; out[4] = sf.normal.y; out[5] = sf.normal.z;
+	out[6] = tint.x; out[7] = tint.y; out[8] = tint.z;
+	memcpy(&out[9], &path.flags, 4);
+	memcpy(&out[10], &rnd[0], 4); memcpy(&out[11], &rnd[1], 4);
+	for (int k = 0; k < 3; k++) { out[12 + k] = m.k[k]; out[15 + k] = m.t[k]; }
+}
+
 extern "C" const char *polaris_oracle_describe(void) {
 	return "CPU restatement of tracer/opencl (oracle/polaris_oracle.cpp); built-ins: polaris_math.h; OpenMP";
 }

@@ -69,6 +69,9 @@ class Oracle:
         self._trace, self._tonemap, self._random = f("trace"), f("tonemap"), f("random")
         self._bxdf, self._tex, self._emissive, self._describe = f("bxdf_probe"), f("tex_probe"), f("emissive_probe"), f("describe")
         self._intersect = f("intersect_probe")
+        self._material = f("material_probe")
+        self._material.argtypes = [C.POINTER(T.SceneView), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        self._material.restype = None
         self._intersect.argtypes = [C.POINTER(T.SceneView), C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         vp = C.c_void_p
         self._trace.argtypes = [C.POINTER(T.SceneView), vp, vp, C.POINTER(T.BlockRequest), vp, C.c_size_t, vp,
@@ -145,6 +148,16 @@ class Oracle:
         out = np.zeros(11, dtype=np.float32)
         self._bxdf(node.ctypes.data, T._ptr(tex_meta), T._ptr(tex_data), n.ctypes.data, u.ctypes.data, i.ctypes.data,
                    s.ctypes.data, e.ctypes.data, out.ctypes.data)
+        return out
+
+    def material_probe(self, scene, root, normal, uv, rng_state, path_flags):
+        """matSelectNode from material node `root`: 18 floats (oracle_api.h), integer fields as bit patterns."""
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+        n, u = f(normal), f(uv)
+        st = np.ascontiguousarray(rng_state, dtype=np.uint32)
+        out = np.zeros(18, dtype=np.float32)
+        view = T.scene_view(scene)
+        self._material(C.byref(view), int(root), n.ctypes.data, u.ctypes.data, st.ctypes.data, int(path_flags), out.ctypes.data)
         return out
 
     def tex_probe(self, tex_meta, tex_data, tex_index, uv):

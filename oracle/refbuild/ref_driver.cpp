@@ -70,6 +70,9 @@ float ref_bxdfGetPdf(Surface *, PolarisMaterialNode *, const void *texMeta, cons
     __asm__("_Z10bxdfGetPdfPU9CLgeneric7SurfacePU9CLgeneric12MaterialNodePU8CLglobal15TextureMetadataPU8CLglobalhDv3_fSA_");
 float3 ref_bxdfEval(Surface *, PolarisMaterialNode *, const void *texMeta, const void *texData, float3 inDir, float3 outDir)
     __asm__("_Z8bxdfEvalPU9CLgeneric7SurfacePU9CLgeneric12MaterialNodePU8CLglobal15TextureMetadataPU8CLglobalhDv3_fSA_");
+void ref_matSelectNode(Path *path, Surface *surface, float3 inRayDir, PolarisMaterialNode *selected, float3 *tint, const void *materialNodes,
+                       uint2 *rndState, const void *texMeta, const void *texData)
+    __asm__("_Z13matSelectNodePU8CLglobal4PathPU9CLgeneric7SurfaceDv3_fPU9CLgeneric12MaterialNodePU9CLgenericS5_PU8CLglobalS6_PU9CLgenericDv2_jPU8CLglobal15TextureMetadataPU8CLglobalh");
 float3 ref_texGetSample3f(float2 uv, int texIndex, const void *texMeta, const void *texData)
     __asm__("_Z14texGetSample3fDv2_fiPU8CLglobal15TextureMetadataPU8CLglobalh");
 float ref_texGetSample1f(float2 uv, int texIndex, const void *texMeta, const void *texData)
@@ -288,6 +291,31 @@ extern "C" void polaris_ref_bxdf_probe(const PolarisMaterialNode *node, const Po
 	out[7] = ref_bxdfGetPdf(&sf, &m, tex_meta, tex_data, f3(in_dir), f3(eval_dir));
 	float3 e = ref_bxdfEval(&sf, &m, tex_meta, tex_data, f3(in_dir), f3(eval_dir));
 	out[8] = e.x; out[9] = e.y; out[10] = e.z;
+}
+
+extern "C" void polaris_ref_material_probe(const PolarisSceneView *sc, uint32_t root, const float normal[3], const float uv[2],
+                                           const uint32_t rng_state[2], uint32_t path_flags, float out[18]) {
+	Path path;
+	memset(&path, 0, sizeof path);
+	path.flags = path_flags;
+	Surface sf;
+	sf.point = (float3){0.0f, 0.0f, 0.0f};
+	sf.normal = f3(normal);
+	sf.uv = (float2){uv[0], uv[1]};
+	sf.matNodeIndex = root;
+	PolarisMaterialNode m;
+	memset(&m, 0, sizeof m);
+	float3 tint = {1.0f, 1.0f, 1.0f};
+	uint2 rnd = {rng_state[0], rng_state[1]};
+	ref_matSelectNode(&path, &sf, (float3){0.0f, 0.0f, 0.0f}, &m, &tint, sc->material_nodes, &rnd, sc->texture_meta, sc->texture_data);
+	memcpy(&out[0], &m.type, 4);
+	out[1] = m.int_ior; out[2] = m.ext_ior;
+	out[3] = sf.normal.x; out[4] = sf.normal.y; out[5] = sf.normal.z;
+	out[6] = tint.x; out[7] = tint.y; out[8] = tint.z;
+	memcpy(&out[9], &path.flags, 4);
+	uint32_t r0 = rnd.x, r1 = rnd.y;
+	memcpy(&out[10], &r0, 4); memcpy(&out[11], &r1, 4);
+	for (int k = 0; k < 3; k++) { out[12 + k] = m.k[k]; out[15 + k] = m.t[k]; }
 }
 
 extern "C" void polaris_ref_tex_probe(const PolarisTextureMetadata *tex_meta, const uint8_t *tex_data,

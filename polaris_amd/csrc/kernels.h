@@ -1174,8 +1174,8 @@ __global__ __launch_bounds__(WG) void k_shade_wave(Streams st, SceneDev Sg, Shad
 // lane per probe, through the SAME table staging the shade kernels use -- so the samplers and BxDFs are checked against
 // the CPU oracle on the GPU one function at a time, not only through whole traces.
 // ------------------------------------------------------------------------------------------
-enum ProbeKind { kProbeBxdf = 0, kProbeTexture = 1, kProbeEmissive = 2 };
-constexpr uint32_t kProbeIn[3] = {13, 2, 11}, kProbeOut[3] = {11, 7, 9};
+enum ProbeKind { kProbeBxdf = 0, kProbeTexture = 1, kProbeEmissive = 2, kProbeMaterial = 3 };
+constexpr uint32_t kProbeIn[4] = {13, 2, 11, 8}, kProbeOut[4] = {11, 7, 9, 18};
 
 template <bool LDS>
 __global__ __launch_bounds__(WG) void k_probe(SceneDev Sg, int kind, uint32_t index, uint32_t n, const float *in, float *out) {
@@ -1208,6 +1208,19 @@ __global__ __launch_bounds__(WG) void k_probe(SceneDev Sg, int kind, uint32_t in
 		const TexQuad q = tex_fetch(f2{p[0], p[1]}, (int)index, S);
 		const f3 c = quad_sample3(q), b = quad_bump3(q);
 		o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = c.x; o[4] = b.x; o[5] = b.y; o[6] = b.z;
+	} else if (kind == kProbeMaterial) { // in: normal[3] uv[2] PRNG state[2] (bits) path flags (bits); out: see polaris_hip.h (matSelectNode, material_sampler.cl:21-95)
+		const float *p = in + (size_t)i * 8;
+		float *o = out + (size_t)i * 18;
+		Surf sf;
+		sf.p = splat(0.0f); sf.n = mk3(p[0], p[1], p[2]); sf.uv = {p[3], p[4]};
+		Rng rng = {(uint32_t)fbits(p[5]), (uint32_t)fbits(p[6])};
+		uint32_t flags = (uint32_t)fbits(p[7]);
+		f3 tint = splat(1.0f);
+		const MatT<LDS> m = select_material(index, sf, flags, tint, rng, S);
+		o[0] = ibits((int)m.type); o[1] = m.int_ior; o[2] = m.ext_ior;
+		o[3] = sf.n.x; o[4] = sf.n.y; o[5] = sf.n.z; o[6] = tint.x; o[7] = tint.y; o[8] = tint.z;
+		o[9] = ibits((int)flags); o[10] = ibits((int)rng.sx); o[11] = ibits((int)rng.sy);
+		for (int k = 0; k < 3; k++) { o[12 + k] = m.nd->k[k]; o[15 + k] = m.nd->t[k]; }
 	} else { // in: point[3] normal[3] sample[2] pdf_dir[3]; out: emissiveGetSample radiance[3] dir[3] pdf dist | emissiveGetPdf (emissive_sampler.cl:176-223)
 		const float *p = in + (size_t)i * 11;
 		float *o = out + (size_t)i * 9;

@@ -876,8 +876,8 @@ int polaris_hip_probe(polaris_hip_tracer *h, int kind, uint32_t index, uint32_t 
 	if (!h) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "handle is null");
 	std::lock_guard<std::mutex> lk(h->mu);
 	if (!h->have_scene) return fail(h, POLARIS_E_NO_SCENE_DATA, "no scene data uploaded");
-	if (kind < 0 || kind > 2 || (n && (!in || !out))) return fail(h, POLARIS_E_BAD_ARGUMENT, "probe: bad kind or null buffers");
-	const uint32_t limit = kind == kProbeBxdf ? h->scene.num_nodes : (kind == kProbeTexture ? h->scene.num_textures : h->scene.num_emissives);
+	if (kind < 0 || kind > 3 || (n && (!in || !out))) return fail(h, POLARIS_E_BAD_ARGUMENT, "probe: bad kind or null buffers");
+	const uint32_t limit = (kind == kProbeBxdf || kind == kProbeMaterial) ? h->scene.num_nodes : (kind == kProbeTexture ? h->scene.num_textures : h->scene.num_emissives);
 	if (index >= limit) return fail(h, POLARIS_E_BAD_ARGUMENT, "probe: index %u out of range (%u)", index, limit);
 	if (n == 0) return POLARIS_OK;
 	HIP_TRY(h, hipSetDevice(h->device));

@@ -159,8 +159,8 @@ class HipTracer:
                                                       taps["primary_tri"].ctypes.data), self._h)
         return taps
 
-    PROBE_BXDF, PROBE_TEXTURE, PROBE_EMISSIVE = 0, 1, 2
-    _PROBE_SHAPES = {0: (13, 11), 1: (2, 7), 2: (11, 9)}
+    PROBE_BXDF, PROBE_TEXTURE, PROBE_EMISSIVE, PROBE_MATERIAL = 0, 1, 2, 3
+    _PROBE_SHAPES = {0: (13, 11), 1: (2, 7), 2: (11, 9), 3: (8, 18)}
 
     def probe(self, kind: int, index: int, inputs) -> np.ndarray:
         """Function-level test tap (polaris_hip_probe): rows of `inputs` through the device-side BxDF / texture / light

@@ -3,8 +3,8 @@ of the HIP library, one function at a time, against the CPU oracle on the same i
 (polaris_hip_probe / polaris_hip_probe_intersect).  Bar: bit-exact (NaN where the oracle has NaN).
 
 Reference functions covered: bxdfGetSample / bxdfGetPdf / bxdfEval (bxdf/bxdf.cl:31-105 and the five bxdf/*.cl behind
-them), texGetSample3f / texGetSample1f / texGetBumpSample3f (samplers/texture_sampler.cl:14-252, all four formats, wrap and
-clamp edges), emissiveGetSample / emissiveGetPdf (samplers/emissive_sampler.cl:176-223, area and environment lights),
+them), matSelectNode (samplers/material_sampler.cl:21-95, every operator), texGetSample3f / texGetSample1f /
+texGetBumpSample3f (samplers/texture_sampler.cl:14-252, all four formats, wrap and clamp edges), emissiveGetSample / emissiveGetPdf (samplers/emissive_sampler.cl:176-223, area and environment lights),
 rayIntersectionQuery / rayIntersectionTest (kernels/intersect.cl:26-347) on arbitrary rays through every traversal kernel.
 """
 import numpy as np
@@ -61,6 +61,36 @@ def test_bxdf_probes_equal_the_oracle(built, oracle):
     finally:
         tr.Close()
     assert checked >= 2 * 5 * n
+
+
+@pytest.mark.parametrize("name", ["materials", "cornell"])
+def test_material_walk_probes_equal_the_oracle(built, oracle, name):
+    """matSelectNode (samplers/material_sampler.cl:21-95) from every material node of two scenes -- mixMap, bumpMap,
+    normalMap, disperse (materials), mix (Cornell box) and plain leaves: leaf chosen, normal after the maps, tint,
+    dispersion flags, IOR override, PRNG state left."""
+    from polaris_amd import scenes
+
+    sc = scenes.SCENES[name]()
+    rng = np.random.default_rng(23)
+    n = 500
+    ops = {int(t) for t in sc.material_nodes["type"]}
+    assert ({10002, 10003, 10004, 10005} <= ops) if name == "materials" else (10001 in ops)
+    tr = make_hip_tracer(sc, 8, 8)
+    try:
+        for stage_lds in (1, 0):
+            tr.set_option("stage_lds", stage_lds)
+            for root in range(len(sc.material_nodes)):
+                nrm = unit(rng.normal(size=(n, 3)))
+                uv = rng.uniform(-2, 3, size=(n, 2)).astype(np.float32)
+                st = rng.integers(0, 2 ** 32, size=(n, 2), dtype=np.uint64).astype(np.uint32)
+                flags = rng.choice([0, 0, 1, 2, 4], size=n).astype(np.uint32)
+                rows = np.concatenate([nrm, uv, st.view(np.float32), flags.view(np.float32)[:, None]], axis=1)
+                got = tr.probe(tr.PROBE_MATERIAL, root, rows)
+                for r in range(n):
+                    want = oracle.material_probe(sc, root, nrm[r], uv[r], st[r], int(flags[r]))
+                    assert same_bits(got[r], want), (stage_lds, root, int(sc.material_nodes[root]["type"]), r, got[r], want)
+    finally:
+        tr.Close()
 
 
 def _with_odd_l8(sc):

@@ -100,6 +100,27 @@ def test_texture_probes_bit_exact(oracle, ref_pm):
             assert np.array_equal(bits(a), bits(b)), (t, uv)
 
 
+def test_material_walk_probes_bit_exact(oracle, ref_pm):
+    """matSelectNode (material_sampler.cl:21-95) from every material node of the scene that touches every operator: which
+    leaf is chosen, the bumped / normal-mapped normal, tint, dispersion flags, IOR override and the PRNG state it leaves."""
+    from polaris_amd import scenes
+
+    rng = np.random.default_rng(13)
+    checked = 0
+    for sc in (scenes.textured_materials_scene(), scenes.cornell_box("layered")):  # every operator incl. plain mix (Cornell)
+      for root in range(len(sc.material_nodes)):
+        for _ in range(40):
+            n = _unit(rng.normal(size=3))
+            uv = rng.uniform(-2, 3, size=2).astype(np.float32)
+            st = rng.integers(0, 2 ** 32, size=2, dtype=np.uint64).astype(np.uint32)
+            flags = int(rng.choice([0, 0, 1, 2, 4]))
+            a = ref_pm.material_probe(sc, root, n, uv, st, flags)
+            b = oracle.material_probe(sc, root, n, uv, st, flags)
+            assert np.array_equal(bits(a), bits(b)), (root, int(sc.material_nodes[root]["type"]), a, b)
+            checked += 1
+    assert checked >= 400
+
+
 def test_emissive_probes_bit_exact(oracle, ref_pm):
     from polaris_amd import scenes
 
