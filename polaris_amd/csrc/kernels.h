@@ -1090,7 +1090,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5, 5))) void
 // and a chunk never holds more emitted rays than rays already read from it.
 constexpr int kSparseGroup = 8;
 template <bool LDS>
-__global__ __launch_bounds__(WG) void k_shade_wave(Streams st, SceneDev Sg, ShadeArgs A, uint32_t num_chunks) {
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) // (fits 128 VGPRs without a spill: 4 waves per SIMD instead of 3)
+void k_shade_wave(Streams st, SceneDev Sg, ShadeArgs A, uint32_t num_chunks) {
 	constexpr int G = kSparseGroup;
 	__shared__ ShadeLds lds;
 	__shared__ uint32_t wg_cursor;

@@ -96,7 +96,7 @@ struct polaris_hip_tracer {
 	int opt_max_leaf_tris = -1;   // subdivide bigger triangle leaves at upload (0 = keep the caller's leaves, -1 = by scene size)
 	int opt_stage_lds = 1;    // k_shade stages material nodes / lights / texture metadata in LDS when they fit
 	int opt_shade_wave = 1;   // 1 = persistent wave-per-chunk shading (k_shade_wave), 0 = one workgroup per chunk (k_shade)
-	int opt_shade_wgs_per_cu = 3;
+	int opt_shade_wgs_per_cu = 4;
 	int opt_shade_wave_from = -1; // first bounce shaded by k_shade_wave; -1 = the bounce AFTER Russian roulette starts thinning the
 	                              // chunks (min_bounces_for_rr + 1: the RR bounce itself still shades dense chunks); earlier bounces use k_shade
 	int opt_shade_sort = -1; // first bounce whose rays k_shade groups by shading class; -1 = default (1), POLARIS_MAX_BOUNCES = never
@@ -326,7 +326,7 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 		{
 			Timed t(h, "shade", q);
 			if (h->opt_shade_wave && b > 0 && (int)b >= (h->opt_shade_wave_from >= 0 ? h->opt_shade_wave_from : (int)r->min_bounces_for_rr + 1)) { // (never the first bounce: k_shade_wave reads the previous step's emit masks)
-				// persistent waves pull groups of kSparseGroup chunks: no more workgroups than the GPU holds at once (3 per CU at
+				// persistent waves pull groups of kSparseGroup chunks: no more workgroups than the GPU holds at once (4 per CU at
 				// the kernel's register count) nor than there are groups for their 4 waves
 				const uint32_t groups = (wgs + kSparseGroup - 1) / kSparseGroup;
 				const uint32_t grid = std::max(1u, std::min<uint32_t>((groups + 3) / 4, (uint32_t)h->num_cus * (uint32_t)std::max(1, h->opt_shade_wgs_per_cu)));
