@@ -433,3 +433,17 @@ def test_soak_one_handle_many_shapes_scenes_and_options(built):
 
     start, end, worst = soak.run(150)
     assert start - end < 512
+
+
+def test_results_do_not_depend_on_timing(built):
+    """The shade kernels append a chunk's rays in whatever order their waves finish (the reference order is carried as
+    data: parent's canonical index + emit masks): 25 traces of the same frame per scene must be bit-identical -- radiance
+    and every counter (tests/tools/determinism_stress.py; 150 frames per scene were run once by hand)."""
+    import subprocess
+    import sys
+    import os
+
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "determinism_stress.py")
+    p = subprocess.run([sys.executable, tool, "25"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert p.stdout.count("bit-identical") == 4, p.stdout
