@@ -653,6 +653,49 @@ def textured_materials_scene(aspect=1.0) -> Scene:
     return sc
 
 
+def many_materials_scene(aspect=1.0) -> Scene:
+    """More than 15 distinct material-tree shapes (every pair of the five BxDF families mixed, some under a bump map or a
+    dispersion node) on a grid of small boxes under an area light and an environment light: more shading classes than the
+    HIP backend's sort key holds (classes beyond the 15th share one) -- parity coverage, not a benchmark."""
+    import itertools
+
+    rng = np.random.default_rng(19)
+    mt = MaterialTable()
+    bump = mt.texture(T.TEX_L32F, rng.random((8, 8)).astype(F32))
+
+    def leaf(kind, tint):
+        if kind == 0:
+            return mt.diffuse(tint)
+        if kind == 1:
+            return mt.conductor(tint)
+        if kind == 2:
+            return mt.rough_conductor(tint, roughness=0.3)
+        if kind == 3:
+            return mt.dielectric((1, 1, 1), tint, int_ior=1.5)
+        return mt.rough_dielectric((1, 1, 1), tint, roughness=0.25, int_ior=1.45)
+
+    mats = [leaf(k, (0.8, 0.6, 0.4)) for k in range(5)]
+    for a, b in itertools.combinations(range(5), 2):  # 10 two-family mixes
+        mats.append(mt.mix(leaf(a, (0.7, 0.7, 0.3)), leaf(b, (0.3, 0.6, 0.8)), 0.5))
+    for k in range(5):                                 # each family under a bump map, and two under dispersion
+        mats.append(mt.bump_map(leaf(k, (0.6, 0.8, 0.6)), bump))
+    mats.append(mt.disperse(leaf(3, (1, 1, 1)), (1.45, 1.5, 1.55), (1.0, 1.0, 1.0)))
+    mats.append(mt.disperse(leaf(4, (1, 1, 1)), (1.4, 1.5, 1.6), (1.0, 1.0, 1.0)))
+    floor = mt.diffuse((0.6, 0.6, 0.6))
+    light = mt.emissive((9, 9, 8), 1.5)
+    bg = mt.diffuse((0.25, 0.3, 0.4))
+    env = mt.emissive((0.7, 0.8, 1.0), 0.5)
+    side = 5
+    parts = [quad((-4, 0, -4), (-4, 0, 4), (4, 0, 4), (4, 0, -4), floor),
+             quad((-1.5, 3.5, -1.5), (1.5, 3.5, -1.5), (1.5, 3.5, 1.5), (-1.5, 3.5, 1.5), light)]
+    for i, m in enumerate(mats):
+        x, z = (i % side - (side - 1) / 2) * 1.4, (i // side - 2) * 1.4
+        parts.append(box((x - 0.45, 0, z - 0.45), (x + 0.45, 0.6 + 0.05 * (i % 4), z + 0.45), m, rot_y=0.1 * i))
+    sc = compile_scene([merge(parts)], [(0, np.eye(4))], mt, scene_diffuse=bg, scene_emissive=env, name="many-materials")
+    sc.set_camera(eye=(0, 4.5, 7.0), look=(0, 0.3, 0), fov=0.8, aspect=aspect)
+    return sc
+
+
 def material_ball(aspect=1.0, detail=1.0) -> Scene:
     """Stand-in for BASELINE.json configs[3] ("Mitsuba scene", 1920x1080, 512 spp): the Mitsuba material
     preview ball is not redistributable and there is no network, so this is a procedural scene of the same
@@ -771,6 +814,7 @@ SCENES = {
     "sphere": sphere_scene,
     "cubes": lambda aspect=1.0: instanced_cubes(3, aspect),
     "materials": textured_materials_scene,
+    "many-materials": many_materials_scene,
     "transformed": transformed_instances,
     "instanced": lambda aspect=1.0: instanced_stress(32, aspect=aspect),
     "instanced-small": lambda aspect=1.0: instanced_stress(6, 9, 10, aspect=aspect),

@@ -13,7 +13,7 @@ from conftest import bits, golden_files, load_golden, make_hip_tracer
 
 pytestmark = pytest.mark.gpu
 
-SCENES = ["cornell-diffuse", "cornell", "sphere", "cubes", "materials", "transformed", "material-ball-small"]
+SCENES = ["cornell-diffuse", "cornell", "sphere", "cubes", "materials", "many-materials", "transformed", "material-ball-small"]
 
 
 def rmse(a, b, spp):

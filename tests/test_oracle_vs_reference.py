@@ -11,7 +11,7 @@ import pytest
 from conftest import bits
 
 
-SCENES = ["cornell-diffuse", "cornell", "sphere", "cubes", "materials", "transformed"]
+SCENES = ["cornell-diffuse", "cornell", "sphere", "cubes", "materials", "many-materials", "transformed"]
 
 
 @pytest.mark.parametrize("name", SCENES)
@@ -163,6 +163,6 @@ def test_libm_build_agrees_pixel_by_pixel(oracle, built, name):
     assert abs(float(a.mean()) - mean) / mean < 0.005
     assert abs(sa.total_rays() - sb.total_rays()) / sb.total_rays() < 0.002
     flipped = float((d > 1e-5 * mean).mean())               # pixels in which at least one path took another branch
-    assert flipped <= (0.40 if name == "cornell" else 0.03), (name, flipped)
+    assert flipped <= (0.40 if name in ("cornell", "many-materials") else 0.03), (name, flipped)  # scenes full of mix nodes and dielectrics: many discrete decisions per path
     assert float(np.sqrt((d ** 2).mean())) / mean < 0.05    # per-pixel RMS deviation, relative to the image mean
     assert float(d.max()) / mean < 1.0                       # no pixel moves by more than the image mean (a few paths of 64)
