@@ -183,7 +183,7 @@ def _random_rays(sc, n, rng):
     return rays
 
 
-@pytest.mark.parametrize("name", ["cornell", "cubes", "transformed", "material-ball-small"])
+@pytest.mark.parametrize("name", ["cornell", "cubes", "transformed", "material-ball-small", "instanced-small", "terrain-small", "many-materials"])
 def test_arbitrary_rays_through_every_traversal_kernel(built, oracle, name):
     """rayIntersectionQuery / rayIntersectionTest on 100 000 arbitrary rays: persistent refill kernel in each node mode
     the scene admits, one-ray-per-lane kernel, wave-packet kernel -- hit flag, triangle and (w,u,v,t) bit-equal to the oracle."""
