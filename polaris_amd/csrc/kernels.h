@@ -848,7 +848,7 @@ __device__ __forceinline__ void shade_ray(const SceneT<LDS> &S, const ShadeArgs 
 	typename Tbl<LDS>::Light em = nullptr;
 	uint32_t e_index = 0;
 	if (S.num_emissives > 0) {
-		sel_pdf = pm_rcp((float)(int)S.num_emissives); // emissiveSelect, emissive_sampler.cl:226-237
+		sel_pdf = S.sel_pdf; // native_recip((float)numEmissives), emissiveSelect, emissive_sampler.cl:226-237: the same for every ray
 		const int ei = pm_clampi((int)(sample1.x * (int)S.num_emissives), 0, (int)S.num_emissives - 1);
 		em = S.emissives + ei;
 		e_index = (uint32_t)ei;
@@ -908,7 +908,7 @@ __device__ __forceinline__ SceneT<LDS> stage_scene(const SceneDev &Sg, ShadeLds 
 	SceneT<LDS> S;
 	S.vertices = Sg.vertices; S.normals = Sg.normals; S.uvs = Sg.uvs; S.mat_index = Sg.mat_index; S.tex_data = Sg.tex_data;
 	S.num_emissives = Sg.num_emissives; S.bg_node = Sg.bg_node; S.num_nodes = Sg.num_nodes; S.num_textures = Sg.num_textures;
-	S.tri_bits = Sg.tri_bits;
+	S.tri_bits = Sg.tri_bits; S.sel_pdf = Sg.sel_pdf;
 	if constexpr (LDS) { // the host launches this variant only when all three tables fit
 		const uint32_t tid = threadIdx.x;
 		const bool has_n = tid < Sg.num_nodes * 4, has_l = tid < Sg.num_emissives * 5, has_t = tid < Sg.num_textures;

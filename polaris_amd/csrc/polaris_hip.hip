@@ -528,6 +528,24 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 			for (int k = 0; k < 3; k++) { g[4 * v + k] = sc->vertices[4 * (off + v) + k]; g[12 + 4 * v + k] = sc->normals[4 * (off + v) + k]; }
 			g[24 + 2 * v] = sc->uvs[2 * (off + v)]; g[25 + 2 * v] = sc->uvs[2 * (off + v) + 1];
 		}
+		// what areaLightGetPdf (emissive_sampler.cl:117-173) and areaLightGetSample (:96) derive from the light alone, with the
+		// kernels' own operations in the kernels' order (this file is compiled without FMA contraction; polaris_math.h is
+		// bit-identical on the host): v0, v1 - v0, v2 - v0 through mul4x1 (util/transform.cl:9-16), normalize(cross(e1, e2)), 1 / area
+		const float *m = sc->emissives[e].transform;
+		auto xform = [&](const float p[3], float out[3]) {
+			out[0] = m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12];
+			out[1] = m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13];
+			out[2] = m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14];
+		};
+		const float v0[3] = {g[0], g[1], g[2]};
+		const float d1[3] = {g[4] - v0[0], g[5] - v0[1], g[6] - v0[2]}, d2[3] = {g[8] - v0[0], g[9] - v0[1], g[10] - v0[2]};
+		float tv0[3], te1[3], te2[3];
+		xform(v0, tv0); xform(d1, te1); xform(d2, te2);
+		const float cx = te1[1] * te2[2] - te1[2] * te2[1], cy = te1[2] * te2[0] - te1[0] * te2[2], cz = te1[0] * te2[1] - te1[1] * te2[0];
+		const float inv_len = 1.0f / pm_sqrt(cx * cx + cy * cy + cz * cz);
+		for (int k = 0; k < 3; k++) { g[32 + k] = tv0[k]; g[36 + k] = te1[k]; g[40 + k] = te2[k]; }
+		g[44] = cx * inv_len; g[45] = cy * inv_len; g[46] = cz * inv_len;
+		g[30] = 1.0f / sc->emissives[e].area;
 	}
 	const size_t nv = (size_t)sc->num_triangles * 3;
 	rc |= dev_upload(h, h->scene_bufs, &vertices, sc->vertices, nv);
@@ -556,7 +574,7 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 		}
 	}
 	h->scene = SceneDev{vertices, normals, uvs, mat_index, nodes, emissives, tex_meta, tex_data, sc->num_emissives,
-	                    sc->scene_diffuse_mat_index, sc->num_material_nodes, sc->num_textures, light_geo, L.tri_bits};
+	                    sc->scene_diffuse_mat_index, sc->num_material_nodes, sc->num_textures, light_geo, sc->num_emissives ? pm_rcp((float)(int)sc->num_emissives) : 0.0f, L.tri_bits};
 	h->max_stack = L.max_stack;
 	if (h->opt_packet_primary < 0) h->packet_primary = sc->num_triangles <= 262144u;
 	// node records: whole tree in LDS for tiny scenes, its top for small ones, global memory otherwise (kernels.h NodeMode)

@@ -78,14 +78,18 @@ template <bool LDS> struct SceneT {
 	int32_t bg_node;                    // scene_diffuse_mat_index or -1
 	uint32_t num_nodes, num_textures;   // table sizes (LDS staging in k_shade)
 	// [num_emissives][kLightGeoFloats] the triangle of every area light, packed at upload (polaris_hip.hip, pack_light_geometry):
-	// v0 v1 v2 | n0 n1 n2 (xyz + pad each) | uv0 uv1 uv2 + pad.  light_sample / light_pdf read it instead of chasing
-	// emissive -> tri_index -> vertices / normals / uvs: with the table staged in LDS the light's geometry costs a shaded
-	// ray no memory round trip (it used to cost two dependent ones, one per function).
+	// v0 v1 v2 | n0 n1 n2 (xyz + pad each) | uv0 uv1 uv2, 1 / area | and what areaLightGetPdf derives from the light alone:
+	// transformed v0, transformed edges e1 e2, their unit normal (xyz + pad each).  light_sample / light_pdf read it instead
+	// of chasing emissive -> tri_index -> vertices / normals / uvs: with the table staged in LDS the light's geometry costs
+	// a shaded ray no memory round trip (it used to cost two dependent ones, one per function), and the per-light
+	// constants -- three point transforms, a cross product, a normalisation and two reciprocals per shaded ray in the
+	// reference -- are computed once, on the host, with the same operations (polaris_math.h is bit-identical there).
 	typename Tbl<LDS>::F light_geo;
+	float sel_pdf; // 1 / number of emissives (emissiveSelect, emissive_sampler.cl:226-237)
 	// a hit record's last word = scene triangle index | shading class << tri_bits (scene_layout.h; 31 = scenes too big to carry a class)
 	uint32_t tri_bits;
 };
-constexpr uint32_t kLightGeoFloats = 32;
+constexpr uint32_t kLightGeoFloats = 48;
 typedef SceneT<false> SceneDev; // what the host fills in
 
 // ---- PRNG: samplers/random_sampler.cl:7-16 ---------------------------------------------
@@ -478,7 +482,7 @@ template <bool LDS> PD LightSample light_sample(const Surf &sf, typename Tbl<LDS
 	// both light types end in matGetSample3f(uv, mn->k, mn->tex) for a uv of their own: computed per type, sampled in one place
 	f2 luv;
 	f3 en = splat(0.0f);
-	float d2 = 0.0f;
+	float d2 = 0.0f, g_inv_area = 0.0f;
 	if (ltype == POLARIS_EMISSIVE_ENVIRONMENT) { // :16-37
 		L.dir = cosine_hemisphere(sf.n, rnd);
 		L.pdf = pm_max(0.0f, dot(sf.n, L.dir)) * kInvPi;
@@ -496,6 +500,7 @@ template <bool LDS> PD LightSample light_sample(const Surf &sf, typename Tbl<LDS
 		f3 nn = mk3(w0 * a.x + ru * b.x + rv * c.x, w0 * a.y + ru * b.y + rv * c.y, w0 * a.z + ru * b.z + rv * c.z);
 		en = xform_point(nn, em->transform);
 		f2 ua = {g[24], g[25]}, ub = {g[26], g[27]}, uc = {g[28], g[29]};
+		g_inv_area = g[30];
 		luv = {w0 * ua.x + ru * ub.x + rv * uc.x, w0 * ua.y + ru * ub.y + rv * uc.y};
 		f3 er = ep - sf.p;
 		d2 = dot(er, er);
@@ -508,7 +513,7 @@ template <bool LDS> PD LightSample light_sample(const Surf &sf, typename Tbl<LDS
 	} else {
 		float nDotOut = dot(en, -L.dir);
 		if (nDotOut > 0.0f) {
-			L.pdf = 1.0f / em->area;
+			L.pdf = g_inv_area; // 1.0f / em->area, from the table
 			L.radiance = mn->scale * ke * nDotOut / d2;
 		} else {
 			L.pdf = 0.0f;
@@ -522,13 +527,9 @@ template <bool LDS> PD float light_pdf(const Surf &sf, typename Tbl<LDS>::Light 
 	if (em->type == POLARIS_EMISSIVE_ENVIRONMENT) return pm_max(0.0f, dot(sf.n, o) * kInvPi); // :39-47
 	if (em->type != POLARIS_EMISSIVE_AREA) return 0.0f;
 	// areaLightGetPdf, :117-173 (edges go through the point transform: quirk kept)
+	// v0, e1 = v1 - v0, e2 = v2 - v0 through the point transform, and normalize(cross(e1, e2)): per-light constants (:121-131, :165)
 	typename Tbl<LDS>::F g = S.light_geo + ei * kLightGeoFloats;
-	f3 v0 = mk3(g[0], g[1], g[2]);
-	f3 e1 = mk3(g[4], g[5], g[6]) - v0;
-	f3 e2 = mk3(g[8], g[9], g[10]) - v0;
-	v0 = xform_point(v0, em->transform);
-	e1 = xform_point(e1, em->transform);
-	e2 = xform_point(e2, em->transform);
+	const f3 v0 = mk3(g[32], g[33], g[34]), e1 = mk3(g[36], g[37], g[38]), e2 = mk3(g[40], g[41], g[42]);
 	f3 pv = cross(o, e2);
 	float det = dot(e1, pv);
 	if (pm_fabs(det) < kEps) return 0.0f;
@@ -541,7 +542,7 @@ template <bool LDS> PD float light_pdf(const Surf &sf, typename Tbl<LDS>::Light 
 	if (v < 0.0f || u + v > 1.0f) return 0.0f;
 	float t = dot(e2, qv) * inv;
 	if (t < kEps) return 0.0f;
-	f3 en = normalize(cross(e1, e2));
+	const f3 en = mk3(g[44], g[45], g[46]);
 	float denom = em->area * pm_fabs(dot(en, o));
 	return denom > 0.0f ? (t * t) / denom : 0.0f;
 }
