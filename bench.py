@@ -87,6 +87,10 @@ def main() -> None:
                     "(tuning aid for the strong-scaling path; not a valid bench line)")
     args = ap.parse_args()
 
+    from polaris_amd.hostinfo import size_openmp
+
+    cpu_threads = size_openmp()  # the CPU-baseline leg: one OpenMP thread per CPU this process may really use (cgroup quota)
+
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -315,16 +319,17 @@ def main() -> None:
                 from oracle import pybind as ob
 
                 orc = ob.Oracle("oracle")
-                cores = os.cpu_count() or 1
+                cores = cpu_threads
                 flags = ob.FIX_EMITTER_INDEX | ob.PARALLEL_SAMPLES
-                probe_spp = cores                        # one sample per hardware thread
-                cseeds = scenes.make_seeds(max(4 * cores, spp), B)
+                probe_spp = cores                        # one sample per thread
+                max_spp = 64 * cores
+                cseeds = scenes.make_seeds(max(max_spp, spp), B)
                 t = time.perf_counter()
                 _, cs, _ = orc.trace(sc, ob.make_request(W, H, spp=probe_spp, bounces=B, rr=args.rr), cseeds[: probe_spp * (1 + B)], flags=flags)
                 dt = time.perf_counter() - t
                 cpu_rays, cpu_dt, cpu_n = cs.total_rays(), dt, probe_spp
-                if dt < 6.0:                             # scale the sample towards ~10-20 s of wall time
-                    more = int(min(4 * cores, max(probe_spp, probe_spp * 12.0 / max(dt, 1e-3)))) // cores * cores
+                if dt < 6.0:                             # scale the sample towards ~12 s of wall time
+                    more = int(min(max_spp, max(probe_spp, probe_spp * 12.0 / max(dt, 1e-3)))) // cores * cores
                     if more > probe_spp:
                         t = time.perf_counter()
                         _, cs2, _ = orc.trace(sc, ob.make_request(W, H, spp=more, bounces=B, rr=args.rr), cseeds[: more * (1 + B)], flags=flags)
@@ -334,7 +339,7 @@ def main() -> None:
                                                  f"oracle/polaris_oracle.cpp, OpenMP over samples on {min(cores, cpu_n)} threads of {host_cpu()}",
                                        "ms_per_frame_extrapolated": cpu_dt / cpu_n * spp * 1e3}
             except Exception as e:  # the baseline is a reported extra, never a reason to lose the bench line
-                out["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+                out["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": cpu_threads, "kind": "port", "sample": f"failed: {e}"}
         if args.save_png:
             from PIL import Image
 

@@ -15,6 +15,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+from polaris_amd.hostinfo import size_openmp  # noqa: E402
+
+size_openmp()  # before any OpenMP library (the oracle, the C++ host layer) is loaded: one thread per CPU we may really use
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

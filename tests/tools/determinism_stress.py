@@ -11,6 +11,10 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 
 import numpy as np  # noqa: E402
 
+from polaris_amd.hostinfo import size_openmp  # noqa: E402
+
+size_openmp()
+
 
 def main():
     from conftest import make_hip_tracer
