@@ -396,6 +396,33 @@ def test_headline_frame_against_the_oracle(built, oracle, name):
     assert rmse(got, want, spp) <= 1e-6
 
 
+@pytest.mark.parametrize("name,W,H,spp", [("cornell", 1024, 1024, 256),       # C3 at its full size: 1.3 G rays
+                                          ("material-ball", 1920, 1080, 32),  # C4's frame, 1/16 of its samples: 170 M rays
+                                          ("instanced", 2048, 2048, 4)])      # C5's frame, 4 of its 1024 samples
+def test_frames_of_the_other_configs_against_the_oracle(built, oracle, name, W, H, spp):
+    """The remaining BASELINE.json configurations at their FULL frame size in the default (batched, overlapped) mode against
+    the CPU oracle over the same seeds (C3 at its full sample count; C4 / C5 with as many samples as the host cores trace in
+    about half a minute): every ray counter identical (=> identical paths through 4 M-pixel blocks, 33 M-slot batches, the
+    global-memory node modes and the 24- / 32-entry stacks), per-pixel RMSE <= 1e-6."""
+    from oracle import pybind as ob
+    from polaris_amd import scenes
+
+    sc = scenes.SCENES[name](W / H)
+    B = 5
+    req = ob.make_request(W, H, spp=spp, bounces=B, rr=3)
+    seeds = scenes.make_seeds(spp, B)
+    want, wst, _ = oracle.trace(sc, req, seeds, flags=ob.FIX_EMITTER_INDEX | ob.PARALLEL_SAMPLES)
+    tr = make_hip_tracer(sc, W, H)
+    try:
+        tr.Trace(req, seeds)
+        got, st = tr.read_accumulator(0), tr.last_trace_stats
+    finally:
+        tr.Close()
+    assert st.primary_rays == W * H * spp
+    assert counters(st, B) == counters(wst, B)
+    assert rmse(got, want, spp) <= 1e-6
+
+
 @pytest.mark.parametrize("name", ["material-ball", "instanced"])
 def test_big_scene_kernel_variants_agree_with_the_oracle(built, oracle, name):
     """Scenes that select the other kernel variants -- 24-entry traversal stack, no LDS tree top, leaves
