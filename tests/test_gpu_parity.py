@@ -74,7 +74,10 @@ def test_hip_vs_oracle_exact_and_batched(built, oracle, name):
                 ({"exact_accumulate": 1, "node_mode": 0}, True), ({"exact_accumulate": 1, "node_mode": 1}, True),
                 ({"exact_accumulate": 1, "node_mode": 2}, True), ({"node_mode": 1, "samples_per_batch": 3}, False),
                 ({"exact_accumulate": 1, "shade_wave": 0}, True), ({"exact_accumulate": 1, "shade_wave_from": 0}, True),
-                ({"shade_wave": 0, "stage_lds": 0, "samples_per_batch": 3}, False), ({"shade_wave_from": 1, "samples_per_batch": 2}, False))
+                ({"shade_wave": 0, "stage_lds": 0, "samples_per_batch": 3}, False), ({"shade_wave_from": 1, "samples_per_batch": 2}, False),
+                # shading order: never sorted by class / sorted from bounce 2 / sorted with the tables in global memory
+                ({"exact_accumulate": 1, "shade_sort": 32}, True), ({"exact_accumulate": 1, "shade_sort": 2}, True),
+                ({"exact_accumulate": 1, "stage_lds": 0}, True), ({"shade_sort": 32, "shade_wave": 0, "samples_per_batch": 3}, False))
     for opts, exact in variants:
         tr = make_hip_tracer(sc, W, H, **opts)
         try:
