@@ -110,7 +110,7 @@ __global__ __launch_bounds__(WG) void k_generate(Streams st, CameraArgs cam, con
 	float inv = 1.0f / pm_sqrt(dx * dx + dy * dy + dz * dz + dw * dw);
 	st.ray_o[slot] = make_float4(cam.eye.x, cam.eye.y, cam.eye.z, kFltMax);
 	st.ray_d[slot] = make_float4(dx * inv, dy * inv, dz * inv, ibits((int)idx));
-	st.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+	// (the throughput of a camera ray is 1: the first shade step does not read it, so it is not written)
 	if (zero_lsum) st.lsum[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
@@ -985,7 +985,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5, 5))) void
 	// the lane's ray is requested before the tables are staged: both round trips are in flight together
 	const size_t base = (size_t)blockIdx.x * WG;
 	const size_t my = base + (tid < cnt ? tid : 0u); // (idle lanes re-read slot 0: no select behind the loads, so nothing waits for them here)
-	float4 d4 = st.ray_d[my], t4 = st.thr[my], h4 = st.hit[my];
+	float4 d4 = st.ray_d[my], t4 = FIRST ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : st.thr[my], h4 = st.hit[my]; // (camera rays carry no throughput: it is 1)
 	uint32_t pmask[8]; // the previous step's emit mask of this chunk (uniform)
 #pragma unroll
 	for (int w = 0; w < 8; w++) pmask[w] = FIRST ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)A.emask_in[(size_t)blockIdx.x * 8 + w]); // (kept in scalar registers)
