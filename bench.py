@@ -46,8 +46,10 @@ def kernel_algorithmic_bytes(st: dict) -> dict:
     """SURVEY.md 8d per-unit stream bytes, attributed to the kernel that moves them
     (intersect_packet = k_trace_packet on camera rays, intersect = k_trace<closest> on bounce rays)."""
     return {
-        "generate": 36 * st["primary_rays"],  # SURVEY's 52 B minus the 16-byte throughput: a camera ray's is 1 and is not stored
-        "intersect_packet": 60 * st["primary_rays"],
+        # camera rays: SURVEY's 52 + 60 B minus what is constant for a camera ray and therefore neither stored nor read
+        # (origin | max distance: 16 B written + 16 B read; throughput: 16 B written)
+        "generate": 20 * st["primary_rays"],
+        "intersect_packet": 44 * st["primary_rays"],
         "intersect": 60 * st["indirect_rays"],
         "shade": 68 * st["shaded_hits"] + 32 * st["indirect_rays"] + 44 * st["occlusion_rays"]
         + 60 * st["shaded_misses"] + 24 * st["emitter_hits"],

@@ -84,7 +84,7 @@ struct CameraArgs { float4 tl, tr, bl, br; float3 eye; float2 texel; };
 
 __global__ __launch_bounds__(WG) void k_generate(Streams st, CameraArgs cam, const uint32_t *seeds, uint32_t seed_stride,
                                                   uint32_t first_sample, uint32_t N, uint32_t Npad, uint32_t W, uint32_t blockY,
-                                                  int zero_lsum) {
+                                                  int zero_lsum, int write_origin) {
 	const uint32_t wgs_per_sample = Npad / WG;
 	const uint32_t s = blockIdx.x / wgs_per_sample;
 	const uint32_t idx0 = (blockIdx.x % wgs_per_sample) * WG;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(WG) void k_generate(Streams st, CameraArgs cam, con
 	float rx = pm_mix(cam.tr.x, cam.br.x, ty), ry = pm_mix(cam.tr.y, cam.br.y, ty), rz = pm_mix(cam.tr.z, cam.br.z, ty), rw = pm_mix(cam.tr.w, cam.br.w, ty);
 	float dx = pm_mix(lx, rx, tx), dy = pm_mix(ly, ry, tx), dz = pm_mix(lz, rz, tx), dw = pm_mix(lw, rw, tx);
 	float inv = 1.0f / pm_sqrt(dx * dx + dy * dy + dz * dz + dw * dw);
-	st.ray_o[slot] = make_float4(cam.eye.x, cam.eye.y, cam.eye.z, kFltMax);
+	if (write_origin) st.ray_o[slot] = make_float4(cam.eye.x, cam.eye.y, cam.eye.z, kFltMax); // (the wave-packet kernel takes the eye from its arguments)
 	st.ray_d[slot] = make_float4(dx * inv, dy * inv, dz * inv, ibits((int)idx));
 	// (the throughput of a camera ray is 1: the first shade step does not read it, so it is not written)
 	if (zero_lsum) st.lsum[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -612,8 +612,10 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 // slab test passed at every ancestor, which is exactly the set of leaves its own traversal (and the
 // reference's rayIntersectionQuery) visits -- so per-ray results are bit-identical to k_trace.
 // ------------------------------------------------------------------------------------------
-template <bool ANY_HIT>
-__global__ __launch_bounds__(WG) void k_trace_packet(Streams st, BvhDev B, float4 *acc, unsigned long long *stats) {
+// CAMERA: every ray starts at the eye with no distance limit (camera rays of a batch): the origin stream is neither written
+// by k_generate nor read here.
+template <bool ANY_HIT, bool CAMERA = false>
+__global__ __launch_bounds__(WG) void k_trace_packet(Streams st, BvhDev B, float4 *acc, unsigned long long *stats, float3 eye) {
 	__shared__ int p_ref[4][kTraversalStack];
 	__shared__ unsigned long long p_mask[4][kTraversalStack];
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -623,7 +625,7 @@ __global__ __launch_bounds__(WG) void k_trace_packet(Streams st, BvhDev B, float
 	if (wave * 64 >= cnt) return; // nothing live in this wave's 64 slots (uniform per wave)
 	const bool valid = tid < cnt;
 	const size_t slot = (size_t)blockIdx.x * WG + tid;
-	const float4 o4 = valid ? src_o[slot] : make_float4(0, 0, 0, 0);
+	const float4 o4 = CAMERA ? make_float4(eye.x, eye.y, eye.z, kFltMax) : (valid ? src_o[slot] : make_float4(0, 0, 0, 0));
 	const float4 d4 = valid ? src_d[slot] : make_float4(1, 1, 1, 0);
 	bool occluded = false; // ANY_HIT: a lane that found its blocker leaves the packet for good
 	const f3 O = xyz(o4), D = xyz(d4);

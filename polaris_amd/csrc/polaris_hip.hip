@@ -284,7 +284,7 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 	{
 		Timed t(h, "generate", q);
 		hipLaunchKernelGGL(k_generate, dim3(wgs), dim3(WG), 0, q, P.st, h->cam, h->d_seeds, stride, s0, N, Npad, h->W, r->block_y,
-		                   exact ? 0 : 1);
+		                   exact ? 0 : 1, (B > 0 && h->packet_primary) ? 0 : 1); // (the wave-packet kernel does not read the origin stream)
 	}
 	ShadeArgs A{};
 	A.seeds = h->d_seeds; A.seed_stride = stride; A.first_sample = s0;
@@ -313,7 +313,7 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 		{
 			Timed t(h, (b == 0 && h->packet_primary) ? "intersect_packet" : "intersect", q);
 			if (b == 0 && h->packet_primary)
-				hipLaunchKernelGGL(k_trace_packet<false>, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, (float4 *)nullptr, h->d_stats);
+				hipLaunchKernelGGL((k_trace_packet<false, true>), dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, (float4 *)nullptr, h->d_stats, h->cam.eye);
 			else if (h->opt_traversal)
 				launch_trace<false>(h, P, persistent, wgs, nullptr);
 			else
@@ -351,7 +351,7 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 		{
 			Timed t(h, "occlusion", q);
 			if ((int)b < h->opt_packet_shadow)
-				hipLaunchKernelGGL(k_trace_packet<true>, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, A.acc, h->d_stats);
+				hipLaunchKernelGGL(k_trace_packet<true>, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, A.acc, h->d_stats, h->cam.eye);
 			else if (h->opt_traversal)
 				launch_trace<true>(h, P, persistent_occl, wgs, A.acc);
 			else
@@ -856,8 +856,8 @@ int polaris_hip_tap_primary(polaris_hip_tracer *h, const PolarisBlockRequest *r,
 	h->cam.texel = make_float2(1.0f / (float)h->W, 1.0f / (float)h->H);
 	hipStream_t q = h->stream;
 	HIP_TRY(h, hipMemcpyAsync(h->d_seeds, &seed, sizeof seed, hipMemcpyHostToDevice, q));
-	hipLaunchKernelGGL(k_generate, dim3(Npad / WG), dim3(WG), 0, q, st0, h->cam, h->d_seeds, 1u, 0u, N, Npad, h->W, r->block_y, 1);
-	if (h->packet_primary) hipLaunchKernelGGL(k_trace_packet<false>, dim3(Npad / WG), dim3(WG), 0, q, st0, h->bvh, (float4 *)nullptr, h->d_stats);
+	hipLaunchKernelGGL(k_generate, dim3(Npad / WG), dim3(WG), 0, q, st0, h->cam, h->d_seeds, 1u, 0u, N, Npad, h->W, r->block_y, 1, 1);
+	if (h->packet_primary) hipLaunchKernelGGL(k_trace_packet<false>, dim3(Npad / WG), dim3(WG), 0, q, st0, h->bvh, (float4 *)nullptr, h->d_stats, h->cam.eye);
 	else hipLaunchKernelGGL(k_intersect, dim3(Npad / WG), dim3(WG), 0, q, st0, h->bvh);
 	HIP_TRY(h, hipGetLastError());
 	std::vector<float4> ro(N), rd(N), ht(N);
@@ -941,11 +941,11 @@ int polaris_hip_probe_intersect(polaris_hip_tracer *h, const float *rays, uint32
 		// the traversal kernel the options select for bounce rays (any_hit: shadow rays); packet_primary=1 sends closest-hit
 		// probes through the wave-packet kernel instead
 		if (any_hit) {
-			if (h->opt_packet_shadow > 0) hipLaunchKernelGGL(k_trace_packet<true>, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, P.st.lsum, h->d_stats);
+			if (h->opt_packet_shadow > 0) hipLaunchKernelGGL(k_trace_packet<true>, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, P.st.lsum, h->d_stats, h->cam.eye);
 			else if (h->opt_traversal) launch_trace<true>(h, P, std::min<uint32_t>(wgs, (uint32_t)h->num_cus * (uint32_t)std::max(1, h->occl_resident_per_cu)), wgs, P.st.lsum);
 			else hipLaunchKernelGGL(k_occlusion, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, P.st.lsum, h->d_stats);
 		} else {
-			if (h->opt_packet_primary == 1) hipLaunchKernelGGL(k_trace_packet<false>, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, (float4 *)nullptr, h->d_stats);
+			if (h->opt_packet_primary == 1) hipLaunchKernelGGL(k_trace_packet<false>, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, (float4 *)nullptr, h->d_stats, h->cam.eye);
 			else if (h->opt_traversal) launch_trace<false>(h, P, std::min<uint32_t>(wgs, (uint32_t)h->num_cus * (uint32_t)std::max(1, h->trace_resident_per_cu)), wgs, nullptr);
 			else hipLaunchKernelGGL(k_intersect, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh);
 		}
