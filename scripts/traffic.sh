@@ -27,7 +27,7 @@ for k, v in out.items():
     v["hbm_bytes_per_launch"] = (v["hbm_read_bytes"] + v["hbm_write_bytes"]) / max(v["launches"], 1)
     res[k] = v
 # the same numbers keyed by bench.py's kernel timers (what bench.py's roofline.traffic reads)
-timers = {"generate": ("pol::k_generate",), "intersect_packet": ("pol::k_trace_packet<false>",), "intersect": ("pol::k_trace<false",),
+timers = {"generate": ("pol::k_generate",), "intersect_packet": ("pol::k_trace_packet<false",), "intersect": ("pol::k_trace<false",),
           "occlusion": ("pol::k_trace<true",), "shade": ("pol::k_shade<", "pol::k_shade_wave<")}
 tm = {}
 for t, prefixes in timers.items():
