@@ -69,8 +69,8 @@ def host_cpu() -> str:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scene", default="cornell")
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--height", type=int, default=512)
