@@ -89,8 +89,10 @@ int polaris_hip_set_camera(polaris_hip_tracer *h, const float eye[3], const floa
  *                        than this are subdivided where a surface-area split pays (default -1:
  *                        2 up to 32 K triangles, 4 above; 0 = keep the caller's leaves).  Never
  *                        changes a result: DESIGN.md 2 (HBM data layout)
- *   further A/B switches of the kernels ("traversal", "packet_shadow", "shade_wave",
- *   "shade_wave_from", "shade_wgs_per_cu", "stage_lds", "trace_wgs_per_cu"): see DESIGN.md 3 */
+ *   further A/B switches of the kernels ("traversal", "node_mode", "packet_shadow", "shade_wave",
+ *   "shade_wave_from", "shade_sort", "shade_wgs_per_cu", "stage_lds", "trace_wgs_per_cu"): see
+ *   DESIGN.md 3.  Apart from "exact_accumulate" (the order of the float sums) no option changes a
+ *   result; an unknown key is POLARIS_E_BAD_ARGUMENT. */
 int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value);
 
 /*
