@@ -548,7 +548,8 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 				const int spm = sp > 0 ? sp - 1 : 0;
 				const int popped = read_ref(spm); // what follows the leaf: read beside the triangles, not after them
 				bool occluded = false;
-				for (uint32_t i = 0; __ballot(i < ntri && !occluded) != 0ull; i++) {
+				uint32_t i = 0; // (bottom-tested: some lane holds a leaf, and a leaf has at least one triangle)
+				do {
 					if (i < ntri && !occluded) {
 						const TriRec T = B.tris[first + i];
 						const f3 e1 = xyz(T.e1), e2 = xyz(T.e2);
@@ -576,7 +577,8 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 							best_irank = take ? irank : best_irank; best_trank = take ? trank : best_trank;
 						}
 					}
-				}
+					i++;
+				} while (__ballot(i < ntri && !occluded) != 0ull);
 				if (tl) {
 					if (ANY_HIT && occluded) cur = kIdle; // blocked: nothing to add
 					else { cur = (sp == 0 || (popped == kExitMarker && spm == 0)) ? kDone : popped; sp = spm; }
@@ -970,9 +972,13 @@ __device__ __forceinline__ uint32_t canonical_index(const uint32_t (&mask)[8], u
 // in registers before the workgroup's last barrier (SORT: the exchange barrier; otherwise the staging barrier, in front
 // of which every wave waits for its loads), and no wave stores before that barrier.
 //
-// Occupancy: shade_ray needs ~106 VGPRs unconstrained (4 waves per SIMD); built for 5 waves (-8 % kernel time).
+// Occupancy: built for 6 waves per SIMD (<= 80 VGPRs, no spill since the SLP vectoriser is off: its register pairs cost ~10
+// VGPRs; with it the kernel needed 90 and 6 waves spilled).  21 KB of LDS per workgroup: 6 workgroups per CU fit.
+#ifndef POLARIS_SHADE_WAVES
+#define POLARIS_SHADE_WAVES 6
+#endif
 template <bool LDS, bool SORT, bool FIRST>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_shade(Streams st, SceneDev Sg, ShadeArgs A) {
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(POLARIS_SHADE_WAVES, POLARIS_SHADE_WAVES))) void k_shade(Streams st, SceneDev Sg, ShadeArgs A) {
 	__shared__ ShadeLds lds;
 	__shared__ uint32_t s_cnt[SORT ? 4 : 1][16];       // rays per (wave, class)
 	__shared__ float4 x_d[SORT ? WG : 1], x_t[SORT ? WG : 1], x_h[SORT ? WG : 1]; // the rays in class order

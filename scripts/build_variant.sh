@@ -6,5 +6,5 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 name=$1; shift
 mkdir -p $ROOT/polaris_amd/lib/exp
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -O3 -fPIC -shared -ffp-contract=off -fno-fast-math \
-  -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -Wall -Wno-unused-function \
+  -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -fno-slp-vectorize -Wall -Wno-unused-function \
   -I$ROOT/include -I$ROOT/polaris_amd/csrc "$@" $ROOT/polaris_amd/csrc/polaris_hip.hip -o $ROOT/polaris_amd/lib/exp/$name.so
