@@ -633,7 +633,8 @@ __global__ __launch_bounds__(WG) void k_trace_packet(Streams st, BvhDev B, float
 	const f3 O = xyz(o4), D = xyz(d4);
 	const float maxDist = o4.w;
 	f3 o = O, d = D;
-	f3 inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)};
+	const f3 INV = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)}; // native_recip(ray.dir), intersect.cl:302 (kept for the way out of an instance)
+	f3 inv = INV;
 	HitRec best;
 	best.t = maxDist; best.tri = -1; best.inst = 0; best.u = best.v = 0.0f; best.irank = best.trank = 0;
 	int inst = 0;
@@ -686,39 +687,44 @@ __global__ __launch_bounds__(WG) void k_trace_packet(Streams st, BvhDev B, float
 				cur = I.meta.x;
 			} else {
 				const int first = -li.x;
-				for (int t = first; t < first + li.y; t++) {
-					const TriRec T = B.tris[t]; // uniform address
+				int t = first; // (bottom-tested: a triangle leaf holds at least one triangle)
+				do {
+					const TriRec T = B.tris[t]; // uniform address: scalar loads
+					// Moeller-Trumbore without early exits (as in k_trace): a packet only skips what ALL its lanes skip, which is rare,
+					// and with nested exits the compiler sinks each load of the record into the branch that first needs it -- three
+					// dependent scalar round trips per triangle instead of one
 					if (active) {
-						f3 e1 = xyz(T.e1), e2 = xyz(T.e2);
-						f3 pv = cross(d, e2);
-						float det = dot(e1, pv);
-						if (!(pm_fabs(det) < kEps)) {
-							float idet = pm_rcp(det);
-							f3 tv = o - xyz(T.v0);
-							float u = dot(tv, pv) * idet;
-							if (!(u < 0.0f || u > 1.0f)) {
-								f3 qv = cross(tv, e1);
-								float v = dot(d, qv) * idet;
-								if (!(v < 0.0f || u + v > 1.0f)) {
-									float tt = dot(e2, qv) * idet;
-									if (ANY_HIT) {
-										if (tt > kEps && tt < maxDist) { occluded = true; active = false; }
-									} else if (tt > kEps) {
-										const uint32_t trank = (uint32_t)fbits(T.v0.w);
-										const bool closer = tt < best.t;
-										const bool tie = tt == best.t && best.tri >= 0 && (irank < best.irank || (irank == best.irank && trank < best.trank));
-										if (closer || tie) { best.t = tt; best.u = u; best.v = v; best.tri = fbits(T.e1.w); best.inst = inst; best.irank = irank; best.trank = trank; }
-									}
-								}
-							}
+						const f3 e1 = xyz(T.e1), e2 = xyz(T.e2);
+						const f3 pv = cross(d, e2);
+						const float det = dot(e1, pv);
+						bool ok = !(pm_fabs(det) < kEps);
+						const float idet = pm_rcp(det);
+						const f3 tv = o - xyz(T.v0);
+						const float u = dot(tv, pv) * idet;
+						ok = ok && !(u < 0.0f || u > 1.0f);
+						const f3 qv = cross(tv, e1);
+						const float v = dot(d, qv) * idet;
+						ok = ok && !(v < 0.0f || u + v > 1.0f);
+						const float tt = dot(e2, qv) * idet;
+						ok = ok && tt > kEps;
+						if (ANY_HIT) {
+							if (ok && tt < maxDist) { occluded = true; active = false; }
+						} else {
+							const uint32_t trank = (uint32_t)fbits(T.v0.w);
+							const bool closer = tt < best.t;
+							const bool tie = tt == best.t && best.tri >= 0 && (irank < best.irank || (irank == best.irank && trank < best.trank));
+							const bool take = ok && (closer || tie);
+							best.t = take ? tt : best.t; best.u = take ? u : best.u; best.v = take ? v : best.v;
+							best.tri = take ? fbits(T.e1.w) : best.tri; best.inst = take ? inst : best.inst;
+							best.irank = take ? irank : best.irank; best.trank = take ? trank : best.trank;
 						}
 					}
-				}
+				} while (++t < first + li.y);
 				need_pop = true;
 			}
 		}
 		if (need_pop) {
-			bool done = false;
+			bool done = false, leave = false;
 			for (;;) {
 				if (sp == 0) { done = true; break; }
 				sp--;
@@ -730,10 +736,10 @@ __global__ __launch_bounds__(WG) void k_trace_packet(Streams st, BvhDev B, float
 					if (__ballot(active) == 0ull) continue; // nobody left for this subtree
 					break;
 				}
-				o = O; d = D; // leaving the instance
-				inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)};
+				leave = true; // leaving the instance (the ray is restored below, outside this loop: nothing in it reads the ray)
 			}
 			if (done) break;
+			if (leave) { o = O; d = D; inv = INV; }
 		}
 	}
 	if (ANY_HIT) {
