@@ -336,16 +336,13 @@ constexpr int kFirstLeafRef = (int)0x80000010;
 enum NodeMode { kNodesGlobal = 0, kNodesLdsTop = 1, kNodesLdsAll = 2 };
 constexpr int kTinyPairs = 512;
 constexpr int kTinyBlock = 1024;
-constexpr uint32_t kTinyMaxIndex = 2046; // triangle slots and node ids must fit the 11-bit field of a 16-bit stack entry (0x7FFF is the exit marker)
+constexpr uint32_t kTinyMaxIndex = 2046; // triangle slots and leaf ids must fit the 11-bit field of a 16-bit stack entry (2047 | 15 is the exit marker)
 
-// 16-bit stack entries of the tiny mode: inner node -> its index (bit 15 clear); leaf code first << 4 | count -> 0x8000 | code;
-// exit marker -> 0xFFFF
-__device__ __forceinline__ uint16_t ref_to16(int ref) {
-	return ref >= 0 ? (uint16_t)ref : (ref == kExitMarker ? (uint16_t)0xFFFFu : (uint16_t)(0x8000u | ((uint32_t)~ref & 0x7FFFu)));
-}
-__device__ __forceinline__ int ref_from16(uint16_t v) {
-	return (v & 0x8000u) ? (v == 0xFFFFu ? kExitMarker : ~(int)(v & 0x7FFFu)) : (int)v;
-}
+// 16-bit stack entries of the tiny mode: every reference the tiny mode can push is the sign extension of its low 16 bits --
+// inner nodes are indices <= 511, a leaf reference is ~(first << 4 | count) with first <= kTinyMaxIndex, i.e. >= -32752 -- so a
+// push is a ds_write_b16 of the register and a pop a ds_read_i16, no conversion.  Only the instance exit marker needs a value of
+// its own there: -32768 (= ~(2047 << 4 | 15), a leaf code kTinyMaxIndex rules out).
+constexpr int kTinyExitMarker = -32768;
 
 template <bool ANY_HIT, int STACK, int NODES>
 __global__ __launch_bounds__(NODES == kNodesLdsAll ? kTinyBlock : WG)
@@ -353,7 +350,8 @@ __attribute__((amdgpu_waves_per_eu(NODES == kNodesLdsAll ? 8 : ((!ANY_HIT && STA
 void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned long long *stats) {
 	constexpr bool LDS_TOP = NODES == kNodesLdsTop, TINY = NODES == kNodesLdsAll;
 	constexpr int BLOCK = TINY ? kTinyBlock : WG; // threads per workgroup (a CHUNK of rays is always WG = 256 slots)
-	typedef typename std::conditional<TINY, uint16_t, int>::type StackEntry;
+	typedef typename std::conditional<TINY, int16_t, int>::type StackEntry;
+	constexpr int EXIT = TINY ? kTinyExitMarker : kExitMarker; // the instance exit marker as this variant's stack holds it
 	__shared__ StackEntry stk[STACK][BLOCK];
 	__shared__ uint32_t wg_cursor;
 	if (threadIdx.x == 0) wg_cursor = 0;
@@ -364,8 +362,8 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 		for (uint32_t i = threadIdx.x; i < n4; i += BLOCK) top[i] = src[i];
 	}
 	__syncthreads();
-	auto push_ref = [&](int at, int ref) { stk[at][threadIdx.x] = TINY ? (StackEntry)ref_to16(ref) : (StackEntry)ref; };
-	auto read_ref = [&](int at) -> int { return TINY ? ref_from16((uint16_t)stk[at][threadIdx.x]) : (int)stk[at][threadIdx.x]; };
+	auto push_ref = [&](int at, int ref) { stk[at][threadIdx.x] = (StackEntry)ref; };
+	auto read_ref = [&](int at) -> int { return (int)stk[at][threadIdx.x]; };
 	const int tid = threadIdx.x;
 	const uint32_t lane = tid & 63;
 	const unsigned long long below = (1ull << lane) - 1ull;
@@ -390,7 +388,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 	auto pop = [&]() {
 		const int spm = sp > 0 ? sp - 1 : 0;
 		const int popped = read_ref(spm);
-		cur = (sp == 0 || (popped == kExitMarker && spm == 0)) ? kDone : popped;
+		cur = (sp == 0 || (popped == EXIT && spm == 0)) ? kDone : popped;
 		sp = spm;
 	};
 
@@ -437,7 +435,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 						               I.r2.x * d.x + I.r2.y * d.y + I.r2.z * d.z};
 						o = no; d = nd;
 						irank = (uint32_t)I.meta.y;
-						push_ref(0, kExitMarker); // (nothing is ever pending below it: popping it ends the ray without a restore)
+						push_ref(0, EXIT); // (nothing is ever pending below it: popping it ends the ray without a restore)
 						sp = 1;
 						cur = I.meta.x;
 					}
@@ -474,7 +472,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 				const int nearc = second_first ? c1 : c0, farc = second_first ? c0 : c1;
 				push_ref(sp, farc); // kept only when both children are hit (sp advances); otherwise the slot stays free
 				const bool both = h0 && h1, none = !(h0 || h1);
-				const int after_pop = (sp == 0 || (popped == kExitMarker && spm == 0)) ? kDone : popped;
+				const int after_pop = (sp == 0 || (popped == EXIT && spm == 0)) ? kDone : popped;
 				cur = none ? after_pop : nearc;
 				sp = both ? sp + 1 : (none ? spm : sp);
 			}
@@ -490,7 +488,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 			}
 			cur = kIdle;
 		}
-		if (cur == kExitMarker) { // leaving the instance: back to the world-space ray (intersect.cl:330-335)
+		if (cur == EXIT) { // leaving the instance: back to the world-space ray (intersect.cl:330-335)
 			const float4 o4 = src_o[slot], d4 = src_d[slot];
 			o = xyz(o4); d = xyz(d4);
 			inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)};
@@ -501,7 +499,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 			if (li.y == 0) { // top-level leaf: enter the mesh instance (intersect.cl:239-252)
 				const InstRec I = B.insts[-li.x];
 				irank = (uint32_t)I.meta.y;
-				push_ref(sp++, kExitMarker);
+				push_ref(sp++, EXIT);
 				// mul4x1 / mul3x1, util/transform.cl:9-26
 				const f3 no = {I.r0.x * o.x + I.r0.y * o.y + I.r0.z * o.z + I.r0.w, I.r1.x * o.x + I.r1.y * o.y + I.r1.z * o.z + I.r1.w,
 				               I.r2.x * o.x + I.r2.y * o.y + I.r2.z * o.z + I.r2.w};
@@ -581,7 +579,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 				} while (__ballot(i < ntri && !occluded) != 0ull);
 				if (tl) {
 					if (ANY_HIT && occluded) cur = kIdle; // blocked: nothing to add
-					else { cur = (sp == 0 || (popped == kExitMarker && spm == 0)) ? kDone : popped; sp = spm; }
+					else { cur = (sp == 0 || (popped == EXIT && spm == 0)) ? kDone : popped; sp = spm; }
 				}
 			}
 		}
