@@ -317,6 +317,17 @@ __device__ __forceinline__ float slab_entry_hw(float4 lo, float4 hi, f3 o, f3 in
 	return (minmax < 0 || maxmin > minmax) ? kFltMax : (maxmin >= maxDist ? kFltMax : maxmin);
 }
 
+// The same test as a predicate: slab_entry_hw(..) < kFltMax, i.e. "the ray enters the box before maxDist", with the entry
+// distance in t -- the compares combined as booleans (scalar mask operations) instead of through a selected kFltMax.
+__device__ __forceinline__ bool slab_hit_hw(float4 lo, float4 hi, f3 o, f3 inv, float maxDist, float &t) {
+	float t0x = (lo.x - o.x) * inv.x, t0y = (lo.y - o.y) * inv.y, t0z = (lo.z - o.z) * inv.z;
+	float t1x = (hi.x - o.x) * inv.x, t1y = (hi.y - o.y) * inv.y, t1z = (hi.z - o.z) * inv.z;
+	float minmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)), __builtin_fmaxf(t0z, t1z));
+	float maxmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)), __builtin_fminf(t0z, t1z));
+	t = maxmin;
+	return !(minmax < 0) && !(maxmin > minmax) && !(maxmin >= maxDist) && maxmin < kFltMax;
+}
+
 // The closest-hit kernel with the 16-entry stack is asked for 7 waves per SIMD (20 KB of LDS per workgroup: -2.4 % kernel
 // time on the Cornell box, -9 % on the sphere scene); the any-hit variant fits 7 by itself since the rewrite.
 // negative node codes that are not leaf references (a leaf code first << 4 | count never has all of bits 4..30 set)
@@ -352,7 +363,11 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 	constexpr int BLOCK = TINY ? kTinyBlock : WG; // threads per workgroup (a CHUNK of rays is always WG = 256 slots)
 	typedef typename std::conditional<TINY, int16_t, int>::type StackEntry;
 	constexpr int EXIT = TINY ? kTinyExitMarker : kExitMarker; // the instance exit marker as this variant's stack holds it
-	__shared__ StackEntry stk[STACK][BLOCK];
+	// The per-lane node stack: a column of an LDS array.  A lane keeps its stack pointer as the BYTE OFFSET of its top entry
+	// (sp0 = empty, + kRow per entry), so a pop reads at `sp` and a push writes at `sp + kRow` with no address arithmetic;
+	// row 0 is a dummy, so that "the entry below an empty stack" can be read (and ignored) without a clamp.
+	__shared__ StackEntry stk[STACK + 1][BLOCK];
+	constexpr uint32_t kRow = BLOCK * sizeof(StackEntry);
 	__shared__ uint32_t wg_cursor;
 	if (threadIdx.x == 0) wg_cursor = 0;
 	__shared__ float4 top[TINY ? kTinyPairs * 4 : (LDS_TOP ? kLdsTopNodes * 4 : 1)];
@@ -362,9 +377,11 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 		for (uint32_t i = threadIdx.x; i < n4; i += BLOCK) top[i] = src[i];
 	}
 	__syncthreads();
-	auto push_ref = [&](int at, int ref) { stk[at][threadIdx.x] = (StackEntry)ref; };
-	auto read_ref = [&](int at) -> int { return (int)stk[at][threadIdx.x]; };
+	char *const stk_bytes = reinterpret_cast<char *>(&stk[0][0]);
 	const int tid = threadIdx.x;
+	const uint32_t sp0 = (uint32_t)tid * (uint32_t)sizeof(StackEntry);
+	auto push_ref = [&](uint32_t at, int ref) { *reinterpret_cast<StackEntry *>(stk_bytes + at + kRow) = (StackEntry)ref; }; // onto a stack whose pointer is `at`
+	auto read_ref = [&](uint32_t at) -> int { return (int)*reinterpret_cast<const StackEntry *>(stk_bytes + at); };         // the top entry of such a stack
 	const uint32_t lane = tid & 63;
 	const unsigned long long below = (1ull << lane) - 1ull;
 	const uint32_t *cnts = ANY_HIT ? st.cnt_occ : st.cnt_ray;
@@ -376,7 +393,8 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 	uint32_t slot = 0; // per-lane ray state
 	f3 o = {0, 0, 0}, d = {0, 0, 0}, inv = {0, 0, 0};
 	float maxDist = 0.0f;
-	int sp = 0, cur = kIdle, cell = 0;
+	uint32_t sp = sp0;
+	int cur = kIdle, cell = 0;
 	uint32_t irank = 0, unocc = 0;
 	float best_t = 0.0f, best_u = 0.0f, best_v = 0.0f;
 	int best_tri = -1;
@@ -386,10 +404,11 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 	// next pending node of the lane's ray: the popped reference, or kDone when nothing is pending -- an instance's exit
 	// marker with nothing above it ends the ray too (no need to restore the world-space ray first)
 	auto pop = [&]() {
-		const int spm = sp > 0 ? sp - 1 : 0;
-		const int popped = read_ref(spm);
-		cur = (sp == 0 || (popped == EXIT && spm == 0)) ? kDone : popped;
-		sp = spm;
+		const int popped = read_ref(sp);
+		const bool empty = sp == sp0;
+		const uint32_t spm = sp - kRow;
+		cur = (empty || (popped == EXIT && spm == sp0)) ? kDone : popped;
+		sp = empty ? sp : spm;
 	};
 
 	for (;;) {
@@ -424,7 +443,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 						const float4 e4 = st.occ_e[slot], a4 = acc[cell];
 						nee = xyz(e4); acc_old = xyz(a4);
 					}
-					sp = 0;
+					sp = sp0;
 					cur = B.root_ref;
 					irank = 0;
 					if (B.root_is_instance) { // enter the scene's one instance right away (intersect.cl:239-252; mul4x1 / mul3x1, util/transform.cl:9-26)
@@ -435,8 +454,8 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 						               I.r2.x * d.x + I.r2.y * d.y + I.r2.z * d.z};
 						o = no; d = nd;
 						irank = (uint32_t)I.meta.y;
-						push_ref(0, EXIT); // (nothing is ever pending below it: popping it ends the ray without a restore)
-						sp = 1;
+						push_ref(sp0, EXIT); // (nothing is ever pending below it: popping it ends the ray without a restore)
+						sp = sp0 + kRow;
 						cur = I.meta.x;
 					}
 					inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)}; // native_recip(ray.dir), intersect.cl:302
@@ -457,24 +476,25 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 				PairNode P;
 				if (TINY || (LDS_TOP && cur < kLdsTopNodes)) { P.lo0 = top[4 * cur]; P.hi0 = top[4 * cur + 1]; P.lo1 = top[4 * cur + 2]; P.hi1 = top[4 * cur + 3]; }
 				else P = B.pairs[cur];
-				// what a pop would deliver: read NOW, beside the node record (slot sp - 1; the push below writes slot sp), so the
+				// what a pop would deliver: read NOW, beside the node record (the push below writes the entry above it), so the
 				// stack's LDS round trip is off the step's dependent chain
-				const int spm = sp > 0 ? sp - 1 : 0;
-				const int popped = read_ref(spm);
-				float t0 = slab_entry_hw(P.lo0, P.hi0, o, inv, maxDist);
-				float t1 = slab_entry_hw(P.lo1, P.hi1, o, inv, maxDist);
+				const int popped = read_ref(sp);
+				const bool empty = sp == sp0;
+				const uint32_t spm = sp - kRow;
+				float t0, t1;
+				const bool e0 = slab_hit_hw(P.lo0, P.hi0, o, inv, maxDist, t0), e1 = slab_hit_hw(P.lo1, P.hi1, o, inv, maxDist, t1);
 				// closest hit: cull subtrees that start beyond the best hit (+inf factor = box does not bound its subtree)
-				const bool h0 = t0 < kFltMax && (ANY_HIT || !(t0 > best_t * P.hi0.w));
-				const bool h1 = t1 < kFltMax && (ANY_HIT || !(t1 > best_t * P.hi1.w));
+				const bool h0 = e0 && (ANY_HIT || !(t0 > best_t * P.hi0.w));
+				const bool h1 = e1 && (ANY_HIT || !(t1 > best_t * P.hi1.w));
 				// nearer child first for closest hits (what makes the cull bite); stored order for shadow rays
 				const bool second_first = h1 && (!h0 || (!ANY_HIT && t1 < t0));
 				const int c0 = fbits(P.lo0.w), c1 = fbits(P.lo1.w);
 				const int nearc = second_first ? c1 : c0, farc = second_first ? c0 : c1;
 				push_ref(sp, farc); // kept only when both children are hit (sp advances); otherwise the slot stays free
 				const bool both = h0 && h1, none = !(h0 || h1);
-				const int after_pop = (sp == 0 || (popped == EXIT && spm == 0)) ? kDone : popped;
+				const int after_pop = (empty || (popped == EXIT && spm == sp0)) ? kDone : popped;
 				cur = none ? after_pop : nearc;
-				sp = both ? sp + 1 : (none ? spm : sp);
+				sp = both ? sp + kRow : ((none && !empty) ? spm : sp);
 			}
 		} while (__popcll(__ballot(cur >= 0)) >= (ANY_HIT ? kStragglersAny : kStragglers));
 		// ---- phase 2: everything that is not an inner node ------------------------------------------------
@@ -499,7 +519,8 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 			if (li.y == 0) { // top-level leaf: enter the mesh instance (intersect.cl:239-252)
 				const InstRec I = B.insts[-li.x];
 				irank = (uint32_t)I.meta.y;
-				push_ref(sp++, EXIT);
+				push_ref(sp, EXIT);
+				sp += kRow;
 				// mul4x1 / mul3x1, util/transform.cl:9-26
 				const f3 no = {I.r0.x * o.x + I.r0.y * o.y + I.r0.z * o.z + I.r0.w, I.r1.x * o.x + I.r1.y * o.y + I.r1.z * o.z + I.r1.w,
 				               I.r2.x * o.x + I.r2.y * o.y + I.r2.z * o.z + I.r2.w};
@@ -543,8 +564,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 			if (__ballot(tl) != 0ull) {
 				const uint32_t code = (uint32_t)~cur;
 				const uint32_t first = code >> 4, ntri = tl ? (code & 15u) : 0u;
-				const int spm = sp > 0 ? sp - 1 : 0;
-				const int popped = read_ref(spm); // what follows the leaf: read beside the triangles, not after them
+				const int popped = read_ref(sp); // what follows the leaf: read beside the triangles, not after them
 				bool occluded = false;
 				uint32_t i = 0; // (bottom-tested: some lane holds a leaf, and a leaf has at least one triangle)
 				do {
@@ -579,7 +599,12 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 				} while (__ballot(i < ntri && !occluded) != 0ull);
 				if (tl) {
 					if (ANY_HIT && occluded) cur = kIdle; // blocked: nothing to add
-					else { cur = (sp == 0 || (popped == EXIT && spm == 0)) ? kDone : popped; sp = spm; }
+					else {
+						const bool empty = sp == sp0;
+						const uint32_t spm = sp - kRow;
+						cur = (empty || (popped == EXIT && spm == sp0)) ? kDone : popped;
+						sp = empty ? sp : spm;
+					}
 				}
 			}
 		}
