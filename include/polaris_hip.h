@@ -168,6 +168,14 @@ int polaris_hip_probe(polaris_hip_tracer *h, int kind, uint32_t index, uint32_t 
 int polaris_hip_probe_intersect(polaris_hip_tracer *h, const float *rays, uint32_t n, int any_hit, int32_t *hit,
                                 float *wuvt, int32_t *tri);
 
+/* Self-test of the one place where the kernels do NOT use the compiler's correctly rounded division: 1 / det of the
+ * triangle tests is v_rcp_f32 + one Newton step (3 instructions instead of 11).  Sweeps all 2^32 float bit patterns x on the
+ * device and counts those whose result differs from 1.0f / x, inside and outside lo <= |x| <= hi (`sample` = one differing
+ * pattern inside, may be NULL).  The claim the kernels rest on: none inside [2^-126, 2^126).  (The directions in
+ * polaris_hip_probe_intersect must be finite with components <= 2^10, origins <= 2^40; scenes: DESIGN.md 2.) */
+int polaris_hip_selftest_rcp(polaris_hip_tracer *h, float lo, float hi, uint64_t *mismatches_inside, uint64_t *mismatches_outside,
+                             uint32_t *sample);
+
 /* With option time_kernels=1: accumulated device milliseconds and launch count of the named
  * kernel ("generate", "intersect", "shade", "occlusion", "scan", "resolve", ...) since the
  * last call for that name. */

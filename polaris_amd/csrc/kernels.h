@@ -34,6 +34,17 @@ namespace pol {
 constexpr int WG = 256;            // threads per workgroup (4 wave64)
 constexpr int kExitMarker = (int)0x80000000;
 
+// 1 / det of the Moeller-Trumbore test in three instructions (v_rcp_f32 + one Newton step) instead of the eleven of the
+// correctly rounded division: bit-equal to 1.0f / x for EVERY float with 2^-126 <= |x| < 2^126 (all 2^32 patterns swept on the
+// GPU: polaris_hip_selftest_rcp, tests/test_gpu_probes.py).  Outside that interval the two differ (zeros, infinities,
+// denormal x, denormal results) -- the triangle tests only consume the quotient when |det| >= kEps, and the scene validation
+// bounds the coordinates so that |det| stays far below 2^126 (scene_layout.h, kMaxCoordinate).
+__device__ __forceinline__ float rcp_det(float x) {
+	const float r = __builtin_amdgcn_rcpf(x);
+	return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+}
+
+
 struct PairNode { float4 lo0, hi0, lo1, hi1; };  // .w of lo0/lo1 carry the child refs (int bits)
 struct TriRec { float4 v0, e1, e2; };             // v0.w = DFS rank, e1.w = scene triangle index (uint bits)
 struct InstRec { float4 r0, r1, r2; int4 meta; }; // meta.x = root ref, meta.y = rank
@@ -195,7 +206,7 @@ __device__ __forceinline__ bool traverse(const BvhDev &B, f3 O, f3 D, float maxD
 				f3 pv = cross(d, e2);
 				float det = dot(e1, pv);
 				if (pm_fabs(det) < kEps) continue;
-				float idet = pm_rcp(det);
+				float idet = rcp_det(det);
 				f3 tv = o - xyz(T.v0);
 				float u = dot(tv, pv) * idet;
 				if (u < 0.0f || u > 1.0f) continue;
@@ -537,7 +548,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 					const f3 pv = cross(d, e2);
 					const float det = dot(e1, pv);
 					if (pm_fabs(det) < kEps) continue;
-					const float idet = pm_rcp(det);
+					const float idet = rcp_det(det);
 					const f3 tv = o - xyz(T.v0);
 					const float u = dot(tv, pv) * idet;
 					if (u < 0.0f || u > 1.0f) continue;
@@ -574,7 +585,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 						const f3 pv = cross(d, e2);
 						const float det = dot(e1, pv);
 						bool ok = !(pm_fabs(det) < kEps);
-						const float idet = pm_rcp(det);
+						const float idet = rcp_det(det);
 						const f3 tv = o - xyz(T.v0);
 						const float u = dot(tv, pv) * idet;
 						ok = ok && !(u < 0.0f || u > 1.0f);
@@ -721,7 +732,7 @@ __global__ __launch_bounds__(WG) void k_trace_packet(Streams st, BvhDev B, float
 						const f3 pv = cross(d, e2);
 						const float det = dot(e1, pv);
 						bool ok = !(pm_fabs(det) < kEps);
-						const float idet = pm_rcp(det);
+						const float idet = rcp_det(det);
 						const f3 tv = o - xyz(T.v0);
 						const float u = dot(tv, pv) * idet;
 						ok = ok && !(u < 0.0f || u > 1.0f);
@@ -1270,6 +1281,24 @@ __global__ __launch_bounds__(WG) void k_probe(SceneDev Sg, int kind, uint32_t in
 		o[6] = L.pdf; o[7] = L.dist;
 		o[8] = light_pdf(sf, em, index, S, mk3(p[8], p[9], p[10]));
 	}
+}
+
+// polaris_hip_selftest_rcp: rcp_det against the correctly rounded 1.0f / x over ALL 2^32 float bit patterns.
+// out[0] = patterns with lo <= |x| <= hi that differ, out[1] = patterns outside that differ, out[2] = one differing pattern inside.
+__global__ __launch_bounds__(WG) void k_rcp_sweep(float lo, float hi, unsigned long long *out) {
+	const uint64_t stride = (uint64_t)gridDim.x * WG;
+	unsigned long long bad_in = 0, bad_out = 0, sample = 0;
+	for (uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x; i < (1ull << 32); i += stride) {
+		const float x = ibits((int)(uint32_t)i);
+		const float want = pm_rcp(x), got = rcp_det(x);
+		if (fbits(want) != fbits(got) && !(want != want && got != got)) { // (any NaN equals any NaN)
+			const float ax = pm_fabs(x);
+			if (ax >= lo && ax <= hi) { bad_in++; sample = i; }
+			else bad_out++;
+		}
+	}
+	if (bad_in) { atomicAdd(&out[0], bad_in); out[2] = sample; }
+	if (bad_out) atomicAdd(&out[1], bad_out);
 }
 
 // Arbitrary rays into the stream layout of the traversal kernels (polaris_hip_probe_intersect): slot i = ray i.

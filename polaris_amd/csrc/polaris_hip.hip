@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -928,6 +929,10 @@ int polaris_hip_probe_intersect(polaris_hip_tracer *h, const float *rays, uint32
 	if (n && (!rays || !hit)) return fail(h, POLARIS_E_BAD_ARGUMENT, "probe_intersect: null buffers");
 	if (n > (1u << 24)) return fail(h, POLARIS_E_BAD_ARGUMENT, "probe_intersect: at most 2^24 rays per call");
 	if (n == 0) return POLARIS_OK;
+	for (uint32_t i = 0; i < n; i++) // (what the tracer's own rays satisfy by construction; the triangle tests rely on it: kernels.h, rcp_det)
+		for (int k = 0; k < 3; k++)
+			if (!(std::fabs(rays[8 * (size_t)i + k]) <= kMaxCoordinate) || !(std::fabs(rays[8 * (size_t)i + 4 + k]) <= 1024.0f))
+				return fail(h, POLARIS_E_BAD_ARGUMENT, "probe_intersect: ray %u: origin beyond 2^40 or direction component beyond 2^10 (or not finite)", i);
 	HIP_TRY(h, hipSetDevice(h->device));
 	const uint32_t npad = (n + WG - 1) / WG * WG, wgs = npad / WG;
 	if (int rc = ensure_streams(h, 0, std::max<size_t>(h->pipe[0].slots, npad), false)) return rc;
@@ -966,6 +971,29 @@ int polaris_hip_probe_intersect(polaris_hip_tracer *h, const float *rays, uint32
 		if (t >= 0 && wuvt) { float *o = wuvt + 4 * (size_t)i; o[0] = 1.0f - (res[i].x + res[i].y); o[1] = res[i].x; o[2] = res[i].y; o[3] = res[i].z; } // intersect.cl:283-288
 		if (tri) tri[i] = t;
 	}
+	return POLARIS_OK;
+}
+
+int polaris_hip_selftest_rcp(polaris_hip_tracer *h, float lo, float hi, uint64_t *mismatches_inside, uint64_t *mismatches_outside, uint32_t *sample) {
+	if (!h) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "handle is null");
+	std::lock_guard<std::mutex> lk(h->mu);
+	if (!mismatches_inside || !mismatches_outside) return fail(h, POLARIS_E_BAD_ARGUMENT, "selftest_rcp: null outputs");
+	HIP_TRY(h, hipSetDevice(h->device));
+	unsigned long long *d = nullptr, res[3] = {0, 0, 0};
+	HIP_TRY(h, hipMalloc((void **)&d, sizeof res));
+	hipError_t e = hipMemcpyAsync(d, res, sizeof res, hipMemcpyHostToDevice, h->stream);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_rcp_sweep, dim3((uint32_t)h->num_cus * 32u), dim3(WG), 0, h->stream, lo, hi, d);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(res, d, sizeof res, hipMemcpyDeviceToHost, h->stream);
+	const hipError_t e2 = hipStreamSynchronize(h->stream);
+	(void)hipFree(d);
+	if (e == hipSuccess) e = e2;
+	if (e != hipSuccess) return fail(h, POLARIS_E_DEVICE, "selftest_rcp: %s", hipGetErrorString(e));
+	*mismatches_inside = res[0];
+	*mismatches_outside = res[1];
+	if (sample) *sample = (uint32_t)res[2];
 	return POLARIS_OK;
 }
 

@@ -45,6 +45,8 @@ static_assert(sizeof(PairNodeH) == 64 && sizeof(TriH) == 48 && sizeof(InstH) == 
 
 constexpr float kCullMargin = 1.001f; // a subtree is skipped when its box starts beyond kCullMargin x the best hit distance
 constexpr float kSplitCost = 1.0f;  // cost of one added pair-of-boxes step, in triangle tests (leaf subdivision)
+constexpr float kMaxCoordinate = 1099511627776.0f; // 2^40: largest vertex coordinate a scene may hold (build_layout, magnitudes)
+constexpr float kMaxMatrixEntry = 1073741824.0f;   // 2^30: largest entry of an instance matrix
 constexpr int kTraversalStack = 32; // entries per ray, == BVH_MAX_STACK_SIZE (intersect.cl:4)
 
 struct SceneLayout {
@@ -137,6 +139,21 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out, in
 	if (sc.num_material_nodes == 0 || !sc.material_nodes) return "scene has no material nodes";
 	if (sc.num_emissives && !sc.emissives) return "emissive list pointer is null";
 	if (sc.num_textures && (!sc.texture_meta || !sc.texture_data)) return "texture pointers are null";
+
+	// ---- magnitudes ------------------------------------------------------------------------
+	// The triangle tests take 1 / det from v_rcp_f32 + one Newton step, which equals the correctly rounded quotient for
+	// 2^-126 <= |det| < 2^126 (kernels.h, rcp_det).  det = e1 . (d x e2) with edges of at most 2 kMaxCoordinate and an instance
+	// space direction of at most 3 sqrt(3) kMaxMatrixEntry: < 2^118 with the bounds below, which no meaningful scene approaches.
+	for (size_t i = 0; i < (size_t)NT * 3; i++) {
+		const float *v = sc.vertices + 4 * i;
+		for (int k = 0; k < 3; k++)
+			if (!(std::fabs(v[k]) <= kMaxCoordinate)) // (also rejects NaN)
+				return "triangle " + std::to_string(i / 3) + ": vertex coordinate not finite or beyond 2^40";
+	}
+	for (uint32_t i = 0; i < NI; i++)
+		for (int k = 0; k < 16; k++)
+			if (!(std::fabs(sc.mesh_instances[i].inv_transform[k]) <= kMaxMatrixEntry))
+				return "mesh instance " + std::to_string(i) + ": matrix entry not finite or beyond 2^30";
 
 	// ---- materials / textures / emissives ------------------------------------------------
 	for (uint32_t t = 0; t < sc.num_textures; t++) {

@@ -117,6 +117,7 @@ C_ABI_SYMBOLS = [
     "polaris_hip_merge_device", "polaris_hip_sync_framebuffer", "polaris_hip_read_framebuffer",
     "polaris_hip_read_accumulator", "polaris_hip_tap_primary", "polaris_hip_abi_version",
     "polaris_hip_kernel_ms", "polaris_hip_reset_frame", "polaris_hip_probe", "polaris_hip_probe_intersect",
+    "polaris_hip_selftest_rcp",
 ]
 
 _lib = None
@@ -157,6 +158,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.polaris_hip_tap_primary.argtypes = [vp, C.POINTER(BlockRequest), u32, vp, vp, vp, vp]
     lib.polaris_hip_probe.argtypes = [vp, i32, u32, u32, vp, vp]
     lib.polaris_hip_probe_intersect.argtypes = [vp, vp, u32, i32, vp, vp, vp]
+    lib.polaris_hip_selftest_rcp.argtypes = [vp, C.c_float, C.c_float, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(u32)]
     lib.polaris_hip_kernel_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     for name in C_ABI_SYMBOLS:
         fn = getattr(lib, name)

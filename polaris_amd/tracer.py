@@ -181,6 +181,13 @@ class HipTracer:
                                                           wuvt.ctypes.data, tri.ctypes.data), self._h)
         return hit, wuvt, tri
 
+    def selftest_rcp(self, lo: float, hi: float) -> tuple[int, int, int]:
+        """polaris_hip_selftest_rcp: the triangle tests' 3-instruction reciprocal against 1.0f / x over all 2^32 floats.
+        Returns (mismatches with lo <= |x| <= hi, mismatches outside, bit pattern of one mismatch inside)."""
+        a, b, smp = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        self._check(self._lib.polaris_hip_selftest_rcp(self._h, lo, hi, C.byref(a), C.byref(b), C.byref(smp)), self._h)
+        return a.value, b.value, smp.value
+
     def kernel_ms(self, name: str) -> tuple[float, int]:
         ms, n = C.c_double(), C.c_uint64()
         self._check(self._lib.polaris_hip_kernel_ms(self._h, name.encode(), C.byref(ms), C.byref(n)), self._h)

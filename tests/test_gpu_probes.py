@@ -208,3 +208,43 @@ def test_arbitrary_rays_through_every_traversal_kernel(built, oracle, name):
         assert np.array_equal(tri[h], w_it[h, 1]), (name, opts)
         assert np.array_equal(bits(wuvt[h]), bits(w_wuvt[h])), (name, opts)
         assert np.array_equal(occ, w_occ), (name, opts, int((occ != w_occ).sum()))
+
+
+def test_the_triangle_tests_reciprocal_is_the_correctly_rounded_one(built):
+    """kernels.h rcp_det: 1 / det as v_rcp_f32 + one Newton step (3 instructions) instead of the 11 of the correctly
+    rounded division the rest of the code is built with.  polaris_hip_selftest_rcp sweeps ALL 2^32 float bit patterns
+    on the device: no pattern with 2^-126 <= |x| < 2^126 may differ from 1.0f / x.  (Outside it does differ -- zeros,
+    infinities, denormal arguments and denormal results: 3 * 2^24 patterns -- which is why the upload bounds the scene's
+    coordinates and the triangle tests ignore the quotient below INTERSECTION_EPSILON; the count is asserted so that the
+    sweep is known to discriminate.)"""
+    from polaris_amd import scenes
+
+    tr = make_hip_tracer(scenes.SCENES["cubes"](), 16, 16)
+    try:
+        below_2_126 = float(np.nextafter(np.float32(2.0 ** 126), np.float32(0)))
+        inside, outside, sample = tr.selftest_rcp(2.0 ** -126, below_2_126)
+        assert inside == 0, hex(sample)
+        assert 0 < outside <= 3 * 2 ** 24
+        everywhere, _, _ = tr.selftest_rcp(0.0, float("inf"))
+        assert everywhere == outside            # every mismatch lies outside the interval
+    finally:
+        tr.Close()
+
+
+def test_probe_rays_outside_the_supported_magnitudes_are_refused(built):
+    from polaris_amd import scenes
+    from polaris_amd.tracer import TracerError
+
+    tr = make_hip_tracer(scenes.SCENES["cubes"](), 16, 16)
+    try:
+        rays = np.zeros((4, 8), np.float32)
+        rays[:, 3] = 1e30
+        rays[:, 4] = 1.0
+        tr.probe_intersect(rays)
+        for col, bad in ((5, 2048.0), (5, np.nan), (1, 2.0 ** 41), (2, np.inf)):
+            r = rays.copy()
+            r[2, col] = bad
+            with pytest.raises(TracerError, match="ray 2"):
+                tr.probe_intersect(r)
+    finally:
+        tr.Close()

@@ -284,3 +284,25 @@ def test_multi_byte_texels_must_be_dword_aligned(harness):
         s2.texture_meta = meta
         rc, msg = _layout_error(harness, s2)
         assert (rc == 0) == ok and (ok or "not dword aligned" in msg), (fmt, rc, msg)
+
+
+def test_coordinates_beyond_the_supported_magnitude_are_rejected(harness):
+    """The triangle tests take 1 / det from v_rcp_f32 + one Newton step, which is the correctly rounded quotient only for
+    2^-126 <= |det| < 2^126 (kernels.h rcp_det; swept on the GPU by test_gpu_probes.py): the upload bounds what det is made
+    of -- vertex coordinates <= 2^40, instance matrix entries <= 2^30, both finite."""
+    assert _layout_error(harness, scenes.SCENES["cubes"]())[0] == 0
+    for bad in (np.float32(2.0 ** 41), np.float32(np.inf), np.float32(np.nan), np.float32(-3e38)):
+        sc = scenes.SCENES["cubes"]()
+        sc.vertices = sc.vertices.copy()
+        sc.vertices.reshape(-1, 4)[7, 1] = bad
+        rc, msg = _layout_error(harness, sc)
+        assert rc != 0 and "vertex coordinate" in msg, (bad, rc, msg)
+        sc = scenes.SCENES["cubes"]()
+        sc.mesh_instances = sc.mesh_instances.copy()
+        sc.mesh_instances[1]["inv_transform"][5] = bad
+        rc, msg = _layout_error(harness, sc)
+        assert rc != 0 and "matrix entry" in msg, (bad, rc, msg)
+    sc = scenes.SCENES["cubes"]()                       # the bound itself is accepted
+    sc.vertices = sc.vertices.copy()
+    sc.vertices.reshape(-1, 4)[7, 1] = np.float32(2.0 ** 40)
+    assert _layout_error(harness, sc)[0] == 0
