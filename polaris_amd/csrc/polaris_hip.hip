@@ -306,6 +306,13 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 	auto grid_of = [&](int resident) {
 		uint32_t per_cu = (uint32_t)std::max(1, resident);
 		if (std::min(h->opt_overlap, (int)polaris_hip_tracer::kMaxPipes) > 1 && !exact && per_cu > 2) per_cu = std::max(2u, per_cu * 2u / 3u);
+		// tiny-scene mode (two 1 024-thread workgroups fill a CU), small launches -- a row block of a multi-GPU frame: with two
+		// batches in flight a launch gets half the GPU at best, and at fewer than 4 chunks per resident wave a full-size grid
+		// leaves every wave a single chunk, i.e. nothing but its ramp-down.  One workgroup per CU then: a 64-row block of the
+		// headline frame 2.10 -> 1.83 ms, a 128-row block 3.30 -> 3.13 ms (256 rows +-0, the full frame +1 %: not applied there)
+		if (h->node_mode == kNodesLdsAll && std::min(h->opt_overlap, (int)polaris_hip_tracer::kMaxPipes) > 1 && !exact && per_cu == 2 &&
+		    (uint64_t)wgs < 4ull * (uint64_t)h->num_cus * per_cu * (kTinyBlock / 64))
+			per_cu = 1;
 		if (h->opt_trace_wgs_per_cu > 0) per_cu = (uint32_t)h->opt_trace_wgs_per_cu;
 		return std::min<uint32_t>(wgs, (uint32_t)h->num_cus * per_cu);
 	};
