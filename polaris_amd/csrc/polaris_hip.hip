@@ -584,7 +584,11 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 	h->scene = SceneDev{vertices, normals, uvs, mat_index, nodes, emissives, tex_meta, tex_data, sc->num_emissives,
 	                    sc->scene_diffuse_mat_index, sc->num_material_nodes, sc->num_textures, light_geo, sc->num_emissives ? pm_rcp((float)(int)sc->num_emissives) : 0.0f, L.tri_bits};
 	h->max_stack = L.max_stack;
-	if (h->opt_packet_primary < 0) h->packet_primary = sc->num_triangles <= 262144u;
+	// camera rays: the wave-packet kernel where a packet stays together -- one instance, a tree of moderate size.  Since the
+	// per-ray kernel's instruction diet the two are level on those scenes (headline 1.2 vs 1.0 ms of 11.3, sphere
+	// +-0, 58 K-triangle ball +-0); in a scene of many instances the packet's lanes part ways inside the instances: per-ray
+	// -5 % frame time on the 1 024-instance scene, -26 % on the 1 M-triangle terrain
+	if (h->opt_packet_primary < 0) h->packet_primary = sc->num_triangles <= 262144u && sc->num_mesh_instances == 1;
 	// node records: whole tree in LDS for tiny scenes, its top for small ones, global memory otherwise (kernels.h NodeMode)
 	const bool tiny_ok = L.pairs.size() <= (size_t)kTinyPairs && L.tris.size() <= kTinyMaxIndex && L.leaves.size() <= kTinyMaxIndex && L.max_stack <= 16;
 	h->node_mode = tiny_ok ? kNodesLdsAll : (L.pairs.size() <= (size_t)(POLARIS_LDS_TOP_MAX_PAIRS) ? kNodesLdsTop : kNodesGlobal);

@@ -67,7 +67,8 @@ def test_hip_vs_oracle_exact_and_batched(built, oracle, name):
     seeds = scenes.make_seeds(spp, B, base=1234)
     want, ws, wt = oracle.trace(sc, ob.make_request(W, H, spp=spp, bounces=B), seeds, tap_sample=0)
     variants = (({"exact_accumulate": 1}, True), ({"exact_accumulate": 1, "traversal": 0, "packet_primary": 0}, True),
-                ({"exact_accumulate": 1, "packet_primary": 0}, True), ({}, False),
+                ({"exact_accumulate": 1, "packet_primary": 0}, True), ({"exact_accumulate": 1, "packet_primary": 1}, True), ({}, False),
+                ({"packet_primary": 1, "samples_per_batch": 3}, False),   # (the default sends camera rays through the packet kernel in single-instance scenes only)
                 ({"samples_per_batch": 4}, False), ({"samples_per_batch": 1, "overlap": 3}, False),
                 ({"samples_per_batch": 2, "overlap": 1, "traversal": 0}, False),
                 # where k_trace reads its node records: global memory / top of the tree in LDS / (tiny scenes) whole tree in LDS
