@@ -12,14 +12,15 @@
 // path word = path index (24 bit, the reference keeps it as a float in dir.w,
 // util/ray.cl:9-12) | dispersion flags << 24 (util/path.cl:4-6).
 //
-// Compaction is per WORKGROUP, in place and stable: surviving rays of a workgroup's 256 slots
-// are packed to the front of the same 256 slots (ballot + popcount ranks inside a wave, LDS
-// across the 4 waves); cnt[wg] says how many are live and a tiny segmented scan turns the
-// counts into pfx[wg], the position the workgroup's first ray WOULD have in the reference's
-// globally compacted buffer.  pfx + lane is therefore exactly the `globalId` the reference
-// seeds the shading PRNG with (kernels/pt_integrator.cl:81) when its atomic compaction runs
-// in work-item order -- without ever moving a ray out of its pixel neighbourhood, without a
-// grid-wide dependency inside the shading kernel, and without host round trips.
+// Rays stay in their 256-slot chunk; their ORDER is data.  The rays a chunk emits are appended to the front of the same 256
+// slots in whatever order its waves finish (cnt[wg] says how many are live); what the reference's stable compaction would
+// have made of them is carried along: every indirect ray holds its parent's canonical index in thr.w, the chunk's 256-bit
+// emit mask (Streams::emask) turns that into the ray's own canonical index, and a tiny segmented scan (k_scan) turns the
+// per-chunk counts into pfx[wg], the position the chunk's first ray WOULD have in the reference's globally compacted
+// buffer.  pfx + canonical index is therefore exactly the `globalId` the reference seeds the shading PRNG with
+// (kernels/pt_integrator.cl:81) when its atomic compaction runs in work-item order -- without ever moving a ray out of
+// its pixel neighbourhood, without a grid-wide dependency inside the shading kernel, and without host round trips.
+// (Round 1 kept the physical order equal to the reference order; see k_shade for why that went.)
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -355,8 +356,10 @@ constexpr int kFirstLeafRef = (int)0x80000010;
 //   kNodesLdsAll  "tiny scene" mode (<= kTinyPairs pair records, < 2047 triangle slots and nodes, stack <= 16): the WHOLE tree
 //                 sits in LDS and is read with ds_read_b128 (no FLAT path, no L1 gathers for nodes).  What makes that fit at
 //                 full occupancy: workgroups of 1024 threads share ONE copy of the tree (32 KB) and the stack entries are
-//                 16-bit node codes (32 KB for 1024 lanes x 16 entries) -- 64 KB per workgroup, two workgroups = 8 waves per
-//                 SIMD.  (Round 1 tried the whole tree in LDS with 256-thread workgroups: 48 KB each, 3 per CU, +-0.)
+//                 16-bit node codes (34 KB for 1024 lanes x (16 entries + the dummy row below an empty stack)) -- 66 KB per
+//                 workgroup, two workgroups (132 KB of a CU's 160 KB) = 8 waves per SIMD: this mode exists for gfx950's LDS
+//                 and is static_assert-ed against it in k_trace.  (Round 1 tried the whole tree in LDS with 256-thread
+//                 workgroups: 48 KB each, 3 per CU, +-0.)
 enum NodeMode { kNodesGlobal = 0, kNodesLdsTop = 1, kNodesLdsAll = 2 };
 constexpr int kTinyPairs = 512;
 constexpr int kTinyBlock = 1024;
@@ -384,6 +387,8 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 	__shared__ uint32_t wg_cursor;
 	if (threadIdx.x == 0) wg_cursor = 0;
 	__shared__ float4 top[TINY ? kTinyPairs * 4 : (LDS_TOP ? kLdsTopNodes * 4 : 1)];
+	// tiny mode: the host's grid and occupancy heuristics assume TWO of these workgroups share a CU's 160 KB of LDS (gfx950)
+	static_assert(!TINY || 2 * (sizeof(stk) + sizeof(top) + 64) <= 160 * 1024, "tiny mode: two workgroups must fit one CU's LDS");
 	if (LDS_TOP || TINY) {
 		const uint32_t n4 = min((uint32_t)(TINY ? kTinyPairs : kLdsTopNodes), B.num_pairs) * 4;
 		const float4 *src = reinterpret_cast<const float4 *>(B.pairs);

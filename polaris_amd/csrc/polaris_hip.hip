@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "kernels_quad.h"
 #include "polaris_hip.h"
 
 using namespace pol;
@@ -47,6 +48,14 @@ struct polaris_hip_tracer {
 	hipStream_t stream = nullptr;
 	std::mutex mu;
 	std::string error;
+	// The frame accumulator belongs to the MERGE stream: the Reset stage, MergeOutput and merge_device run there, under
+	// merge_mu only -- never under `mu`, which a Trace holds from start to end -- so a secondary's MergeOutput onto the
+	// primary overlaps the primary's own Trace (Exec1DNoWait, tracer/opencl/resources.go:119; renderer/default.go:188-191
+	// calls it from the secondaries' goroutines).  SyncFramebuffer makes the main stream wait for the merges queued so far.
+	// Lock order: mu, then merge_mu.  W / H / frame_acc are written under both and may be read under either.
+	hipStream_t merge_stream = nullptr;
+	std::mutex merge_mu;
+	hipEvent_t ev_merged = nullptr;
 
 	// frame-sized state (buffers.go:127-174)
 	uint32_t W = 0, H = 0;
@@ -61,14 +70,20 @@ struct polaris_hip_tracer {
 	int max_stack = 0;
 	int node_mode = kNodesGlobal; // where k_trace reads node records from (kernels.h NodeMode), resolved at upload
 	int opt_node_mode = -1;       // -1 = by scene size
+	// four lanes per ray over the four-wide tree (kernels_quad.h); an A/B alternative to k_trace, off by default
+	Bvh4Dev bvh4{};
+	int quad_stack = 0;  // stack entries the collapsed tree needs (0 = not available)
+	int opt_wide = 0;    // option "wide": 1 = k_trace4 wherever the collapsed tree is available, 0 = k_trace
+	bool wide = false;   // resolved at upload
 	int trace_resident_per_cu = 6, occl_resident_per_cu = 6; // workgroups of the selected k_trace<closest | any hit> variant a CU holds at once (occupancy API, at upload)
 
 	// camera (tracer.go:175-179)
 	bool have_camera = false;
 	CameraArgs cam{};
 
-	// wavefront batch state: two pipelines so consecutive batches overlap (the sparse late-bounce
-	// launches of batch i run beside the dense early bounces of batch i+1 on the other stream)
+	// wavefront batch state: up to kMaxPipes pipelines (option "overlap", default 4; a Trace uses min(overlap, #batches) of
+	// them) so that consecutive batches overlap: the sparse late-bounce launches of batch i run beside the dense early
+	// bounces of batch i+1 on another stream
 	struct Pipe {
 		hipStream_t q = nullptr;
 		size_t slots = 0; // capacity in slots
@@ -106,6 +121,7 @@ struct polaris_hip_tracer {
 	// per-kernel timing (option time_kernels)
 	struct Pending { const char *name; hipEvent_t a, b; };
 	std::vector<Pending> pending;
+	std::vector<Pending> merge_pending; // launches on the merge stream (under merge_mu)
 	std::vector<hipEvent_t> event_pool;
 	std::map<std::string, KernelTimer> timers;
 	hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_fork = nullptr;
@@ -159,12 +175,13 @@ struct Timed {
 	polaris_hip_tracer *h;
 	const char *name;
 	hipStream_t q;
+	bool on_merge; // a launch on the merge stream: the caller holds merge_mu (not mu), so the event pool is not touched
 	hipEvent_t a = nullptr, b = nullptr;
-	Timed(polaris_hip_tracer *h_, const char *n, hipStream_t q_ = nullptr) : h(h_), name(n), q(q_ ? q_ : h_->stream) {
+	Timed(polaris_hip_tracer *h_, const char *n, hipStream_t q_ = nullptr, bool merge = false) : h(h_), name(n), q(q_ ? q_ : h_->stream), on_merge(merge) {
 		if (!h->opt_time_kernels) return;
 		auto get = [&]() {
 			hipEvent_t e;
-			if (!h->event_pool.empty()) { e = h->event_pool.back(); h->event_pool.pop_back(); }
+			if (!on_merge && !h->event_pool.empty()) { e = h->event_pool.back(); h->event_pool.pop_back(); }
 			else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
 			return e;
 		};
@@ -174,26 +191,42 @@ struct Timed {
 	~Timed() {
 		if (!a || !b) return;
 		(void)hipEventRecord(b, q);
-		h->pending.push_back({name, a, b});
+		(on_merge ? h->merge_pending : h->pending).push_back({name, a, b});
 	}
 };
 
-void collect_timers(polaris_hip_tracer *h) { // stream must be idle
-	for (auto &p : h->pending) {
-		float ms = 0.0f;
-		if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
-			auto &t = h->timers[p.name];
-			t.ms += ms;
-			t.launches++;
+void collect_timers(polaris_hip_tracer *h) { // caller holds mu; the main stream must be idle
+	auto take = [&](std::vector<polaris_hip_tracer::Pending> &list, bool may_be_running) {
+		std::vector<polaris_hip_tracer::Pending> keep;
+		for (auto &p : list) {
+			float ms = 0.0f;
+			const hipError_t e = hipEventElapsedTime(&ms, p.a, p.b);
+			if (e == hipErrorNotReady && may_be_running) { (void)hipGetLastError(); keep.push_back(p); continue; }
+			if (e == hipSuccess) {
+				auto &t = h->timers[p.name];
+				t.ms += ms;
+				t.launches++;
+			}
+			h->event_pool.push_back(p.a);
+			h->event_pool.push_back(p.b);
 		}
-		h->event_pool.push_back(p.a);
-		h->event_pool.push_back(p.b);
-	}
-	h->pending.clear();
+		list.swap(keep);
+	};
+	take(h->pending, false);
+	std::lock_guard<std::mutex> lk(h->merge_mu); // (another thread may be queueing a merge right now: its events stay pending)
+	take(h->merge_pending, true);
+}
+
+// Everything queued on the merge stream so far happens before whatever is queued on `q` next (caller holds mu).
+hipError_t join_merges(polaris_hip_tracer *h, hipStream_t q) {
+	std::lock_guard<std::mutex> lk(h->merge_mu);
+	hipError_t e = hipEventRecord(h->ev_merged, h->merge_stream);
+	if (e == hipSuccess) e = hipStreamWaitEvent(q, h->ev_merged, 0);
+	return e;
 }
 
 hipError_t sync_all(polaris_hip_tracer *h) { // every pipeline of the handle idle (before anything the kernels use is freed)
-	hipError_t first = hipSuccess;
+	hipError_t first = h->merge_stream ? hipStreamSynchronize(h->merge_stream) : hipSuccess;
 	for (int p = 0; p < polaris_hip_tracer::kMaxPipes; p++)
 		if (h->pipe[p].q) {
 			const hipError_t e = hipStreamSynchronize(h->pipe[p].q);
@@ -249,6 +282,10 @@ inline uint32_t grid_for(size_t n) { return (uint32_t)((n + WG - 1) / WG); }
 // (kernels.h, NodeMode).  fn = the kernel (for the occupancy query), block = its workgroup size.
 template <bool ANY_HIT>
 const void *trace_kernel(polaris_hip_tracer *h, int *block) {
+	if (h->wide) { // k_trace4<ANY_HIT, STACK>: one LDS stack column per RAY, so even the 64-entry variant keeps 8 workgroups per CU
+		*block = WG;
+		return h->quad_stack <= 32 ? (const void *)k_trace4<ANY_HIT, 32> : (const void *)k_trace4<ANY_HIT, 64>;
+	}
 	*block = h->node_mode == kNodesLdsAll ? kTinyBlock : WG;
 	if (h->node_mode == kNodesLdsAll) return (const void *)k_trace<ANY_HIT, 16, kNodesLdsAll>;
 	const bool top = h->node_mode == kNodesLdsTop;
@@ -261,7 +298,7 @@ template <bool ANY_HIT>
 void launch_trace(polaris_hip_tracer *h, polaris_hip_tracer::Pipe &P, uint32_t grid, uint32_t chunks, float4 *acc) {
 	int block = WG;
 	const void *fn = trace_kernel<ANY_HIT>(h, &block);
-	void *args[] = {(void *)&P.st, (void *)&h->bvh, (void *)&chunks, (void *)&acc, (void *)&h->d_stats};
+	void *args[] = {(void *)&P.st, h->wide ? (void *)&h->bvh4 : (void *)&h->bvh, (void *)&chunks, (void *)&acc, (void *)&h->d_stats};
 	(void)hipLaunchKernel(fn, dim3(grid), dim3(block), args, 0, P.q);
 }
 
@@ -416,6 +453,8 @@ int polaris_hip_create(int device_index, polaris_hip_tracer **out) {
 	for (int p = 1; p < polaris_hip_tracer::kMaxPipes && e == hipSuccess; p++) e = hipStreamCreateWithFlags(&h->pipe[p].q, hipStreamNonBlocking);
 	for (int p = 0; p < polaris_hip_tracer::kMaxPipes && e == hipSuccess; p++) e = hipEventCreateWithFlags(&h->pipe[p].done, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->merge_stream, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_merged, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipMalloc((void **)&h->d_stats, ST_COUNT * sizeof(unsigned long long));
 	if (e == hipSuccess) {
 		hipDeviceProp_t p;
@@ -440,7 +479,11 @@ void polaris_hip_destroy(polaris_hip_tracer *h) {
 		if (h->stream) (void)hipStreamSynchronize(h->stream);
 		for (int p = 1; p < polaris_hip_tracer::kMaxPipes; p++)
 			if (h->pipe[p].q) (void)hipStreamSynchronize(h->pipe[p].q);
+		if (h->merge_stream) (void)hipStreamSynchronize(h->merge_stream);
 		collect_timers(h);
+		std::lock_guard<std::mutex> lk_merge(h->merge_mu);
+		if (h->merge_stream) (void)hipStreamDestroy(h->merge_stream);
+		if (h->ev_merged) (void)hipEventDestroy(h->ev_merged);
 		for (auto e : h->event_pool) (void)hipEventDestroy(e);
 		for (auto &P : h->pipe) {
 			free_pool(P.bufs);
@@ -479,6 +522,7 @@ int polaris_hip_resize(polaris_hip_tracer *h, uint32_t frame_w, uint32_t frame_h
 	if (frame_w == 0 || frame_h == 0 || (uint64_t)frame_w * frame_h > (1ull << 28))
 		return fail(h, POLARIS_E_BAD_ARGUMENT, "bad frame dimensions %ux%u", frame_w, frame_h);
 	HIP_TRY(h, hipSetDevice(h->device));
+	std::lock_guard<std::mutex> lk_merge(h->merge_mu); // (the frame accumulator is the merge stream's)
 	HIP_TRY(h, sync_all(h));
 	if (h->trace_acc) (void)hipFree(h->trace_acc);
 	if (h->frame_acc) (void)hipFree(h->frame_acc);
@@ -519,7 +563,8 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 	free_pool(h->scene_bufs);
 	h->have_scene = false;
 	int rc = 0;
-	PairNode *pairs; int2 *leaves; TriRec *tris; InstRec *insts;
+	PairNode *pairs; int2 *leaves; TriRec *tris; InstRec *insts; QuadNode *quads;
+	rc |= dev_upload(h, h->scene_bufs, &quads, L.quads.data(), L.quads.size());
 	rc |= dev_upload(h, h->scene_bufs, &pairs, L.pairs.data(), L.pairs.size());
 	rc |= dev_upload(h, h->scene_bufs, &leaves, L.leaves.data(), L.leaves.size());
 	rc |= dev_upload(h, h->scene_bufs, &tris, L.tris.data(), L.tris.size());
@@ -578,9 +623,11 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 			h->bvh.root_inst.r0 = make_float4(I.r0[0], I.r0[1], I.r0[2], I.r0[3]);
 			h->bvh.root_inst.r1 = make_float4(I.r1[0], I.r1[1], I.r1[2], I.r1[3]);
 			h->bvh.root_inst.r2 = make_float4(I.r2[0], I.r2[1], I.r2[2], I.r2[3]);
-			h->bvh.root_inst.meta = make_int4(I.root_ref, (int)I.rank, 0, 0);
+			h->bvh.root_inst.meta = make_int4(I.root_ref, (int)I.rank, (int)I.pad[0], 0);
 		}
 	}
+	h->bvh4 = Bvh4Dev{quads, leaves, tris, insts, L.quad_root_ref, h->bvh.root_is_instance, h->bvh.root_inst};
+	h->quad_stack = L.quad_stack;
 	h->scene = SceneDev{vertices, normals, uvs, mat_index, nodes, emissives, tex_meta, tex_data, sc->num_emissives,
 	                    sc->scene_diffuse_mat_index, sc->num_material_nodes, sc->num_textures, light_geo, sc->num_emissives ? pm_rcp((float)(int)sc->num_emissives) : 0.0f, L.tri_bits};
 	h->max_stack = L.max_stack;
@@ -593,6 +640,9 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 	const bool tiny_ok = L.pairs.size() <= (size_t)kTinyPairs && L.tris.size() <= kTinyMaxIndex && L.leaves.size() <= kTinyMaxIndex && L.max_stack <= 16;
 	h->node_mode = tiny_ok ? kNodesLdsAll : (L.pairs.size() <= (size_t)(POLARIS_LDS_TOP_MAX_PAIRS) ? kNodesLdsTop : kNodesGlobal);
 	if (h->opt_node_mode >= 0 && (h->opt_node_mode != kNodesLdsAll || tiny_ok)) h->node_mode = h->opt_node_mode;
+	// four lanes per ray over the four-wide tree (kernels_quad.h): bit-exact, measured, and slower than one lane per ray on
+	// every scene tried -- so only on request (option "wide" = 1)
+	h->wide = h->quad_stack > 0 && h->opt_wide > 0;
 	h->trace_resident_per_cu = trace_occupancy<false>(h);
 	h->occl_resident_per_cu = trace_occupancy<true>(h);
 	h->have_scene = true;
@@ -623,6 +673,7 @@ int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value
 	else if (k == "packet_shadow") h->opt_packet_shadow = (int)std::max<int64_t>(0, std::min<int64_t>(value, POLARIS_MAX_BOUNCES));
 	else if (k == "time_kernels") h->opt_time_kernels = value != 0;
 	else if (k == "node_mode") h->opt_node_mode = (int)std::max<int64_t>(-1, std::min<int64_t>(value, 2)); // next upload; 2 only where the scene is tiny enough
+	else if (k == "wide") h->opt_wide = value != 0; // next upload
 	else if (k == "traversal") h->opt_traversal = value != 0; // 0 = one ray per lane (k_intersect / k_occlusion), 1 = persistent waves with lane refill (k_trace)
 	else if (k == "shade_wave") h->opt_shade_wave = value != 0;
 	else if (k == "shade_wave_from") h->opt_shade_wave_from = (int)std::max<int64_t>(-1, std::min<int64_t>(value, POLARIS_MAX_BOUNCES));
@@ -681,8 +732,10 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 	const size_t F = (size_t)h->W * h->H;
 	hipStream_t q = h->stream;
 	HIP_TRY(h, hipEventRecord(h->ev_start, q));
-	if (r->accumulated_samples == 0) // pipeline Reset stage (tracer.go:208-213)
-		HIP_TRY(h, hipMemsetAsync(h->frame_acc, 0, F * sizeof(float4), q));
+	if (r->accumulated_samples == 0) { // pipeline Reset stage (tracer.go:208-213): the frame accumulator lives on the merge stream
+		std::lock_guard<std::mutex> lk_merge(h->merge_mu);
+		HIP_TRY(h, hipMemsetAsync(h->frame_acc, 0, F * sizeof(float4), h->merge_stream));
+	}
 	HIP_TRY(h, hipMemsetAsync(h->trace_acc, 0, F * sizeof(float4), q)); // ClearTraceAccumulator (tracer.go:215)
 	HIP_TRY(h, hipMemsetAsync(h->d_stats, 0, ST_COUNT * sizeof(unsigned long long), q));
 	if (need_seeds) HIP_TRY(h, hipMemcpyAsync(h->d_seeds, seeds, need_seeds * sizeof(uint32_t), hipMemcpyHostToDevice, q));

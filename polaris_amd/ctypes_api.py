@@ -123,6 +123,42 @@ C_ABI_SYMBOLS = [
 _lib = None
 
 
+def _torch_first() -> None:
+    """The load-order rule of INTEGRATION.md section 4, enforced: this image's torch wheel bundles its own libamdhip64, and a
+    process in which libpolaris_hip.so (system libamdhip64) is loaded BEFORE torch has created its GPU context ends up with
+    polaris_hip_device_count() == 0.  If torch is already imported, make it touch the GPU now, before the library loads."""
+    import sys
+
+    torch = sys.modules.get("torch")
+    if torch is None:
+        return
+    try:
+        if torch.cuda.is_available() and not torch.cuda.is_initialized():
+            torch.cuda.init()
+    except Exception as e:  # a broken torch install must not be reported as a tracer problem later
+        raise RuntimeError(f"polaris_amd: torch is imported but its GPU context cannot be created ({e}); "
+                           f"libpolaris_hip.so must be loaded after torch has touched the GPU (INTEGRATION.md section 4)") from e
+
+
+def check_load_order(lib) -> None:
+    """Fail loudly on the other half of the trap: the library was loaded first, torch came later and sees GPUs the library
+    does not.  Called by HipTracer.Init before it reports 'no device'."""
+    import sys
+
+    torch = sys.modules.get("torch")
+    if torch is None or lib.polaris_hip_device_count() > 0:
+        return
+    try:
+        seen = torch.cuda.device_count()
+    except Exception:
+        seen = 0
+    if seen > 0:
+        raise RuntimeError(f"libpolaris_hip.so sees no HIP device while torch sees {seen}: the library was loaded before torch "
+                           f"created its GPU context (this image's torch bundles its own libamdhip64).  Import torch and call "
+                           f"torch.cuda.init() before the first polaris_amd.ctypes_api.load_library() / HipTracer() "
+                           f"(INTEGRATION.md section 4)")
+
+
 def load_library(path: str | None = None) -> C.CDLL:
     """Load libpolaris_hip.so (built in-tree by __graft_entry__.build()).  Fails loudly if absent:
     there is no CPU fallback for the product path."""
@@ -133,6 +169,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     if not os.path.exists(p):
         raise RuntimeError(f"{p} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; "
                            f"g.build()'); the tracer has no CPU fallback")
+    _torch_first()
     lib = C.CDLL(p)
     vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
     lib.polaris_hip_abi_version.restype = i32

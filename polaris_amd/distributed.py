@@ -89,6 +89,12 @@ class StripExchange:
             return [(0, self.rows[0], self.strips[i])]
         if work is not None:
             work.wait()
+        # On the nccl backend Work.wait() only makes torch's CURRENT STREAM wait for the collective; the host returns at once.
+        # The strip buffer is refilled two posts later from the tracer's own (non-blocking) HIP stream, which has no ordering
+        # against RCCL's stream -- so EVERY rank, not only dst, blocks here until its part of the gather has really finished.
+        # That also bounds the skew between ranks to the depth of the exchange.
+        if self.strips[i].is_cuda and not self.via_host:
+            torch.cuda.current_stream(self.strips[i].device).synchronize()
         if self.rank != self.dst:
             return None
         g = self.gathered[i]

@@ -34,6 +34,13 @@ def effective_cpus() -> int:
 def size_openmp() -> int:
     """Set OMP_NUM_THREADS (unless the caller's environment already does) to the CPUs this process may use, and make idle
     OpenMP threads sleep instead of spinning.  Call before the first OpenMP library is loaded.  Returns the thread count."""
-    n = int(os.environ.setdefault("OMP_NUM_THREADS", str(effective_cpus())))
+    cpus = effective_cpus()
+    raw = os.environ.setdefault("OMP_NUM_THREADS", str(cpus))
+    try:  # OpenMP allows a list ("8,2": one entry per nesting level); the outermost level is what sizes the team here
+        n = int(raw.split(",")[0].strip())
+    except ValueError:
+        n = 0
+    if n < 1:
+        n = cpus
     os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
     return n

@@ -82,6 +82,7 @@ class HipTracer:
         return self._speed
 
     def Init(self) -> None:
+        T.check_load_order(self._lib)
         name = C.create_string_buffer(256)
         cus, mhz, mem = C.c_uint32(), C.c_uint32(), C.c_uint64()
         self._check(self._lib.polaris_hip_device_info(self._device, name, C.byref(cus), C.byref(mhz), C.byref(mem)), None)

@@ -1,0 +1,27 @@
+"""scripts/pmc_sum.py <rocprofv3 output dir> -- per kernel symbol: launches and the sum of every collected counter,
+plus the derived SQ ratios when their counters are present."""
+import collections
+import csv
+import glob
+import sys
+
+f = glob.glob(sys.argv[1] + "/*/*counter_collection.csv")[0]
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+launches = collections.defaultdict(set)
+for r in csv.DictReader(open(f)):
+    k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+    agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+    launches[k].add(r["Dispatch_Id"])
+for k, d in sorted(agg.items()):
+    if "pol::" not in k:
+        continue
+    line = "%-44s launches=%d" % (k[-44:], len(launches[k]))
+    for c, v in sorted(d.items()):
+        line += " %s=%.4g" % (c, v)
+    if d.get("SQ_WAVES") and d.get("SQ_ACTIVE_INST_VALU") and d.get("SQ_WAVE_CYCLES"):
+        line += " | valu/wave=%.0f lane_util=%.3f valu_busy=%.3f wait_any=%.3f wait_inst=%.3f" % (
+            d["SQ_INSTS_VALU"] / d["SQ_WAVES"], d["SQ_THREAD_CYCLES_VALU"] / (64 * d["SQ_ACTIVE_INST_VALU"]),
+            d["SQ_ACTIVE_INST_VALU"] / d["SQ_WAVE_CYCLES"], d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"], d["SQ_WAIT_INST_ANY"] / d["SQ_WAVE_CYCLES"])
+    if d.get("TCC_HIT_sum") is not None and d.get("TCC_MISS_sum") is not None and d["TCC_HIT_sum"] + d["TCC_MISS_sum"] > 0:
+        line += " | l2_hit=%.3f" % (d["TCC_HIT_sum"] / (d["TCC_HIT_sum"] + d["TCC_MISS_sum"]))
+    print(line)

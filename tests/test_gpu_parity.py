@@ -72,8 +72,11 @@ def test_hip_vs_oracle_exact_and_batched(built, oracle, name):
                 ({"samples_per_batch": 4}, False), ({"samples_per_batch": 1, "overlap": 3}, False),
                 ({"samples_per_batch": 2, "overlap": 1, "traversal": 0}, False),
                 # where k_trace reads its node records: global memory / top of the tree in LDS / (tiny scenes) whole tree in LDS
-                ({"exact_accumulate": 1, "node_mode": 0}, True), ({"exact_accumulate": 1, "node_mode": 1}, True),
-                ({"exact_accumulate": 1, "node_mode": 2}, True), ({"node_mode": 1, "samples_per_batch": 3}, False),
+                ({"exact_accumulate": 1, "node_mode": 0, "wide": 0}, True), ({"exact_accumulate": 1, "node_mode": 1, "wide": 0}, True),
+                ({"exact_accumulate": 1, "node_mode": 2}, True), ({"node_mode": 1, "wide": 0, "samples_per_batch": 3}, False),
+                # four lanes per ray over the four-wide tree (k_trace4), with the leaves the upload makes by default, the caller's, and 4-triangle ones
+                ({"exact_accumulate": 1, "wide": 1}, True), ({"exact_accumulate": 1, "wide": 1, "max_leaf_tris": 0}, True),
+                ({"exact_accumulate": 1, "wide": 1, "max_leaf_tris": 4, "packet_primary": 0}, True), ({"wide": 1, "samples_per_batch": 3}, False),
                 ({"exact_accumulate": 1, "shade_wave": 0}, True), ({"exact_accumulate": 1, "shade_wave_from": 0}, True),
                 ({"shade_wave": 0, "stage_lds": 0, "samples_per_batch": 3}, False), ({"shade_wave_from": 1, "samples_per_batch": 2}, False),
                 # shading order: never sorted by class / sorted from bounce 2 / sorted with the tables in global memory
@@ -429,9 +432,10 @@ def test_frames_of_the_other_configs_against_the_oracle(built, oracle, name, W, 
 
 @pytest.mark.parametrize("name", ["material-ball", "instanced"])
 def test_big_scene_kernel_variants_agree_with_the_oracle(built, oracle, name):
-    """Scenes that select the other kernel variants -- 24-entry traversal stack, no LDS tree top, leaves
-    of up to 4 triangles, (for > 256 K triangles) per-ray camera traversal -- traced in exact mode with
-    each upload / traversal option flipped: all bit-identical to the CPU oracle."""
+    """Scenes that select the other kernel variants -- four lanes per ray over the four-wide tree (the default where the
+    tree does not fit LDS) and, with wide=0, the one-lane-per-ray kernel with its 24-entry stack and no LDS tree top;
+    leaves of up to 4 triangles, (for > 256 K triangles) per-ray camera traversal -- traced in exact mode with each
+    upload / traversal option flipped: all bit-identical to the CPU oracle."""
     from oracle import pybind as ob
     from polaris_amd import scenes
 
@@ -441,7 +445,8 @@ def test_big_scene_kernel_variants_agree_with_the_oracle(built, oracle, name):
     seeds = scenes.make_seeds(spp, B, base=21)
     want, wst, _ = oracle.trace(sc, req, seeds)
     assert wst.shaded_hits > 0
-    for opts in ({}, {"max_leaf_tris": 0}, {"max_leaf_tris": 1}, {"packet_primary": 0}, {"traversal": 0}, {"stage_lds": 0}, {"node_mode": 0}, {"node_mode": 2}):
+    for opts in ({}, {"max_leaf_tris": 0}, {"max_leaf_tris": 1}, {"packet_primary": 0}, {"traversal": 0}, {"stage_lds": 0}, {"node_mode": 0}, {"node_mode": 2},
+                 {"wide": 0}, {"wide": 0, "max_leaf_tris": 0}, {"wide": 0, "packet_primary": 0}, {"wide": 0, "node_mode": 1}, {"wide": 1, "max_leaf_tris": 2}):
         tr = make_hip_tracer(sc, W, H, exact_accumulate=1, **opts)
         try:
             tr.Trace(req, seeds)
