@@ -18,17 +18,22 @@ the timed region starts.
 
 Prints ONE JSON line (rank 0).  `value` = rays traced by all ranks in the K timed frames / wall
 time (max over ranks); rays = primary + indirect + occlusion rays handed to an intersection kernel
-(BASELINE.md section 3).  `roofline` prices the dominant kernel against HBM: algorithmic bytes
-(SURVEY.md 8d split per kernel) / its HIP-event time.  `cpu_baseline` times the CPU
-restatement under oracle/ (the checker, never the product) on a bounded sample of the same
-workload on the host cores.
+(BASELINE.md section 3).  `roofline` prices ONE kernel symbol -- the one with the largest isolated
+time -- against HBM: algorithmic bytes (SURVEY.md 8d split per kernel) / its HIP-event
+time; `roofline_per_kernel` holds the same object for every symbol that moves ray streams.
+`cpu_baseline` times the CPU restatement under oracle/ (the checker, never the product) on a bounded
+sample of the same workload on the host cores.
+
+`--inproc` runs the same frame the way the reference itself does: ONE process, one worker thread per
+GPU (polaris_amd/host/renderer.cpp), blocks merged into the primary by polaris_hip_merge over xGMI
+peer access, `--scheduler naive|perfect` (tracer/scheduler.go) -- no torch.distributed, no collective.
+The driver's launcher (one process per GPU under torch.distributed.run) always gets the default mode.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
-import socket
 import subprocess
 import sys
 import time
@@ -38,23 +43,56 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-KERNELS = ("generate", "intersect_packet", "intersect", "shade", "scan", "occlusion", "resolve", "aggregate", "tonemap")
+SHADE_TIMERS = ("shade_first", "shade_sort", "shade_plain", "shade_wave")  # one library timer per shade kernel symbol
+KERNELS = ("generate", "intersect_packet", "intersect", *SHADE_TIMERS, "scan", "occlusion", "resolve", "aggregate", "tonemap")
+PRICED = ("generate", "intersect_packet", "intersect", *SHADE_TIMERS, "occlusion")  # the kernels that move ray streams
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
 
-def kernel_algorithmic_bytes(st: dict) -> dict:
-    """SURVEY.md 8d per-unit stream bytes, attributed to the kernel that moves them
-    (intersect_packet = k_trace_packet on camera rays, intersect = k_trace<closest> on bounce rays)."""
-    return {
-        # camera rays: SURVEY's 52 + 60 B minus what is constant for a camera ray and therefore neither stored nor read
-        # (origin | max distance: 16 B written + 16 B read; throughput: 16 B written)
-        "generate": 20 * st["primary_rays"],
-        "intersect_packet": 44 * st["primary_rays"],
-        "intersect": 60 * st["indirect_rays"],
-        "shade": 68 * st["shaded_hits"] + 32 * st["indirect_rays"] + 44 * st["occlusion_rays"]
-        + 60 * st["shaded_misses"] + 24 * st["emitter_hits"],
-        "occlusion": 36 * st["occlusion_rays"] + 44 * st["unoccluded"],
+def kernel_algorithmic_bytes(st, shade_counts, B: int, packet_camera: bool) -> dict:
+    """SURVEY.md 8d per-unit stream bytes, attributed to the library timer (= kernel symbol) that moves them.
+    st = PolarisTraceStats of one frame, shade_counts = HipTracer.shade_counts(B) of the same frame."""
+    prim, rays, occl = int(st.primary_rays), [int(v) for v in st.rays_per_bounce], [int(v) for v in st.occl_per_bounce]
+    out = {
+        # camera rays: SURVEY's 52 B minus what is constant for a camera ray and therefore not stored (origin | max distance,
+        # throughput) = 20 B -- plus the 16 B per path slot of the batch's per-path radiance, which k_generate zeroes
+        # (and the origin after all when the per-ray kernel, which reads it, traces the camera rays)
+        "generate": (20 + 16 + (0 if packet_camera else 16)) * prim,
+        "intersect_packet": 44 * prim if packet_camera else 0,
+        "intersect": 60 * (int(st.indirect_rays) + (0 if packet_camera else prim)),
+        "occlusion": 36 * int(st.occlusion_rays) + 44 * int(st.unoccluded),
     }
+    for name in SHADE_TIMERS:
+        out[name] = 0
+    for b in range(B):  # the shade step of bounce b: 68 B per shaded hit, 60 per shaded miss, 24 per emitter hit, 32 per emitted bounce ray, 44 per shadow ray
+        c = shade_counts[b]
+        out[c["timer"]] += 68 * c["hits"] + 60 * c["misses"] + 24 * c["emitters"] + 32 * (rays[b + 1] if b + 1 < B else 0) + 44 * occl[b]
+    return out
+
+
+def committed_counters(symbol: str, workload_is_headline: bool):
+    """PMC data cannot be collected inside this run (rocprofv3 --pmc passes: scripts/traffic.sh, scripts/pmc.sh); they are read
+    from the newest committed profile of the headline workload, keyed by kernel symbol.  Returns (hbm bytes per launch,
+    lane utilisation, description of the source) -- None where there is no committed number for this symbol."""
+    if not workload_is_headline:
+        return None, None, None
+    import glob
+
+    traffic = lane_util = None
+    src = []
+    for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        ent = json.load(open(tpath)).get("kernels", {}).get(symbol)
+        if ent and ent.get("launches"):
+            traffic = (ent["hbm_read_bytes"] + ent["hbm_write_bytes"]) / ent["launches"]
+            src.append("profiles/" + os.path.basename(tpath) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 1`)")
+            break
+    for spath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_counters.json")), reverse=True):
+        ent = json.load(open(spath)).get("kernels", {}).get(symbol)
+        if ent and "lane_util" in ent:
+            lane_util = ent["lane_util"]
+            src.append("profiles/" + os.path.basename(spath) + " (SQ_THREAD_CYCLES_VALU / 64 / SQ_ACTIVE_INST_VALU)")
+            break
+    return traffic, lane_util, ("; ".join(src) + "; collected on the builder's MI355X lease, not re-measured in this run") if src else None
 
 
 def host_cpu() -> str:
@@ -64,6 +102,69 @@ def host_cpu() -> str:
         return f"{len(models)} x {models[0]}" if models else f"{os.cpu_count()} logical CPUs"
     except OSError:
         return f"{os.cpu_count()} logical CPUs"
+
+
+def run_inproc(args) -> None:
+    """`--inproc`: the frame loop of renderer/default.go:106-196 as the reference runs it -- one process, one worker thread per
+    tracer (polaris_amd/host/renderer.cpp), every tracer Trace()s the rows the scheduler hands it, the workers MergeOutput
+    into the primary (tracer 0) through polaris_hip_merge -- xGMI peer access when the block lives on another GPU -- and the
+    primary tone-maps.  No collective anywhere ("independent tiles, so no RCCL").  A step = one renderFrame()."""
+    from polaris_amd import ctypes_api as T
+    from polaris_amd import host_api, scenes
+
+    lib = T.load_library()
+    visible = lib.polaris_hip_device_count()
+    if visible < 1:
+        raise SystemExit("bench.py needs a GPU: the tracer has no CPU fallback")
+    devices = [int(v) for v in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    if len(devices) != args.gpus:
+        raise SystemExit(f"bench.py --inproc --gpus {args.gpus}: --devices names {len(devices)} tracer(s)")
+    if max(devices) >= visible or min(devices) < 0:
+        raise SystemExit(f"bench.py --inproc --gpus {args.gpus}: only {visible} HIP device(s) visible on this host")
+    W, H, spp, B = args.width, args.height, args.spp, args.bounces
+    sc = scenes.SCENES[args.scene](W / H)
+    r = host_api.Renderer(sc, devices, primary=0, scheduler=host_api.PERFECT if args.scheduler == "perfect" else host_api.NAIVE, width=W, height=H,
+                          spp=spp, bounces=B, min_rr=args.rr, exposure=1.2, seed=1)
+    try:
+        if args.samples_per_batch:
+            r.set_option("samples_per_batch", args.samples_per_batch)
+        for kv in args.opt:
+            k, v = kv.split("=")
+            r.set_option(k, int(v))
+        rows = None
+        for _ in range(args.warmup):               # (the perfect scheduler settles on its rows here: it feeds on the last frame's times)
+            rows, _ = r.render(0)
+        rays = 0
+        all_rows = []
+        t0 = time.perf_counter()
+        for f in range(args.steps):
+            if args.test_seeds:
+                for t in range(len(devices)):
+                    r.push_seeds(t, scenes.make_seeds(spp, B, base=1000 * f + 17 * t))
+            rows, _ = r.render(0)                  # synchronous: every Trace, every merge and the primary's tone-map are done
+            all_rows.append(rows)
+            rays += sum(r.tracer_stats(i)[0].total_rays() for i in range(len(devices)))
+        elapsed = time.perf_counter() - t0
+        trace_ms = [round(r.tracer_stats(i)[1], 3) for i in range(len(devices))]
+        if args.save_accumulator:
+            np.save(args.save_accumulator, r.read()[1])
+        if args.save_png:
+            r.save(args.save_png)
+    finally:
+        r.close()
+    ms = elapsed / args.steps * 1e3
+    print(json.dumps({
+        "metric": "Mrays/s (primary+indirect+occlusion rays traced / wall), Cornell box 512x512x128spp",
+        "value": rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": len(set(devices)), "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms, "ms_per_frame": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{sc.name} {W}x{H} {spp}spp {B} bounces rr>={args.rr}, {sc.num_triangles} tris, row blocks {rows} of the last frame "
+                               f"({args.scheduler} scheduler), merge into the primary + tonemap",
+                   "mode": "in-process: one worker thread per tracer, polaris_hip_merge (peer access), no collective", "tracers": len(devices), "devices": devices,
+                   "scheduler": args.scheduler, "rows_first_timed_frame": all_rows[0] if all_rows else None, "rows_last_frame": rows,
+                   "trace_ms_last_frame_per_tracer": trace_ms, "frame": [W, H], "spp": spp, "bounces": B, "rays_per_frame": rays // max(args.steps, 1),
+                   "paths_per_s": W * H * spp * args.steps / elapsed},
+        "roofline": None, "cpu_baseline": None,
+        "note": "roofline / cpu_baseline are measured by the default (one process per GPU) mode at N = 1; this mode times the reference's in-process frame loop"}))
 
 
 def main() -> None:
@@ -87,7 +188,17 @@ def main() -> None:
     ap.add_argument("--same-device", action="store_true", help="testing aid: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--emulate-rank", default="", help="R/N: on ONE GPU, trace only the row block rank R of N would own "
                     "(tuning aid for the strong-scaling path; not a valid bench line)")
+    ap.add_argument("--inproc", action="store_true", help="ONE process, one worker thread per GPU, blocks merged into the primary over peer access "
+                    "(polaris_hip_merge): the reference renderer's own model (renderer/default.go:106-196); no torch.distributed, no RCCL")
+    ap.add_argument("--devices", default="", help="--inproc: comma separated device index per tracer (default 0..N-1; repeating a device, "
+                    "e.g. 0,0,0, runs several tracers on one GPU: a testing aid)")
+    ap.add_argument("--scheduler", default="naive", choices=("naive", "perfect"), help="--inproc: block scheduler (tracer/scheduler.go); "
+                    "`polaris render` uses the naive one (cmd/render.go:65)")
+    ap.add_argument("--test-seeds", action="store_true", help="testing aid: fixed host PRNG draws -- --inproc: tracer t of frame f draws from "
+                    "make_seeds(base = 1000 f + 17 t); default mode: frame f uses make_seeds(base = 0xC0FFEE + f) instead of one list for every frame")
     args = ap.parse_args()
+    if args.inproc:
+        return run_inproc(args)
 
     from polaris_amd.hostinfo import size_openmp
 
@@ -106,11 +217,9 @@ def main() -> None:
             visible = torch.cuda.device_count()
             if visible < args.gpus:
                 raise SystemExit(f"bench.py --gpus {args.gpus}: only {visible} HIP device(s) visible on this host")
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        # (--standalone: torchrun picks a free rendezvous port itself -- no bind / close / reuse race on a busy box)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               os.path.abspath(__file__), *sys.argv[1:]]
         raise SystemExit(subprocess.run(cmd).returncode)
 
     rank = int(os.environ.get("RANK", "0"))
@@ -188,9 +297,15 @@ def main() -> None:
         while pending:
             finish_frame(pending.pop(0))
 
+    frame_no = [0]
+
     def frame(count: bool):
         req = make_req(block_y, block_h)
-        tr.Trace(req, seeds)                       # Trace (tracer.go:194-247)
+        fseeds = seeds
+        if args.test_seeds:                        # a different frame every step: a strip merged one frame late or early shows
+            fseeds = scenes.make_seeds(spp, B, base=0xC0FFEE + frame_no[0])
+            frame_no[0] += 1
+        tr.Trace(req, fseeds)                      # Trace (tracer.go:194-247)
         if count:
             st = tr.last_trace_stats
             for k in totals:
@@ -254,62 +369,43 @@ def main() -> None:
                        "frame": [W, H], "spp": spp, "bounces": B, "rays_per_frame": rays // args.steps,
                        "paths_per_s": W * H * spp * args.steps / elapsed},
         }
-        # ---- roofline of the dominant kernel ---------------------------------------------------
+        # ---- roofline, per kernel symbol -----------------------------------------------------------
         # Kernel durations are HIP events on the tracer's own streams (the library brackets every launch
-        # when time_kernels=1).  They are NOT taken inside the timed region (event pairs around ~88 launches
-        # per frame, and up to four batches share the GPU there): ONE extra frame is traced afterwards with
-        # overlap=1 -- same kernels, same inputs, one batch at a time -- and the roofline uses those times.
+        # when time_kernels=1; one timer per kernel symbol).  They are NOT taken inside the timed region (event
+        # pairs around ~88 launches per frame, and up to four batches share the GPU there): ONE extra frame is
+        # traced afterwards with overlap=1 -- same kernels, same inputs, one batch at a time.  `roofline` is the
+        # symbol with the largest isolated time (the top row of `rocprofv3 --kernel-trace --stats` on the same
+        # command, profiles/r*_kernel_stats_overlap1.csv); `roofline_per_kernel` holds the same object for every
+        # symbol that moves ray streams.
         if not args.no_kernel_timers:
-            mine = {k: totals[k] // args.steps for k in totals}     # per-frame counters of rank 0
             tr.set_option("overlap", 1)
             tr.set_option("time_kernels", 1)
             for name in KERNELS:
                 tr.kernel_ms(name)
             tr.Trace(make_req(block_y, block_h), seeds)   # local to rank 0: no collective in here
-            iso = {name: tr.kernel_ms(name) for name in KERNELS[:-2]}
-            alg = kernel_algorithmic_bytes(mine)
-            dom = max(("generate", "intersect_packet", "intersect", "shade", "occlusion"), key=lambda k: iso[k][0])
-            ms, n = iso[dom]
-            achieved = alg[dom] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            # HBM traffic per launch of that kernel: PMC data (FETCH_SIZE x2 + WRITE_SIZE, separate passes: scripts/traffic.sh)
-            # cannot be collected inside this run; it is read from the newest committed profile of THIS workload, and
-            # traffic_source says which file that was (null + null when there is none for the workload).
-            traffic, traffic_source = None, None
-            if (W, H, spp, B, args.scene, world) == (512, 512, 128, 5, "cornell", 1):
-                import glob
-
-                for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
-                    tj = json.load(open(tpath))
-                    ent = tj.get("timers", {}).get(dom)
-                    if ent is None:  # round-1 file: keyed by kernel name
-                        kn = {"intersect": ("pol::k_trace<false",), "occlusion": ("pol::k_trace<true",), "shade": ("pol::k_shade<", "pol::k_shade_wave<"),
-                              "generate": ("pol::k_generate",), "intersect_packet": ("pol::k_trace_packet<false>",)}[dom]
-                        tks = [v for k, v in tj["kernels"].items() if k.startswith(kn)]
-                        if tks:
-                            ent = {"hbm_bytes": sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for v in tks), "launches": sum(v["launches"] for v in tks)}
-                    if ent and ent.get("launches"):
-                        traffic = ent["hbm_bytes"] / ent["launches"]
-                        traffic_source = "profiles/" + os.path.basename(tpath) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 1`, " \
-                            "collected on the builder's MI355X lease; not re-measured in this run)"
-                        break
-            names = {"intersect": "k_trace<false,...> (closest hit, bounce rays)", "intersect_packet": "k_trace_packet<false> (camera rays)",
-                     "occlusion": "k_trace<true,...> (any hit + NEE accumulate)", "shade": "k_shade + k_shade_wave (shadeHits, miss shading, compaction)",
-                     "generate": "k_generate"}
-            out["roofline"] = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                               "algorithmic_bytes_per_launch": alg[dom] / max(n, 1), "avg_launch_ms": ms / max(n, 1), "launches": n,
-                               "measured": "HIP events, one extra frame with overlap=1 after the timed region"}
-            # the same object for every traversal / shading kernel (the dominant one is repeated above as `roofline`)
+            iso = {name: tr.kernel_ms(name) for name in KERNELS}
+            symbols = {name: tr.kernel_symbol(name) for name in PRICED}
+            fst = tr.last_trace_stats
+            alg = kernel_algorithmic_bytes(fst, tr.shade_counts(B), B, packet_camera=iso["intersect_packet"][1] > 0)
+            headline = (W, H, spp, B, args.scene, world, args.opt) == (512, 512, 128, 5, "cornell", 1, [])
             per_kernel = {}
-            for k in ("generate", "intersect_packet", "intersect", "shade", "occlusion"):
+            for k in PRICED:
                 kms, kn_ = iso[k]
-                if kms > 0 and kn_:
-                    ach = alg[k] / (kms * 1e-3) / 1e9
-                    per_kernel[k] = {"kernel": names[k], "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "avg_launch_ms": round(kms / kn_, 4),
-                                     "launches": kn_, "algorithmic_bytes_per_launch": round(alg[k] / kn_)}
+                if kms <= 0 or not kn_:
+                    continue
+                ach = alg[k] / (kms * 1e-3) / 1e9
+                traffic, lane_util, source = committed_counters(symbols[k], headline)
+                per_kernel[symbols[k]] = {"bound": "hbm", "kernel": symbols[k], "timer": k, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "lane_util": lane_util, "counters_source": source,
+                                          "algorithmic_bytes_per_launch": alg[k] / kn_, "avg_launch_ms": kms / kn_, "launches": kn_, "ms_per_frame": kms,
+                                          "measured": "HIP events, one extra frame with overlap=1 after the timed region"}
+            if per_kernel:
+                dom = max(per_kernel.values(), key=lambda e: e["ms_per_frame"])
+                out["roofline"] = dict(dom)
             out["roofline_per_kernel"] = per_kernel
-            out["kernels_isolated_ms_per_frame"] = {k: round(v[0], 3) for k, v in iso.items()}
-            out["kernels_isolated_GBps_algorithmic"] = {k: round(alg[k] / (iso[k][0] * 1e-3) / 1e9, 1) for k in alg if iso[k][0] > 0}
+            shade_ms = sum(iso[k][0] for k in SHADE_TIMERS)
+            out["kernels_isolated_ms_per_frame"] = {**{k: round(v[0], 3) for k, v in iso.items() if k not in ("aggregate", "tonemap")}, "shade": round(shade_ms, 3)}
+            mine = {k: totals[k] // args.steps for k in totals}     # per-frame counters of rank 0
             whole = (112 * mine["primary_rays"] + 68 * mine["shaded_hits"] + 92 * mine["indirect_rays"] + 80 * mine["occlusion_rays"]
                      + 44 * mine["unoccluded"] + 60 * mine["shaded_misses"] + 24 * mine["emitter_hits"] + (48 + 16) * rows[0] * W)
             out["whole_path_algorithmic_GBps_rank0"] = whole / (elapsed / args.steps) / 1e9

@@ -110,9 +110,14 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *req, con
                       size_t n_seeds, PolarisTraceStats *stats);
 
 /* Tracer.MergeOutput: dst.frameAccumulator[rows of req] += src.traceAccumulator[rows of req].
- * Asynchronous on dst's merge stream like the reference (Exec1DNoWait, resources.go:119);
- * completed by polaris_hip_sync_framebuffer(dst).  src may live on another GPU of the same
- * process (peer access over xGMI, falling back to a staged peer copy). */
+ * Asynchronous like the reference (Exec1DNoWait, resources.go:119): queued on dst's MERGE stream -- the
+ * stream that owns the frame accumulator (the Reset stage, merges) -- under a mutex of its own, so it does
+ * not wait for a Trace running on dst (renderer/default.go:188-191 merges from the secondaries' goroutines
+ * while the primary still traces); completed by polaris_hip_sync_framebuffer(dst).  The caller orders it
+ * after src's Trace (synchronous) and after the START of dst's Trace of the same frame, which clears the
+ * frame accumulator when accumulated_samples == 0 (the reference races there; polaris_amd/host/renderer.cpp
+ * waits).  src may live on another GPU of the same process (peer access over xGMI, falling back to a
+ * staged peer copy). */
 int polaris_hip_merge(polaris_hip_tracer *dst, polaris_hip_tracer *src, const PolarisBlockRequest *req);
 
 /* One-process-per-GPU variant of the same exchange (bench.py under torch.distributed):
@@ -127,6 +132,15 @@ int polaris_hip_merge_device(polaris_hip_tracer *dst, const void *device_rows, c
  * frame's Trace has started (bench.py keeps the strip exchange one frame behind the tracing) calls it before
  * merging, so that exactly one frame's blocks are ever summed.  Asynchronous on the handle's stream. */
 int polaris_hip_reset_frame(polaris_hip_tracer *h);
+
+/* Ordering merges from other threads against the Reset stage without waiting for a whole Trace.  The reset epoch of a
+ * tracer counts the Traces with accumulated_samples == 0 (and reset_frame calls) that have queued the clear of the frame
+ * accumulator -- or have failed before they could.  A frame loop reads the primary's epoch before it hands out the
+ * frame's blocks; a worker that is about to merge into the primary first waits for the epoch to pass that value: its
+ * merge then lands behind this frame's clear, while the primary is still tracing (the reference leaves this to chance,
+ * renderer/default.go:188-191 against tracer.go:208-213; polaris_amd/host/renderer.cpp shows the use). */
+int polaris_hip_reset_epoch(polaris_hip_tracer *h, uint64_t *epoch);
+int polaris_hip_wait_reset(polaris_hip_tracer *h, uint64_t epoch);
 
 /* Tracer.SyncFramebuffer: wait for pending merges, then tonemapSimpleReinhard over rows of
  * req with weight 1/(accumulated_samples+samples_per_pixel) into the RGBA8 frame buffer. */
@@ -177,9 +191,20 @@ int polaris_hip_selftest_rcp(polaris_hip_tracer *h, float lo, float hi, uint64_t
                              uint32_t *sample);
 
 /* With option time_kernels=1: accumulated device milliseconds and launch count of the named
- * kernel ("generate", "intersect", "shade", "occlusion", "scan", "resolve", ...) since the
- * last call for that name. */
+ * timer since the last call for that name.  Timers: "generate", "intersect_packet" (camera rays through
+ * the wave-packet kernel), "intersect" (closest hit), "shade_first" / "shade_sort" / "shade_plain" /
+ * "shade_wave" (one per shade kernel symbol), "scan", "occlusion", "resolve", "aggregate", "tonemap". */
 int polaris_hip_kernel_ms(polaris_hip_tracer *h, const char *kernel, double *ms, uint64_t *launches);
+
+/* The kernel symbol (as rocprofv3 prints it, e.g. "pol::k_trace<false, 16, 2>") the named timer last
+ * bracketed; "" if it has not run.  Measurement aid: bench.py names its roofline objects by it. */
+int polaris_hip_kernel_symbol(polaris_hip_tracer *h, const char *kernel, char symbol[128]);
+
+/* Shading events of the last Trace per bounce: counts[4 b + 0..2] = shaded hits, shaded misses, emitter
+ * hits of the shade step of bounce b (their sums are PolarisTraceStats' totals), counts[4 b + 3] = which
+ * shade timer that step ran under (0 shade_first, 1 shade_sort, 2 shade_plain, 3 shade_wave).
+ * n_counts >= 4 * POLARIS_MAX_BOUNCES.  Measurement aid: algorithmic bytes per shade kernel symbol. */
+int polaris_hip_shade_counts(polaris_hip_tracer *h, uint64_t *counts, size_t n_counts);
 
 #ifdef __cplusplus
 }

@@ -84,7 +84,11 @@ struct Streams {
 };
 
 // device-side counters of one Trace call (mirrors PolarisTraceStats, all uint64)
-enum StatSlot { ST_SHADED_HITS = 0, ST_SHADED_MISSES, ST_EMITTER_HITS, ST_UNOCCLUDED, ST_RAYS_BOUNCE, ST_OCCL_BOUNCE = ST_RAYS_BOUNCE + POLARIS_MAX_BOUNCES, ST_DEBUG = ST_OCCL_BOUNCE + POLARIS_MAX_BOUNCES, ST_COUNT = ST_DEBUG + 16 };
+// (shaded hits / misses / emitter hits are kept per bounce: the totals of PolarisTraceStats are their sums, and bench.py prices
+// every shade launch -- i.e. every kernel symbol -- with its own counts, polaris_hip_shade_counts)
+enum StatSlot { ST_UNOCCLUDED = 0, ST_RAYS_BOUNCE, ST_OCCL_BOUNCE = ST_RAYS_BOUNCE + POLARIS_MAX_BOUNCES, ST_HITS_BOUNCE = ST_OCCL_BOUNCE + POLARIS_MAX_BOUNCES,
+                ST_MISSES_BOUNCE = ST_HITS_BOUNCE + POLARIS_MAX_BOUNCES, ST_EMITTERS_BOUNCE = ST_MISSES_BOUNCE + POLARIS_MAX_BOUNCES,
+                ST_DEBUG = ST_EMITTERS_BOUNCE + POLARIS_MAX_BOUNCES, ST_COUNT = ST_DEBUG + 16 };
 
 __device__ __forceinline__ int fbits(float f) { return __float_as_int(f); }
 __device__ __forceinline__ float ibits(int i) { return __int_as_float(i); }
@@ -1372,7 +1376,7 @@ __global__ __launch_bounds__(1024) void k_scan(Streams st, uint32_t wgs_per_samp
 	if (tid < 3) {
 		uint32_t t = 0;
 		for (int w = 0; w < 16; w++) t += red[tid][w];
-		if (t) atomicAdd(&stats[tid == 0 ? ST_SHADED_HITS : (tid == 1 ? ST_SHADED_MISSES : ST_EMITTER_HITS)], (unsigned long long)t);
+		if (t) atomicAdd(&stats[(tid == 0 ? ST_HITS_BOUNCE : (tid == 1 ? ST_MISSES_BOUNCE : ST_EMITTERS_BOUNCE)) + bounce], (unsigned long long)t);
 	}
 }
 

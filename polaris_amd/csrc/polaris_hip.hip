@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -33,6 +35,7 @@ using namespace pol;
 namespace {
 
 thread_local std::string g_thread_error;
+std::atomic<uint64_t> g_error_seq{0};
 
 struct KernelTimer { double ms = 0.0; uint64_t launches = 0; };
 
@@ -56,6 +59,14 @@ struct polaris_hip_tracer {
 	hipStream_t merge_stream = nullptr;
 	std::mutex merge_mu;
 	hipEvent_t ev_merged = nullptr;
+	// Reset epoch: how many times a Trace with accumulated_samples == 0 (or reset_frame) has got as far as queueing the clear
+	// of the frame accumulator -- or has failed before it could.  A host that merges from other threads waits for the
+	// primary's epoch to advance before it queues this frame's merges (polaris_hip_wait_reset), instead of for the
+	// primary's whole Trace.
+	uint64_t reset_epoch = 0;
+	std::condition_variable reset_cv;
+	std::string merge_error;              // last error of a merge (under merge_mu); `error` belongs to mu
+	uint64_t error_seq = 0, merge_error_seq = 0; // which of the two is the newer one (g_error_seq)
 
 	// frame-sized state (buffers.go:127-174)
 	uint32_t W = 0, H = 0;
@@ -124,6 +135,9 @@ struct polaris_hip_tracer {
 	std::vector<Pending> merge_pending; // launches on the merge stream (under merge_mu)
 	std::vector<hipEvent_t> event_pool;
 	std::map<std::string, KernelTimer> timers;
+	std::map<std::string, std::string> timer_symbol; // timer name -> the kernel symbol it last bracketed (polaris_hip_kernel_symbol)
+	int last_shade_timer[POLARIS_MAX_BOUNCES] = {};            // per bounce of the last Trace: 0 shade_first, 1 shade_sort, 2 shade_plain, 3 shade_wave
+	uint64_t last_shade_counts[3 * POLARIS_MAX_BOUNCES] = {}; // per bounce of the last Trace: shaded hits, shaded misses, emitter hits
 	hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_fork = nullptr;
 };
 
@@ -135,7 +149,7 @@ int fail(polaris_hip_tracer *h, int code, const char *fmt, ...) {
 	va_start(ap, fmt);
 	vsnprintf(buf, sizeof buf, fmt, ap);
 	va_end(ap);
-	if (h) h->error = buf;
+	if (h) { h->error = buf; h->error_seq = ++g_error_seq; }
 	g_thread_error = buf;
 	return code;
 }
@@ -294,6 +308,17 @@ const void *trace_kernel(polaris_hip_tracer *h, int *block) {
 	return top ? (const void *)k_trace<ANY_HIT, 32, kNodesLdsTop> : (const void *)k_trace<ANY_HIT, 32, kNodesGlobal>;
 }
 
+// the symbol rocprofv3 prints for that kernel (bench.py names its roofline objects by it)
+template <bool ANY_HIT>
+std::string trace_symbol(polaris_hip_tracer *h) {
+	char buf[96];
+	const char *a = ANY_HIT ? "true" : "false";
+	if (h->wide) snprintf(buf, sizeof buf, "pol::k_trace4<%s, %d>", a, h->quad_stack <= 32 ? 32 : 64);
+	else if (h->node_mode == kNodesLdsAll) snprintf(buf, sizeof buf, "pol::k_trace<%s, 16, %d>", a, (int)kNodesLdsAll);
+	else snprintf(buf, sizeof buf, "pol::k_trace<%s, %d, %d>", a, h->max_stack <= 16 ? 16 : (h->max_stack <= 24 ? 24 : 32), h->node_mode);
+	return buf;
+}
+
 template <bool ANY_HIT>
 void launch_trace(polaris_hip_tracer *h, polaris_hip_tracer::Pipe &P, uint32_t grid, uint32_t chunks, float4 *acc) {
 	int block = WG;
@@ -321,6 +346,7 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 	hipStream_t q = P.q;
 	{
 		Timed t(h, "generate", q);
+		if (h->opt_time_kernels) h->timer_symbol["generate"] = "pol::k_generate";
 		hipLaunchKernelGGL(k_generate, dim3(wgs), dim3(WG), 0, q, P.st, h->cam, h->d_seeds, stride, s0, N, Npad, h->W, r->block_y,
 		                   exact ? 0 : 1, (B > 0 && h->packet_primary) ? 0 : 1); // (the wave-packet kernel does not read the origin stream)
 	}
@@ -357,6 +383,10 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 	for (uint32_t b = 0; b < B; b++) {
 		{
 			Timed t(h, (b == 0 && h->packet_primary) ? "intersect_packet" : "intersect", q);
+			if (h->opt_time_kernels) {
+				if (b == 0 && h->packet_primary) h->timer_symbol["intersect_packet"] = "pol::k_trace_packet<false, true>";
+				else h->timer_symbol["intersect"] = h->opt_traversal ? trace_symbol<false>(h) : std::string("pol::k_intersect");
+			}
 			if (b == 0 && h->packet_primary)
 				hipLaunchKernelGGL((k_trace_packet<false, true>), dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, (float4 *)nullptr, h->d_stats, h->cam.eye);
 			else if (h->opt_traversal)
@@ -369,8 +399,24 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 		A.emask_in = b == 0 ? nullptr : P.st.emask[(b + 1) & 1]; // the masks the previous step wrote
 		A.emask_out = P.st.emask[b & 1];
 		{
-			Timed t(h, "shade", q);
-			if (h->opt_shade_wave && b > 0 && (int)b >= (h->opt_shade_wave_from >= 0 ? h->opt_shade_wave_from : (int)r->min_bounces_for_rr + 1)) { // (never the first bounce: k_shade_wave reads the previous step's emit masks)
+			// one timer per kernel symbol: shade_first = k_shade<.., FIRST> (camera rays), shade_sort = k_shade<.., SORT, ..> (bounce
+			// rays in class order), shade_plain = k_shade<.., false, false>, shade_wave = k_shade_wave
+			const bool wave = h->opt_shade_wave && b > 0 && (int)b >= (h->opt_shade_wave_from >= 0 ? h->opt_shade_wave_from : (int)r->min_bounces_for_rr + 1); // (never the first bounce: k_shade_wave reads the previous step's emit masks)
+			// bounce rays are shaded in the order of their material's shading class (kernels.h, k_shade SORT); camera rays are
+			// coherent as they come (64 neighbouring pixels per wave)
+			const bool sorted = b > 0 && h->scene.tri_bits < 31 && (int)b >= (h->opt_shade_sort >= 0 ? h->opt_shade_sort : 1);
+			const int which = wave ? 3 : (b == 0 ? 0 : (sorted ? 1 : 2));
+			static const char *const kShadeTimer[4] = {"shade_first", "shade_sort", "shade_plain", "shade_wave"};
+			h->last_shade_timer[b] = which;
+			Timed t(h, kShadeTimer[which], q);
+			if (h->opt_time_kernels) {
+				const char *l = staged ? "true" : "false";
+				char buf[64];
+				if (wave) snprintf(buf, sizeof buf, "pol::k_shade_wave<%s>", l);
+				else snprintf(buf, sizeof buf, "pol::k_shade<%s, %s, %s>", l, which == 1 ? "true" : "false", which == 0 ? "true" : "false");
+				h->timer_symbol[kShadeTimer[which]] = buf;
+			}
+			if (wave) {
 				// persistent waves pull groups of kSparseGroup chunks: no more workgroups than the GPU holds at once (4 per CU at
 				// the kernel's register count) nor than there are groups for their 4 waves
 				const uint32_t groups = (wgs + kSparseGroup - 1) / kSparseGroup;
@@ -378,9 +424,6 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 				if (staged) hipLaunchKernelGGL(k_shade_wave<true>, dim3(grid), dim3(WG), 0, q, P.st, h->scene, A, wgs);
 				else hipLaunchKernelGGL(k_shade_wave<false>, dim3(grid), dim3(WG), 0, q, P.st, h->scene, A, wgs);
 			} else {
-				// bounce rays are shaded in the order of their material's shading class (kernels.h, k_shade SORT); camera rays are
-				// coherent as they come (64 neighbouring pixels per wave)
-				const bool sorted = b > 0 && h->scene.tri_bits < 31 && (int)b >= (h->opt_shade_sort >= 0 ? h->opt_shade_sort : 1);
 				const void *fn;
 				if (b == 0) fn = staged ? (const void *)k_shade<true, false, true> : (const void *)k_shade<false, false, true>;
 				else if (sorted) fn = staged ? (const void *)k_shade<true, true, false> : (const void *)k_shade<false, true, false>;
@@ -395,6 +438,7 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 		}
 		{
 			Timed t(h, "occlusion", q);
+			if (h->opt_time_kernels) h->timer_symbol["occlusion"] = (int)b < h->opt_packet_shadow ? std::string("pol::k_trace_packet<true, false>") : (h->opt_traversal ? trace_symbol<true>(h) : std::string("pol::k_occlusion"));
 			if ((int)b < h->opt_packet_shadow)
 				hipLaunchKernelGGL(k_trace_packet<true>, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, A.acc, h->d_stats, h->cam.eye);
 			else if (h->opt_traversal)
@@ -508,10 +552,16 @@ void polaris_hip_destroy(polaris_hip_tracer *h) {
 
 const char *polaris_hip_last_error(polaris_hip_tracer *h) {
 	if (!h) return g_thread_error.c_str();
-	thread_local std::string copy; // a concurrent merge may be failing on the same handle: read under its lock
+	thread_local std::string copy; // a concurrent call may be failing on the same handle: read under the locks
+	uint64_t seq;
 	{
 		std::lock_guard<std::mutex> lk(h->mu);
 		copy = h->error;
+		seq = h->error_seq;
+	}
+	{
+		std::lock_guard<std::mutex> lk(h->merge_mu);
+		if (h->merge_error_seq > seq) copy = h->merge_error; // the newer of the two
 	}
 	return copy.c_str();
 }
@@ -691,6 +741,13 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
                       PolarisTraceStats *stats) {
 	if (!h) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "handle is null");
 	std::lock_guard<std::mutex> lk(h->mu);
+	// a Trace that resets the frame announces it (reset epoch) once the clear is queued -- or when it fails before that, so
+	// that nobody waits for a reset that will not come
+	struct ResetAnnounce {
+		polaris_hip_tracer *h; bool due, done = false;
+		void now() { if (due && !done) { done = true; { std::lock_guard<std::mutex> lk(h->merge_mu); h->reset_epoch++; } h->reset_cv.notify_all(); } }
+		~ResetAnnounce() { now(); }
+	} announce{h, r && r->accumulated_samples == 0};
 	if (!h->have_scene) return fail(h, POLARIS_E_NO_SCENE_DATA, "no scene data uploaded"); // ErrNoSceneData, tracer.go:203-205
 	if (int rc = check_request(h, r)) return rc;
 	if (!h->have_camera) return fail(h, POLARIS_E_BAD_ARGUMENT, "camera not set (UpdateState CameraData)");
@@ -733,8 +790,11 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 	hipStream_t q = h->stream;
 	HIP_TRY(h, hipEventRecord(h->ev_start, q));
 	if (r->accumulated_samples == 0) { // pipeline Reset stage (tracer.go:208-213): the frame accumulator lives on the merge stream
-		std::lock_guard<std::mutex> lk_merge(h->merge_mu);
-		HIP_TRY(h, hipMemsetAsync(h->frame_acc, 0, F * sizeof(float4), h->merge_stream));
+		{
+			std::lock_guard<std::mutex> lk_merge(h->merge_mu);
+			HIP_TRY(h, hipMemsetAsync(h->frame_acc, 0, F * sizeof(float4), h->merge_stream));
+		}
+		announce.now(); // merges queued from here on land on the cleared accumulator
 	}
 	HIP_TRY(h, hipMemsetAsync(h->trace_acc, 0, F * sizeof(float4), q)); // ClearTraceAccumulator (tracer.go:215)
 	HIP_TRY(h, hipMemsetAsync(h->d_stats, 0, ST_COUNT * sizeof(unsigned long long), q));
@@ -762,12 +822,19 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 	HIP_TRY(h, hipStreamSynchronize(q));
 	drain.armed = false; // the join above made q wait for every pipeline
 	collect_timers(h);
+	for (uint32_t b = 0; b < POLARIS_MAX_BOUNCES; b++) {
+		h->last_shade_counts[3 * b] = b < B ? hs[ST_HITS_BOUNCE + b] : 0;
+		h->last_shade_counts[3 * b + 1] = b < B ? hs[ST_MISSES_BOUNCE + b] : 0;
+		h->last_shade_counts[3 * b + 2] = b < B ? hs[ST_EMITTERS_BOUNCE + b] : 0;
+	}
 	if (stats) {
 		memset(stats, 0, sizeof *stats);
 		stats->primary_rays = (uint64_t)N * spp;
-		stats->shaded_hits = hs[ST_SHADED_HITS];
-		stats->shaded_misses = hs[ST_SHADED_MISSES];
-		stats->emitter_hits = hs[ST_EMITTER_HITS];
+		for (uint32_t b = 0; b < B; b++) {
+			stats->shaded_hits += hs[ST_HITS_BOUNCE + b];
+			stats->shaded_misses += hs[ST_MISSES_BOUNCE + b];
+			stats->emitter_hits += hs[ST_EMITTERS_BOUNCE + b];
+		}
 		stats->unoccluded = hs[ST_UNOCCLUDED];
 		if (B > 0) stats->rays_per_bounce[0] = (uint64_t)N * spp;
 		for (uint32_t b = 1; b < B; b++) {
@@ -787,42 +854,61 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 
 int polaris_hip_merge(polaris_hip_tracer *dst, polaris_hip_tracer *src, const PolarisBlockRequest *r) {
 	if (!dst || !src) return fail(dst, POLARIS_E_BAD_ARGUMENT, "merge: null tracer handle");
-	// both handles' state is read: lock both (in one deadlock-free step when they differ)
-	std::unique_lock<std::mutex> lk(dst->mu, std::defer_lock), lk_src(src->mu, std::defer_lock);
-	if (src == dst) lk.lock();
-	else std::lock(lk, lk_src);
-	if (int rc = check_request(dst, r)) return rc;
-	if (src->W != dst->W || src->H != dst->H || !src->trace_acc)
-		return fail(dst, POLARIS_E_BAD_ARGUMENT, "merge: source tracer has different frame dimensions");
-	HIP_TRY(dst, hipSetDevice(dst->device));
+	// The source's trace accumulator is complete (its Trace is synchronous and has returned): snapshot what is needed of the
+	// source under ITS lock, briefly.  The destination is touched under merge_mu only -- never under dst->mu, which the
+	// destination's own Trace holds from start to end: a secondary's MergeOutput overlaps the primary's Trace
+	// (renderer/default.go:188-191 calls it from the secondaries' goroutines; Exec1DNoWait, resources.go:119).
+	int src_device;
+	uint32_t src_w, src_h;
+	const float4 *src_acc;
+	{
+		std::lock_guard<std::mutex> lk_src(src->mu);
+		src_device = src->device; src_w = src->W; src_h = src->H; src_acc = src->trace_acc;
+	}
+	std::lock_guard<std::mutex> lk(dst->merge_mu);
+	auto fail_merge = [&](int code, const char *msg) { // (dst->error belongs to dst->mu, which a running Trace holds)
+		dst->merge_error = msg;
+		dst->merge_error_seq = ++g_error_seq;
+		g_thread_error = msg;
+		return code;
+	};
+	if (!r) return fail_merge(POLARIS_E_BAD_ARGUMENT, "block request is null");
+	if (dst->W == 0 || dst->H == 0) return fail_merge(POLARIS_E_BAD_ARGUMENT, "frame dimensions not set (UpdateState FrameDimensions)");
+	if (r->frame_w != dst->W || r->frame_h != dst->H) return fail_merge(POLARIS_E_BAD_ARGUMENT, "merge: request frame does not match the tracer's");
+	if (r->block_h == 0 || (uint64_t)r->block_y + r->block_h > dst->H) return fail_merge(POLARIS_E_BAD_ARGUMENT, "merge: block rows outside the frame");
+	if (r->block_x != 0 || (r->block_w != 0 && r->block_w != dst->W)) return fail_merge(POLARIS_E_BAD_ARGUMENT, "only full-width row blocks are supported (BlockW = FrameW, renderer/default.go:110)");
+	if (src_w != dst->W || src_h != dst->H || !src_acc) return fail_merge(POLARIS_E_BAD_ARGUMENT, "merge: source tracer has different frame dimensions");
+	if (hipSetDevice(dst->device) != hipSuccess) return fail_merge(POLARIS_E_DEVICE, "merge: hipSetDevice failed");
 	const size_t off = (size_t)r->block_y * dst->W, n = (size_t)r->block_h * dst->W;
-	const float4 *rows = src->trace_acc + off;
-	if (src->device != dst->device) {
+	const float4 *rows = src_acc + off;
+	hipStream_t q = dst->merge_stream;
+	if (src_device != dst->device) {
 		int can = 0;
-		HIP_TRY(dst, hipDeviceCanAccessPeer(&can, dst->device, src->device));
+		if (hipDeviceCanAccessPeer(&can, dst->device, src_device) != hipSuccess) return fail_merge(POLARIS_E_DEVICE, "merge: hipDeviceCanAccessPeer failed");
 		bool direct = false;
 		if (can) {
-			hipError_t e = hipDeviceEnablePeerAccess(src->device, 0);
+			hipError_t e = hipDeviceEnablePeerAccess(src_device, 0);
 			if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) direct = true;
 			(void)hipGetLastError();
 		}
-		if (!direct) { // staged copy over xGMI / PCIe, then add
+		if (!direct) { // staged copy over xGMI / PCIe, then add (the staging strip is the merge stream's: merges are serialised on it)
 			if (dst->staging_bytes < n * sizeof(float4)) {
+				(void)hipStreamSynchronize(q);
 				if (dst->staging) (void)hipFree(dst->staging);
 				dst->staging = nullptr;
 				dst->staging_bytes = 0;
-				HIP_TRY(dst, hipMalloc(&dst->staging, n * sizeof(float4)));
+				if (hipMalloc(&dst->staging, n * sizeof(float4)) != hipSuccess) return fail_merge(POLARIS_E_DEVICE, "merge: out of device memory for the staging strip");
 				dst->staging_bytes = n * sizeof(float4);
 			}
-			HIP_TRY(dst, hipMemcpyPeerAsync(dst->staging, dst->device, rows, src->device, n * sizeof(float4), dst->stream));
+			if (hipMemcpyPeerAsync(dst->staging, dst->device, rows, src_device, n * sizeof(float4), q) != hipSuccess) return fail_merge(POLARIS_E_DEVICE, "merge: hipMemcpyPeerAsync failed");
 			rows = (const float4 *)dst->staging;
 		}
 	}
 	{
-		Timed t(dst, "aggregate");
-		hipLaunchKernelGGL(k_aggregate, dim3(grid_for(n)), dim3(WG), 0, dst->stream, rows, dst->frame_acc + off, (uint32_t)n);
+		Timed t(dst, "aggregate", q, true);
+		hipLaunchKernelGGL(k_aggregate, dim3(grid_for(n)), dim3(WG), 0, q, rows, dst->frame_acc + off, (uint32_t)n);
 	}
-	HIP_TRY(dst, hipGetLastError());
+	if (hipGetLastError() != hipSuccess) return fail_merge(POLARIS_E_DEVICE, "merge: kernel launch failed");
 	return POLARIS_OK; // asynchronous like Exec1DNoWait (resources.go:119); completed by sync_framebuffer
 }
 
@@ -845,10 +931,11 @@ int polaris_hip_merge_device(polaris_hip_tracer *dst, const void *device_rows, c
 	if (!device_rows) return fail(dst, POLARIS_E_BAD_ARGUMENT, "merge_device: source is null");
 	HIP_TRY(dst, hipSetDevice(dst->device));
 	const size_t off = (size_t)r->block_y * dst->W, n = (size_t)r->block_h * dst->W;
-	hipLaunchKernelGGL(k_aggregate, dim3(grid_for(n)), dim3(WG), 0, dst->stream, (const float4 *)device_rows, dst->frame_acc + off,
+	std::lock_guard<std::mutex> lk_merge(dst->merge_mu); // the frame accumulator is the merge stream's
+	hipLaunchKernelGGL(k_aggregate, dim3(grid_for(n)), dim3(WG), 0, dst->merge_stream, (const float4 *)device_rows, dst->frame_acc + off,
 	                   (uint32_t)n);
 	HIP_TRY(dst, hipGetLastError());
-	HIP_TRY(dst, hipStreamSynchronize(dst->stream)); // the caller owns device_rows: do not outlive it
+	HIP_TRY(dst, hipStreamSynchronize(dst->merge_stream)); // the caller owns device_rows: do not outlive it
 	return POLARIS_OK;
 }
 
@@ -857,7 +944,26 @@ int polaris_hip_reset_frame(polaris_hip_tracer *h) {
 	std::lock_guard<std::mutex> lk(h->mu);
 	if (h->W == 0 || h->H == 0) return fail(h, POLARIS_E_BAD_ARGUMENT, "frame dimensions not set (UpdateState FrameDimensions)");
 	HIP_TRY(h, hipSetDevice(h->device));
-	HIP_TRY(h, hipMemsetAsync(h->frame_acc, 0, (size_t)h->W * h->H * sizeof(float4), h->stream));
+	{
+		std::lock_guard<std::mutex> lk_merge(h->merge_mu);
+		HIP_TRY(h, hipMemsetAsync(h->frame_acc, 0, (size_t)h->W * h->H * sizeof(float4), h->merge_stream));
+		h->reset_epoch++;
+	}
+	h->reset_cv.notify_all();
+	return POLARIS_OK;
+}
+
+int polaris_hip_reset_epoch(polaris_hip_tracer *h, uint64_t *epoch) {
+	if (!h || !epoch) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "reset_epoch: null argument");
+	std::lock_guard<std::mutex> lk(h->merge_mu);
+	*epoch = h->reset_epoch;
+	return POLARIS_OK;
+}
+
+int polaris_hip_wait_reset(polaris_hip_tracer *h, uint64_t epoch) {
+	if (!h) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "handle is null");
+	std::unique_lock<std::mutex> lk(h->merge_mu);
+	h->reset_cv.wait(lk, [&] { return h->reset_epoch > epoch; });
 	return POLARIS_OK;
 }
 
@@ -869,6 +975,7 @@ int polaris_hip_sync_framebuffer(polaris_hip_tracer *h, const PolarisBlockReques
 	HIP_TRY(h, hipSetDevice(h->device));
 	const size_t off = (size_t)r->block_y * h->W, n = (size_t)r->block_h * h->W;
 	const float weight = (float)(1.0 / (float)(r->accumulated_samples + r->samples_per_pixel)); // resources.go:347
+	HIP_TRY(h, join_merges(h, h->stream)); // "wait for pending merges" (tracer.go:258-262): everything queued on the merge stream so far
 	{
 		Timed t(h, "tonemap");
 		hipLaunchKernelGGL(k_tonemap, dim3(grid_for(n)), dim3(WG), 0, h->stream, h->frame_acc + off, h->framebuffer + off, (uint32_t)n,
@@ -898,6 +1005,7 @@ int polaris_hip_read_accumulator(polaris_hip_tracer *h, int which, float *out, s
 	if (!out || n_floats < need || need == 0 || which < 0 || which > 1)
 		return fail(h, POLARIS_E_BAD_ARGUMENT, "read_accumulator: need %zu floats, which in {0,1}", need);
 	HIP_TRY(h, hipSetDevice(h->device));
+	if (which == 1) HIP_TRY(h, join_merges(h, h->stream));
 	HIP_TRY(h, hipMemcpyAsync(out, which == 0 ? h->trace_acc : h->frame_acc, need * sizeof(float), hipMemcpyDeviceToHost, h->stream));
 	HIP_TRY(h, hipStreamSynchronize(h->stream));
 	return POLARIS_OK;
@@ -1058,6 +1166,28 @@ int polaris_hip_selftest_rcp(polaris_hip_tracer *h, float lo, float hi, uint64_t
 	*mismatches_inside = res[0];
 	*mismatches_outside = res[1];
 	if (sample) *sample = (uint32_t)res[2];
+	return POLARIS_OK;
+}
+
+int polaris_hip_kernel_symbol(polaris_hip_tracer *h, const char *kernel, char symbol[128]) {
+	if (!h) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "handle is null");
+	std::lock_guard<std::mutex> lk(h->mu);
+	if (!kernel || !symbol) return fail(h, POLARIS_E_BAD_ARGUMENT, "kernel_symbol: null argument");
+	auto it = h->timer_symbol.find(kernel);
+	snprintf(symbol, 128, "%s", it == h->timer_symbol.end() ? "" : it->second.c_str());
+	return POLARIS_OK;
+}
+
+int polaris_hip_shade_counts(polaris_hip_tracer *h, uint64_t *counts, size_t n_counts) {
+	if (!h) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "handle is null");
+	std::lock_guard<std::mutex> lk(h->mu);
+	if (!counts || n_counts < 4 * (size_t)POLARIS_MAX_BOUNCES) return fail(h, POLARIS_E_BAD_ARGUMENT, "shade_counts: need 4 * POLARIS_MAX_BOUNCES entries");
+	for (int b = 0; b < POLARIS_MAX_BOUNCES; b++) {
+		counts[4 * b] = h->last_shade_counts[3 * b];
+		counts[4 * b + 1] = h->last_shade_counts[3 * b + 1];
+		counts[4 * b + 2] = h->last_shade_counts[3 * b + 2];
+		counts[4 * b + 3] = (uint64_t)h->last_shade_timer[b];
+	}
 	return POLARIS_OK;
 }
 

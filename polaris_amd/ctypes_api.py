@@ -117,7 +117,8 @@ C_ABI_SYMBOLS = [
     "polaris_hip_merge_device", "polaris_hip_sync_framebuffer", "polaris_hip_read_framebuffer",
     "polaris_hip_read_accumulator", "polaris_hip_tap_primary", "polaris_hip_abi_version",
     "polaris_hip_kernel_ms", "polaris_hip_reset_frame", "polaris_hip_probe", "polaris_hip_probe_intersect",
-    "polaris_hip_selftest_rcp",
+    "polaris_hip_selftest_rcp", "polaris_hip_reset_epoch", "polaris_hip_wait_reset",
+    "polaris_hip_kernel_symbol", "polaris_hip_shade_counts",
 ]
 
 _lib = None
@@ -196,6 +197,10 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.polaris_hip_probe.argtypes = [vp, i32, u32, u32, vp, vp]
     lib.polaris_hip_probe_intersect.argtypes = [vp, vp, u32, i32, vp, vp, vp]
     lib.polaris_hip_selftest_rcp.argtypes = [vp, C.c_float, C.c_float, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(u32)]
+    lib.polaris_hip_reset_epoch.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.polaris_hip_wait_reset.argtypes = [vp, C.c_uint64]
+    lib.polaris_hip_kernel_symbol.argtypes = [vp, C.c_char_p, C.c_char_p]
+    lib.polaris_hip_shade_counts.argtypes = [vp, C.POINTER(C.c_uint64), C.c_size_t]
     lib.polaris_hip_kernel_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     for name in C_ABI_SYMBOLS:
         fn = getattr(lib, name)

@@ -41,6 +41,10 @@ public:
 
 	Error ReadFrameBuffer(uint8_t *rgba, size_t n);
 	Error ReadAccumulator(int which, float *out, size_t n);
+	// ordering merges from other threads behind this tracer's Reset stage (include/polaris_hip.h, polaris_hip_reset_epoch)
+	uint64_t ResetEpoch() const { uint64_t e = 0; if (h_) (void)polaris_hip_reset_epoch(h_, &e); return e; }
+	void WaitReset(uint64_t epoch) const { if (h_) (void)polaris_hip_wait_reset(h_, epoch); }
+	void ResetFrame() { if (h_) (void)polaris_hip_reset_frame(h_); } // the Reset stage on its own (also advances the epoch)
 	const PolarisTraceStats &LastTraceStats() const { return last_; }
 	polaris_hip_tracer *Handle() const { return h_; }
 

@@ -141,6 +141,14 @@ int polaris_host_renderer_render(void *h, uint32_t accumulated, uint32_t *rows_o
 	if (frame_ms) *frame_ms = std::chrono::duration<double, std::milli>(box->r->Stats().RenderTime).count();
 	return 0;
 }
+// counters of tracer `tracer_index`'s last Trace (PolarisTraceStats) and the wall time of that Trace in milliseconds
+int polaris_host_renderer_tracer_stats(void *h, uint32_t tracer_index, PolarisTraceStats *out, double *trace_ms) {
+	auto *box = static_cast<RendererBox *>(h);
+	if (tracer_index >= box->hips.size()) return POLARIS_E_BAD_ARGUMENT;
+	if (out) *out = box->hips[tracer_index]->LastTraceStats();
+	if (trace_ms) *trace_ms = std::chrono::duration<double, std::milli>(box->hips[tracer_index]->GetStats()->RenderTime).count();
+	return 0;
+}
 int polaris_host_renderer_read(void *h, uint8_t *rgba, size_t n_rgba, float *frame_acc, size_t n_floats) {
 	auto *box = static_cast<RendererBox *>(h);
 	auto *p = dynamic_cast<tracer::hip::HipTracer *>(box->r->Primary());

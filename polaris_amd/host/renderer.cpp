@@ -53,13 +53,28 @@ void DefaultRenderer::jobWorker(size_t trIndex) {
 			ch.q.pop_front();
 		}
 		Error err = tracers_[trIndex]->Trace(&blockReq);
-		{ // merges of this frame may start once the primary's Trace (and with it the Reset of the frame accumulator) is over
+		// A merge of this frame must land behind the Reset stage of the primary's Trace, which clears the frame accumulator when
+		// it STARTS (tracer.go:208-213; the reference leaves the order to chance).  A HIP primary announces the queued clear
+		// (reset epoch): a secondary that is done early merges while the primary still traces -- merges run on the primary's
+		// merge stream, not under the lock its Trace holds.  Any other primary: wait until its Trace has returned.
+		{
 			std::unique_lock<std::mutex> lk(frameMu_);
 			if (trIndex == primary_) {
 				primaryTraced_ = frame_;
 				frameCv_.notify_all();
-			} else {
-				frameCv_.wait(lk, [&] { return primaryTraced_ == frame_; });
+				// a Trace that failed before it reached the device (a pending state change that could not be committed) has
+				// announced nothing: release the workers that wait for this frame's reset
+				auto *hp = dynamic_cast<tracer::hip::HipTracer *>(tracers_[primary_].get());
+				if (err && frameResets_ && hp && hp->ResetEpoch() == primaryEpoch_) hp->ResetFrame();
+			} else if (frameResets_) {
+				auto *hp = dynamic_cast<tracer::hip::HipTracer *>(tracers_[primary_].get());
+				if (hp) {
+					const uint64_t epoch = primaryEpoch_;
+					lk.unlock();
+					hp->WaitReset(epoch);
+				} else {
+					frameCv_.wait(lk, [&] { return primaryTraced_ == frame_; });
+				}
 			}
 		}
 		// merge this block into the primary's frame accumulator -- called from THIS worker onto the
@@ -94,6 +109,8 @@ Error DefaultRenderer::renderFrame(uint32_t accumulatedSamples) {
 	{
 		std::lock_guard<std::mutex> lk(frameMu_);
 		frame_++;
+		frameResets_ = accumulatedSamples == 0;
+		if (auto *hp = dynamic_cast<tracer::hip::HipTracer *>(tracers_[primary_].get())) primaryEpoch_ = hp->ResetEpoch();
 	}
 	for (size_t trIndex = 0; trIndex < blockAssignments_.size(); trIndex++) {
 		const uint32_t blockH = blockAssignments_[trIndex];

@@ -80,6 +80,8 @@ private:
 	std::mutex frameMu_;
 	std::condition_variable frameCv_;
 	uint64_t frame_ = 0, primaryTraced_ = 0;
+	uint64_t primaryEpoch_ = 0;  // the primary's reset epoch when the frame's blocks were handed out (HIP primaries)
+	bool frameResets_ = false;   // this frame's Trace on the primary clears the frame accumulator (accumulated samples == 0)
 	std::vector<uint32_t> blockAssignments_;
 	FrameStats stats_;
 	bool closed_ = false;

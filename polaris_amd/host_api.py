@@ -34,6 +34,7 @@ def load() -> C.CDLL:
         lib.polaris_host_renderer_push_seeds.argtypes = [vp, C.c_uint32, vp, C.c_size_t]
         lib.polaris_host_renderer_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
         lib.polaris_host_renderer_read.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t]
+        lib.polaris_host_renderer_tracer_stats.argtypes = [vp, C.c_uint32, C.POINTER(T.TraceStats), C.POINTER(C.c_double)]
         lib.polaris_host_renderer_save.argtypes = [vp, C.c_char_p]
         lib.polaris_host_write_png.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
         lib.polaris_host_renderer_error.argtypes = [vp]
@@ -129,6 +130,13 @@ class Renderer:
         if rc:
             raise RuntimeError(f"render failed ({rc}): {self._lib.polaris_host_renderer_error(self._h).decode()}")
         return [int(v) for v in rows], ms.value
+
+    def tracer_stats(self, tracer_index: int):
+        """(TraceStats, wall milliseconds) of tracer `tracer_index`'s last Trace."""
+        st, ms = T.TraceStats(), C.c_double()
+        if self._lib.polaris_host_renderer_tracer_stats(self._h, tracer_index, C.byref(st), C.byref(ms)):
+            raise RuntimeError("tracer_stats: bad tracer index")
+        return st, ms.value
 
     def read(self):
         fb = np.zeros((self.H, self.W, 4), dtype=np.uint8)

@@ -194,6 +194,21 @@ class HipTracer:
         self._check(self._lib.polaris_hip_kernel_ms(self._h, name.encode(), C.byref(ms), C.byref(n)), self._h)
         return ms.value, n.value
 
+    def kernel_symbol(self, name: str) -> str:
+        """The kernel symbol the named timer last bracketed (polaris_hip_kernel_symbol)."""
+        buf = C.create_string_buffer(128)
+        self._check(self._lib.polaris_hip_kernel_symbol(self._h, name.encode(), buf), self._h)
+        return buf.value.decode()
+
+    SHADE_TIMERS = ("shade_first", "shade_sort", "shade_plain", "shade_wave")
+
+    def shade_counts(self, bounces: int) -> list[dict]:
+        """Per bounce of the last Trace: shaded hits / misses / emitter hits and the shade timer the step ran under."""
+        a = (C.c_uint64 * (4 * T.MAX_BOUNCES))()
+        self._check(self._lib.polaris_hip_shade_counts(self._h, a, len(a)), self._h)
+        return [{"hits": int(a[4 * b]), "misses": int(a[4 * b + 1]), "emitters": int(a[4 * b + 2]), "timer": self.SHADE_TIMERS[int(a[4 * b + 3])]}
+                for b in range(bounces)]
+
     def export_block(self, req: T.BlockRequest, device_ptr: int) -> None:
         self._check(self._lib.polaris_hip_export_block(self._h, C.byref(req), C.c_void_p(device_ptr)), self._h)
 

@@ -4,6 +4,7 @@
 #   <tag>_kernel_stats_overlap{1,4}.csv   rocprofv3 --kernel-trace --stats of `bench.py --steps 20 --warmup 5` (one batch at a time / default)
 #   <tag>_bench_under_rocprof.json        the bench line of that profiled run
 #   <tag>_traffic.json                    PMC FETCH_SIZE / WRITE_SIZE passes (scripts/traffic.sh)
+#   <tag>_sq_counters.{txt,json}          one SQ pass (scripts/pmc.sh): VALU instructions per wave, lane utilisation, waiting share
 export TMPDIR=/tmp
 tag=$1
 R=$GRAFT_REPO_ROOT
@@ -17,5 +18,6 @@ for ov in 1 4; do
 done
 bash scripts/traffic.sh > gpurun_out/${tag}_traffic.txt 2>&1
 cp gpurun_out/traffic.json gpurun_out/${tag}_traffic.json
+bash scripts/pmc.sh ${tag} > /dev/null 2>&1
 head -12 gpurun_out/${tag}_kernel_stats_overlap1.csv
 cat gpurun_out/${tag}_bench.json | cut -c1-1500

@@ -37,6 +37,12 @@ def test_bench_single_gpu_line(built):
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["workload"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    # ONE kernel symbol, the one with the largest isolated time; every stream-moving symbol has the same object
+    assert r["kernel"].startswith("pol::k_") and r["kernel"] in d["roofline_per_kernel"]
+    assert r["ms_per_frame"] == max(e["ms_per_frame"] for e in d["roofline_per_kernel"].values())
+    syms = set(d["roofline_per_kernel"])
+    assert any(s.startswith("pol::k_shade<") and s.endswith(", true>") for s in syms)          # k_shade<.., FIRST>
+    assert "pol::k_generate" in syms and any(s.startswith("pol::k_trace<true") for s in syms)
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
 
 
@@ -81,6 +87,78 @@ def test_bench_two_ranks_bare_launch_and_frame(built, tmp_path):
     assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert "row blocks [49, 48]" in d["config"]["workload"]
     _two_rank_frame_matches_the_oracle(d, acc)
+
+
+def test_bench_two_ranks_with_a_different_frame_every_step(built, tmp_path):
+    """The strip exchange runs one frame behind the tracing (polaris_amd/distributed.py): with the same seeds every frame a
+    strip merged into the wrong frame would go unnoticed.  --test-seeds gives every frame its own seed list; the frame rank 0
+    assembled LAST must be the per-block oracle result of the last frame's seeds."""
+    import numpy as np
+
+    from oracle import pybind as ob
+    from polaris_amd import scenes
+    from polaris_amd.distributed import block_of, naive_rows
+
+    acc = str(tmp_path / "frame.npy")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    steps, warmup = 3, 2
+    small = ["--width", "128", "--height", "97", "--spp", "8", "--steps", str(steps), "--warmup", str(warmup)]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *small, "--backend", "gloo", "--same-device", "--no-cpu-baseline",
+           "--no-kernel-timers", "--opt", "exact_accumulate=1", "--save-accumulator", acc, "--test-seeds"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    W, H, spp, B = 128, 97, 8, 5
+    frame = np.load(acc)
+    sc = scenes.SCENES["cornell"](W / H)
+    seeds = scenes.make_seeds(spp, B, base=0xC0FFEE + steps + warmup - 1)   # the last frame's list
+    rows = naive_rows(2, H)
+    orc = ob.Oracle("oracle")
+    expect = np.zeros((H, W, 3), np.float32)
+    for r in range(2):
+        by, bh = block_of(r, rows)
+        a, _, _ = orc.trace(sc, ob.make_request(W, H, spp=spp, bounces=B, rr=3, block_y=by, block_h=bh), seeds)
+        expect[by:by + bh] = a[by:by + bh, :, :3]
+    assert np.array_equal(frame[..., :3].view(np.uint32), expect.view(np.uint32))
+
+
+@pytest.mark.parametrize("scheduler", ["naive", "perfect"])
+def test_bench_inproc_three_tracers_on_one_gpu(built, tmp_path, scheduler):
+    """`bench.py --gpus 3 --inproc --devices 0,0,0`: ONE process, the C++ frame loop (worker thread per tracer), the blocks
+    merged into the primary through polaris_hip_merge on its merge stream -- the reference renderer's own model
+    (renderer/default.go:106-196), no torch.distributed.  The last frame must be the per-block oracle result for the rows the
+    scheduler handed out, bit for bit."""
+    import numpy as np
+
+    from oracle import pybind as ob
+    from polaris_amd import scenes
+
+    acc = str(tmp_path / "frame.npy")
+    W, H, spp, B, steps = 96, 90, 4, 5, 3
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--inproc", "--devices", "0,0,0", "--scheduler", scheduler, "--width", str(W),
+           "--height", str(H), "--spp", str(spp), "--steps", str(steps), "--warmup", "0", "--opt", "exact_accumulate=1", "--test-seeds",
+           "--save-accumulator", acc]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    rows = d["config"]["rows_last_frame"]
+    assert d["config"]["tracers"] == 3 and sum(rows) == H and min(rows) >= 1 and d["value"] > 0
+    assert d["config"]["rows_first_timed_frame"] == [30, 30, 30]      # both schedulers start from the naive split (scheduler.go:52-56)
+    assert scheduler in d["config"]["workload"] and str(rows) in d["config"]["workload"]
+    sc = scenes.SCENES["cornell"](W / H)
+    orc = ob.Oracle("oracle")
+    expect = np.zeros((H, W, 3), np.float32)
+    y, rays = 0, 0
+    for t in range(3):
+        a, st, _ = orc.trace(sc, ob.make_request(W, H, spp=spp, bounces=B, rr=3, block_y=y, block_h=rows[t]), scenes.make_seeds(spp, B, base=1000 * (steps - 1) + 17 * t))
+        expect[y:y + rows[t]] = a[y:y + rows[t], :, :3]
+        y += rows[t]
+    frame = np.load(acc)
+    assert np.array_equal(frame[..., :3].view(np.uint32), expect.view(np.uint32))
+
+
+def test_bench_inproc_refuses_more_gpus_than_visible(built):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--inproc", *SMALL], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode != 0 and "only" in (out.stderr + out.stdout) and "{" not in out.stdout
 
 
 def test_bench_refuses_more_gpus_than_visible(built):

@@ -217,6 +217,99 @@ def test_merge_from_a_tracer_on_another_gpu(built, oracle):
     assert np.array_equal(bits(frame[..., :3]), bits(expect))
 
 
+def test_asynchronous_camera_update_applies_at_the_next_trace(built, oracle):
+    """UpdateState(Asynchronous, CameraData) queues the change; the NEXT Trace commits it before tracing
+    (tracer/opencl/tracer.go:150-158,161-192 -- how the interactive renderer moves the camera, renderer/opengl.go:294-303).
+    Nothing changes until then: a SyncFramebuffer in between still shows the old frame; the second Trace equals the oracle with
+    the NEW camera bit for bit; a second queued update replaces the first (latest wins)."""
+    import copy
+
+    from oracle import pybind as ob
+    from polaris_amd import scenes
+    from polaris_amd.tracer import ChangeType, UpdateMode
+
+    sc = scenes.SCENES["cornell"]()
+    W, H, spp, B = 64, 48, 3, 4
+    seeds = scenes.make_seeds(spp, B, base=77)
+    moved, moved2 = copy.copy(sc), copy.copy(sc)
+    moved.eye = np.asarray(sc.eye, np.float32) + np.float32([0.15, -0.1, 0.2])
+    moved.frustum = np.asarray(sc.frustum, np.float32).copy()
+    moved.frustum.reshape(4, 4)[:, 0] += np.float32(0.05)         # a different view direction per corner ray
+    moved2.eye = np.asarray(sc.eye, np.float32) + np.float32([-0.2, 0.05, 0.1])
+    moved2.frustum = moved.frustum
+    tr = make_hip_tracer(sc, W, H, exact_accumulate=1)
+    try:
+        req = ob.make_request(W, H, spp=spp, bounces=B)
+        tr.Trace(req, seeds)
+        first = tr.read_accumulator(0)
+        took = tr.UpdateState(UpdateMode.Asynchronous, ChangeType.CameraData, moved2)
+        assert took == 0.0
+        tr.UpdateState(UpdateMode.Asynchronous, ChangeType.CameraData, moved)        # latest wins
+        assert np.array_equal(bits(tr.read_accumulator(0)), bits(first))             # nothing happened yet
+        tr.Trace(ob.make_request(W, H, spp=spp, bounces=B), seeds)
+        second = tr.read_accumulator(0)
+    finally:
+        tr.Close()
+    want_first, _, _ = oracle.trace(sc, ob.make_request(W, H, spp=spp, bounces=B), seeds)
+    want_second, _, _ = oracle.trace(moved, ob.make_request(W, H, spp=spp, bounces=B), seeds)
+    assert np.array_equal(bits(first[..., :3]), bits(want_first[..., :3]))
+    assert np.array_equal(bits(second[..., :3]), bits(want_second[..., :3]))
+    assert not np.array_equal(bits(first[..., :3]), bits(second[..., :3]))
+
+
+def test_merge_does_not_wait_for_a_trace_on_the_destination(built, oracle):
+    """MergeOutput is queued on the destination's merge stream under a lock of its own (include/polaris_hip.h): a secondary's
+    merge called while the primary is inside a long Trace returns at once, and -- ordered behind the primary's Reset stage
+    through the reset epoch -- its rows are in the frame when SyncFramebuffer completes.  (renderer/default.go:188-191 merges
+    from the secondaries' goroutines while the primary still traces.)"""
+    import threading
+    import time
+
+    from oracle import pybind as ob
+    from polaris_amd import ctypes_api as T
+    from polaris_amd import scenes
+    import ctypes as C
+
+    sc = scenes.SCENES["cornell"]()
+    W, H, B = 256, 256, 5
+    lib = T.load_library()
+    prim, sec = make_hip_tracer(sc, W, H, exact_accumulate=1), make_hip_tracer(sc, W, H, exact_accumulate=1)
+    try:
+        # the secondary's block first (small), its Trace is over before the primary starts
+        sreq = ob.make_request(W, H, spp=2, bounces=B, block_y=128, block_h=128)
+        sseeds = scenes.make_seeds(2, B, base=5)
+        sec.Trace(sreq, sseeds)
+        epoch = C.c_uint64()
+        assert lib.polaris_hip_reset_epoch(prim._h, C.byref(epoch)) == 0
+        preq = ob.make_request(W, H, spp=96, bounces=B, block_y=0, block_h=128)  # long: exact mode traces one sample per batch
+        pseeds = scenes.make_seeds(96, B, base=6)
+        t_trace = {}
+
+        def run_primary():
+            t0 = time.perf_counter()
+            prim.Trace(preq, pseeds)
+            t_trace["s"] = time.perf_counter() - t0
+
+        th = threading.Thread(target=run_primary)
+        th.start()
+        assert lib.polaris_hip_wait_reset(prim._h, epoch.value) == 0       # the primary's Reset is queued: merges land behind it
+        t0 = time.perf_counter()
+        prim.MergeOutput(sec, ob.make_request(W, H, spp=2, bounces=B, block_y=128, block_h=128))
+        t_merge = time.perf_counter() - t0
+        still_tracing = th.is_alive()
+        th.join()
+        prim.MergeOutput(prim, ob.make_request(W, H, spp=96, bounces=B, block_y=0, block_h=128))
+        prim.SyncFramebuffer(ob.make_request(W, H, spp=96, bounces=B))
+        frame = prim.read_accumulator(1)
+    finally:
+        prim.Close()
+        sec.Close()
+    assert still_tracing and t_merge < 0.5 * t_trace["s"], (t_merge, t_trace)   # the merge did not sit out the Trace
+    a, _, _ = oracle.trace(sc, sreq, sseeds)
+    assert np.array_equal(bits(frame[128:, :, :3]), bits(a[128:, :, :3]))     # the early merge survived the primary's Reset
+    assert frame[:128, :, :3].sum() > 0
+
+
 def test_progressive_accumulation(built, oracle):
     """accumulated_samples > 0 keeps the frame accumulator (tracer.go:208-213) and the tone-map
     weight is 1/(accumulated+spp) (resources.go:347)."""
