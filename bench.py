@@ -43,7 +43,7 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-SHADE_TIMERS = ("shade_first", "shade_sort", "shade_plain", "shade_wave")  # one library timer per shade kernel symbol
+SHADE_TIMERS = ("shade_first", "shade_group", "shade_sort", "shade_plain", "shade_wave")  # one library timer per shade kernel symbol
 KERNELS = ("generate", "intersect_packet", "intersect", *SHADE_TIMERS, "scan", "occlusion", "resolve", "aggregate", "tonemap")
 PRICED = ("generate", "intersect_packet", "intersect", *SHADE_TIMERS, "occlusion")  # the kernels that move ray streams
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)

@@ -90,7 +90,7 @@ int polaris_hip_set_camera(polaris_hip_tracer *h, const float eye[3], const floa
  *                        2 up to 32 K triangles, 4 above; 0 = keep the caller's leaves).  Never
  *                        changes a result: DESIGN.md 2 (HBM data layout)
  *   further A/B switches of the kernels ("traversal", "node_mode", "packet_shadow", "shade_wave",
- *   "shade_wave_from", "shade_sort", "shade_wgs_per_cu", "stage_lds", "trace_wgs_per_cu"): see
+ *   "shade_wave_from", "shade_group", "shade_sort", "wide", "shade_wgs_per_cu", "stage_lds", "trace_wgs_per_cu"): see
  *   DESIGN.md 3.  Apart from "exact_accumulate" (the order of the float sums) no option changes a
  *   result; an unknown key is POLARIS_E_BAD_ARGUMENT. */
 int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value);
@@ -192,8 +192,8 @@ int polaris_hip_selftest_rcp(polaris_hip_tracer *h, float lo, float hi, uint64_t
 
 /* With option time_kernels=1: accumulated device milliseconds and launch count of the named
  * timer since the last call for that name.  Timers: "generate", "intersect_packet" (camera rays through
- * the wave-packet kernel), "intersect" (closest hit), "shade_first" / "shade_sort" / "shade_plain" /
- * "shade_wave" (one per shade kernel symbol), "scan", "occlusion", "resolve", "aggregate", "tonemap". */
+ * the wave-packet kernel), "intersect" (closest hit), "shade_first" / "shade_group" / "shade_sort" /
+ * "shade_plain" / "shade_wave" (one per shade kernel symbol), "scan", "occlusion", "resolve", "aggregate", "tonemap". */
 int polaris_hip_kernel_ms(polaris_hip_tracer *h, const char *kernel, double *ms, uint64_t *launches);
 
 /* The kernel symbol (as rocprofv3 prints it, e.g. "pol::k_trace<false, 16, 2>") the named timer last
@@ -202,7 +202,7 @@ int polaris_hip_kernel_symbol(polaris_hip_tracer *h, const char *kernel, char sy
 
 /* Shading events of the last Trace per bounce: counts[4 b + 0..2] = shaded hits, shaded misses, emitter
  * hits of the shade step of bounce b (their sums are PolarisTraceStats' totals), counts[4 b + 3] = which
- * shade timer that step ran under (0 shade_first, 1 shade_sort, 2 shade_plain, 3 shade_wave).
+ * shade timer that step ran under (0 shade_first, 1 shade_sort, 2 shade_plain, 3 shade_wave, 4 shade_group).
  * n_counts >= 4 * POLARIS_MAX_BOUNCES.  Measurement aid: algorithmic bytes per shade kernel symbol. */
 int polaris_hip_shade_counts(polaris_hip_tracer *h, uint64_t *counts, size_t n_counts);
 

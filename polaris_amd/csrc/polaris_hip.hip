@@ -99,6 +99,9 @@ struct polaris_hip_tracer {
 		hipStream_t q = nullptr;
 		size_t slots = 0; // capacity in slots
 		Streams st{};
+		float4 *alt_o = nullptr, *alt_d = nullptr, *alt_thr = nullptr; // the second set of bounce-ray buffers (launch_batch alternates the two)
+		uint32_t *tickets = nullptr;                                   // one work-queue counter per bounce (k_shade_group), zeroed per batch
+		GroupArgs *group_args = nullptr;                               // k_shade_group's arguments, one record per bounce (k_store_group_args)
 		std::vector<DevBuf> bufs;
 		hipEvent_t done = nullptr; // recorded after the pipe's last resolve
 	};
@@ -126,6 +129,8 @@ struct polaris_hip_tracer {
 	int opt_shade_wgs_per_cu = 4;
 	int opt_shade_wave_from = -1; // first bounce shaded by k_shade_wave; -1 = the bounce AFTER Russian roulette starts thinning the
 	                              // chunks (min_bounces_for_rr + 1: the RR bounce itself still shades dense chunks); earlier bounces use k_shade
+	int opt_shade_group = 0; // 1 = bounce rays shaded class by class across groups of chunks (k_shade_group: fewer vector instructions, more time -- DESIGN.md 3.2), 0 = per chunk (k_shade / k_shade_wave)
+	int shade_group_resident_per_cu = 5; // workgroups of k_shade_group a CU holds at once (occupancy API, at upload)
 	int opt_shade_sort = -1; // first bounce whose rays k_shade groups by shading class; -1 = default (1), POLARIS_MAX_BOUNCES = never
 	int opt_traversal = 1; // 1 = persistent waves with lane refill (k_trace), 0 = one ray per lane (k_intersect/k_occlusion)
 
@@ -136,7 +141,7 @@ struct polaris_hip_tracer {
 	std::vector<hipEvent_t> event_pool;
 	std::map<std::string, KernelTimer> timers;
 	std::map<std::string, std::string> timer_symbol; // timer name -> the kernel symbol it last bracketed (polaris_hip_kernel_symbol)
-	int last_shade_timer[POLARIS_MAX_BOUNCES] = {};            // per bounce of the last Trace: 0 shade_first, 1 shade_sort, 2 shade_plain, 3 shade_wave
+	int last_shade_timer[POLARIS_MAX_BOUNCES] = {};            // per bounce of the last Trace: 0 shade_first, 1 shade_sort, 2 shade_plain, 3 shade_wave, 4 shade_group
 	uint64_t last_shade_counts[3 * POLARIS_MAX_BOUNCES] = {}; // per bounce of the last Trace: shaded hits, shaded misses, emitter hits
 	hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_fork = nullptr;
 };
@@ -255,12 +260,20 @@ int ensure_streams(polaris_hip_tracer *h, int p, size_t slots, bool want_inst) {
 	HIP_TRY(h, hipStreamSynchronize(P.q));
 	free_pool(P.bufs);
 	P.st = Streams{};
+	P.alt_o = P.alt_d = P.alt_thr = nullptr;
+	P.tickets = nullptr;
+	P.group_args = nullptr;
 	P.slots = 0;
 	const size_t wgs = slots / WG;
 	int rc = 0;
 	rc |= dev_alloc(h, P.bufs, &P.st.ray_o, slots);
 	rc |= dev_alloc(h, P.bufs, &P.st.ray_d, slots);
 	rc |= dev_alloc(h, P.bufs, &P.st.thr, slots);
+	rc |= dev_alloc(h, P.bufs, &P.alt_o, slots);
+	rc |= dev_alloc(h, P.bufs, &P.alt_d, slots);
+	rc |= dev_alloc(h, P.bufs, &P.alt_thr, slots);
+	rc |= dev_alloc(h, P.bufs, &P.tickets, (size_t)POLARIS_MAX_BOUNCES);
+	rc |= dev_alloc(h, P.bufs, &P.group_args, (size_t)POLARIS_MAX_BOUNCES);
 	rc |= dev_alloc(h, P.bufs, &P.st.hit, slots);
 	rc |= dev_alloc(h, P.bufs, &P.st.occ_o, slots);
 	rc |= dev_alloc(h, P.bufs, &P.st.occ_d, slots);
@@ -274,6 +287,7 @@ int ensure_streams(polaris_hip_tracer *h, int p, size_t slots, bool want_inst) {
 	rc |= dev_alloc(h, P.bufs, &P.st.emask[1], wgs * 8);
 	if (want_inst) rc |= dev_alloc(h, P.bufs, &P.st.hit_inst, slots);
 	if (rc) { free_pool(P.bufs); P.st = Streams{}; return rc; }
+	P.st.out_o = P.st.ray_o; P.st.out_d = P.st.ray_d; P.st.out_thr = P.st.thr; // (in place unless a caller alternates the sets)
 	P.slots = slots;
 	return POLARIS_OK;
 }
@@ -320,10 +334,10 @@ std::string trace_symbol(polaris_hip_tracer *h) {
 }
 
 template <bool ANY_HIT>
-void launch_trace(polaris_hip_tracer *h, polaris_hip_tracer::Pipe &P, uint32_t grid, uint32_t chunks, float4 *acc) {
+void launch_trace(polaris_hip_tracer *h, polaris_hip_tracer::Pipe &P, const Streams &st, uint32_t grid, uint32_t chunks, float4 *acc) {
 	int block = WG;
 	const void *fn = trace_kernel<ANY_HIT>(h, &block);
-	void *args[] = {(void *)&P.st, h->wide ? (void *)&h->bvh4 : (void *)&h->bvh, (void *)&chunks, (void *)&acc, (void *)&h->d_stats};
+	void *args[] = {(void *)&st, h->wide ? (void *)&h->bvh4 : (void *)&h->bvh, (void *)&chunks, (void *)&acc, (void *)&h->d_stats};
 	(void)hipLaunchKernel(fn, dim3(grid), dim3(block), args, 0, P.q);
 }
 
@@ -380,7 +394,16 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 		return std::min<uint32_t>(wgs, (uint32_t)h->num_cus * per_cu);
 	};
 	const uint32_t persistent = grid_of(h->trace_resident_per_cu), persistent_occl = grid_of(h->occl_resident_per_cu);
+	// with k_shade_group, bounce rays alternate between two sets of buffers: the shade step of bounce b reads set b & 1 and
+	// writes the rays it emits to the other one (kernels.h, Streams::out_*)
+	if (h->opt_shade_group) (void)hipMemsetAsync(P.tickets, 0, POLARIS_MAX_BOUNCES * sizeof(uint32_t), q);
+	float4 *const set_o[2] = {P.st.ray_o, P.alt_o}, *const set_d[2] = {P.st.ray_d, P.alt_d}, *const set_t[2] = {P.st.thr, P.alt_thr};
 	for (uint32_t b = 0; b < B; b++) {
+		Streams S = P.st; // (in place: k_shade / k_shade_wave read a chunk's rays before they write into it)
+		if (h->opt_shade_group) { // k_shade_group shades in class order: its outputs go to the other set
+			S.ray_o = set_o[b & 1]; S.ray_d = set_d[b & 1]; S.thr = set_t[b & 1];
+			S.out_o = set_o[(b + 1) & 1]; S.out_d = set_d[(b + 1) & 1]; S.out_thr = set_t[(b + 1) & 1];
+		}
 		{
 			Timed t(h, (b == 0 && h->packet_primary) ? "intersect_packet" : "intersect", q);
 			if (h->opt_time_kernels) {
@@ -388,11 +411,11 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 				else h->timer_symbol["intersect"] = h->opt_traversal ? trace_symbol<false>(h) : std::string("pol::k_intersect");
 			}
 			if (b == 0 && h->packet_primary)
-				hipLaunchKernelGGL((k_trace_packet<false, true>), dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, (float4 *)nullptr, h->d_stats, h->cam.eye);
+				hipLaunchKernelGGL((k_trace_packet<false, true>), dim3(wgs), dim3(WG), 0, q, S, h->bvh, (float4 *)nullptr, h->d_stats, h->cam.eye);
 			else if (h->opt_traversal)
-				launch_trace<false>(h, P, persistent, wgs, nullptr);
+				launch_trace<false>(h, P, S, persistent, wgs, nullptr);
 			else
-				hipLaunchKernelGGL(k_intersect, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh);
+				hipLaunchKernelGGL(k_intersect, dim3(wgs), dim3(WG), 0, q, S, h->bvh);
 		}
 		A.bounce = b;
 		A.last_bounce = (b + 1 == B) ? 1 : 0;
@@ -405,46 +428,58 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 			// bounce rays are shaded in the order of their material's shading class (kernels.h, k_shade SORT); camera rays are
 			// coherent as they come (64 neighbouring pixels per wave)
 			const bool sorted = b > 0 && h->scene.tri_bits < 31 && (int)b >= (h->opt_shade_sort >= 0 ? h->opt_shade_sort : 1);
-			const int which = wave ? 3 : (b == 0 ? 0 : (sorted ? 1 : 2));
-			static const char *const kShadeTimer[4] = {"shade_first", "shade_sort", "shade_plain", "shade_wave"};
+			// bounce rays: class by class across a group of chunks (k_shade_group) unless switched off; it also serves the sparse bounces
+			const bool grouped = b > 0 && h->opt_shade_group != 0 && h->scene.tri_bits < 31;
+			const int which = grouped ? 4 : (wave ? 3 : (b == 0 ? 0 : (sorted ? 1 : 2)));
+			static const char *const kShadeTimer[5] = {"shade_first", "shade_sort", "shade_plain", "shade_wave", "shade_group"};
 			h->last_shade_timer[b] = which;
 			Timed t(h, kShadeTimer[which], q);
 			if (h->opt_time_kernels) {
 				const char *l = staged ? "true" : "false";
 				char buf[64];
-				if (wave) snprintf(buf, sizeof buf, "pol::k_shade_wave<%s>", l);
+				if (grouped) snprintf(buf, sizeof buf, "pol::k_shade_group<%s>", l);
+				else if (wave) snprintf(buf, sizeof buf, "pol::k_shade_wave<%s>", l);
 				else snprintf(buf, sizeof buf, "pol::k_shade<%s, %s, %s>", l, which == 1 ? "true" : "false", which == 0 ? "true" : "false");
 				h->timer_symbol[kShadeTimer[which]] = buf;
 			}
-			if (wave) {
+			if (grouped) {
+				// persistent workgroups draw groups of kShadeGroup chunks: no more of them than the GPU holds at once, nor than groups
+				const uint32_t groups = (wgs + kShadeGroup - 1) / kShadeGroup;
+				const uint32_t grid = std::max(1u, std::min<uint32_t>(groups, (uint32_t)h->num_cus * (uint32_t)std::max(1, h->shade_group_resident_per_cu)));
+				uint32_t *ticket = P.tickets + b;
+				GroupArgs *ga = P.group_args + b;
+				hipLaunchKernelGGL(k_store_group_args, dim3(1), dim3(64), 0, q, GroupArgs{S, h->scene, A}, ga);
+				if (staged) hipLaunchKernelGGL(k_shade_group<true>, dim3(grid), dim3(WG), 0, q, (const GroupArgs *)ga, wgs, ticket);
+				else hipLaunchKernelGGL(k_shade_group<false>, dim3(grid), dim3(WG), 0, q, (const GroupArgs *)ga, wgs, ticket);
+			} else if (wave) {
 				// persistent waves pull groups of kSparseGroup chunks: no more workgroups than the GPU holds at once (4 per CU at
 				// the kernel's register count) nor than there are groups for their 4 waves
 				const uint32_t groups = (wgs + kSparseGroup - 1) / kSparseGroup;
 				const uint32_t grid = std::max(1u, std::min<uint32_t>((groups + 3) / 4, (uint32_t)h->num_cus * (uint32_t)std::max(1, h->opt_shade_wgs_per_cu)));
-				if (staged) hipLaunchKernelGGL(k_shade_wave<true>, dim3(grid), dim3(WG), 0, q, P.st, h->scene, A, wgs);
-				else hipLaunchKernelGGL(k_shade_wave<false>, dim3(grid), dim3(WG), 0, q, P.st, h->scene, A, wgs);
+				if (staged) hipLaunchKernelGGL(k_shade_wave<true>, dim3(grid), dim3(WG), 0, q, S, h->scene, A, wgs);
+				else hipLaunchKernelGGL(k_shade_wave<false>, dim3(grid), dim3(WG), 0, q, S, h->scene, A, wgs);
 			} else {
 				const void *fn;
 				if (b == 0) fn = staged ? (const void *)k_shade<true, false, true> : (const void *)k_shade<false, false, true>;
 				else if (sorted) fn = staged ? (const void *)k_shade<true, true, false> : (const void *)k_shade<false, true, false>;
 				else fn = staged ? (const void *)k_shade<true, false, false> : (const void *)k_shade<false, false, false>;
-				void *args[] = {(void *)&P.st, (void *)&h->scene, (void *)&A};
+				void *args[] = {(void *)&S, (void *)&h->scene, (void *)&A};
 				(void)hipLaunchKernel(fn, dim3(wgs), dim3(WG), args, 0, q);
 			}
 		}
 		{
 			Timed t(h, "scan", q);
-			hipLaunchKernelGGL(k_scan, dim3(K), dim3(1024), 0, q, P.st, wgs_per_sample, b, A.last_bounce ? 0 : 1, h->d_stats);
+			hipLaunchKernelGGL(k_scan, dim3(K), dim3(1024), 0, q, S, wgs_per_sample, b, A.last_bounce ? 0 : 1, h->d_stats);
 		}
 		{
 			Timed t(h, "occlusion", q);
 			if (h->opt_time_kernels) h->timer_symbol["occlusion"] = (int)b < h->opt_packet_shadow ? std::string("pol::k_trace_packet<true, false>") : (h->opt_traversal ? trace_symbol<true>(h) : std::string("pol::k_occlusion"));
 			if ((int)b < h->opt_packet_shadow)
-				hipLaunchKernelGGL(k_trace_packet<true>, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, A.acc, h->d_stats, h->cam.eye);
+				hipLaunchKernelGGL(k_trace_packet<true>, dim3(wgs), dim3(WG), 0, q, S, h->bvh, A.acc, h->d_stats, h->cam.eye);
 			else if (h->opt_traversal)
-				launch_trace<true>(h, P, persistent_occl, wgs, A.acc);
+				launch_trace<true>(h, P, S, persistent_occl, wgs, A.acc);
 			else
-				hipLaunchKernelGGL(k_occlusion, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, A.acc, h->d_stats);
+				hipLaunchKernelGGL(k_occlusion, dim3(wgs), dim3(WG), 0, q, S, h->bvh, A.acc, h->d_stats);
 		}
 	}
 	if (!exact) {
@@ -693,6 +728,12 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 	// four lanes per ray over the four-wide tree (kernels_quad.h): bit-exact, measured, and slower than one lane per ray on
 	// every scene tried -- so only on request (option "wide" = 1)
 	h->wide = h->quad_stack > 0 && h->opt_wide > 0;
+	{
+		const bool staged_tables = h->opt_stage_lds && sc->num_material_nodes <= kLdsMatNodes && sc->num_emissives <= kLdsLights && sc->num_textures <= kLdsTextures;
+		int n = 0;
+		const void *fn = staged_tables ? (const void *)k_shade_group<true> : (const void *)k_shade_group<false>;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, WG, 0) == hipSuccess && n >= 1) h->shade_group_resident_per_cu = std::min(n, 8);
+	}
 	h->trace_resident_per_cu = trace_occupancy<false>(h);
 	h->occl_resident_per_cu = trace_occupancy<true>(h);
 	h->have_scene = true;
@@ -729,6 +770,8 @@ int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value
 	else if (k == "shade_wave_from") h->opt_shade_wave_from = (int)std::max<int64_t>(-1, std::min<int64_t>(value, POLARIS_MAX_BOUNCES));
 	else if (k == "shade_wgs_per_cu") h->opt_shade_wgs_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(value, 64));
 	else if (k == "stage_lds") h->opt_stage_lds = value != 0;
+	else if (k == "shade_group") h->opt_shade_group = value != 0;
+	else if (k == "shade_group_wgs_per_cu") h->shade_group_resident_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(value, 16));
 	else if (k == "shade_sort") h->opt_shade_sort = (int)std::max<int64_t>(-1, std::min<int64_t>(value, POLARIS_MAX_BOUNCES));
 	else if (k == "overlap") h->opt_overlap = (int)std::max<int64_t>(1, std::min<int64_t>(value, polaris_hip_tracer::kMaxPipes));
 	else if (k == "trace_wgs_per_cu") h->opt_trace_wgs_per_cu = (int)std::max<int64_t>(0, std::min<int64_t>(value, 64));
@@ -1119,11 +1162,11 @@ int polaris_hip_probe_intersect(polaris_hip_tracer *h, const float *rays, uint32
 		// probes through the wave-packet kernel instead
 		if (any_hit) {
 			if (h->opt_packet_shadow > 0) hipLaunchKernelGGL(k_trace_packet<true>, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, P.st.lsum, h->d_stats, h->cam.eye);
-			else if (h->opt_traversal) launch_trace<true>(h, P, std::min<uint32_t>(wgs, (uint32_t)h->num_cus * (uint32_t)std::max(1, h->occl_resident_per_cu)), wgs, P.st.lsum);
+			else if (h->opt_traversal) launch_trace<true>(h, P, P.st, std::min<uint32_t>(wgs, (uint32_t)h->num_cus * (uint32_t)std::max(1, h->occl_resident_per_cu)), wgs, P.st.lsum);
 			else hipLaunchKernelGGL(k_occlusion, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, P.st.lsum, h->d_stats);
 		} else {
 			if (h->opt_packet_primary == 1) hipLaunchKernelGGL(k_trace_packet<false>, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, (float4 *)nullptr, h->d_stats, h->cam.eye);
-			else if (h->opt_traversal) launch_trace<false>(h, P, std::min<uint32_t>(wgs, (uint32_t)h->num_cus * (uint32_t)std::max(1, h->trace_resident_per_cu)), wgs, nullptr);
+			else if (h->opt_traversal) launch_trace<false>(h, P, P.st, std::min<uint32_t>(wgs, (uint32_t)h->num_cus * (uint32_t)std::max(1, h->trace_resident_per_cu)), wgs, nullptr);
 			else hipLaunchKernelGGL(k_intersect, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh);
 		}
 		e = hipGetLastError();

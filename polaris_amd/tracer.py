@@ -200,7 +200,7 @@ class HipTracer:
         self._check(self._lib.polaris_hip_kernel_symbol(self._h, name.encode(), buf), self._h)
         return buf.value.decode()
 
-    SHADE_TIMERS = ("shade_first", "shade_sort", "shade_plain", "shade_wave")
+    SHADE_TIMERS = ("shade_first", "shade_sort", "shade_plain", "shade_wave", "shade_group")
 
     def shade_counts(self, bounces: int) -> list[dict]:
         """Per bounce of the last Trace: shaded hits / misses / emitter hits and the shade timer the step ran under."""

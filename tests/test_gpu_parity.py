@@ -80,6 +80,8 @@ def test_hip_vs_oracle_exact_and_batched(built, oracle, name):
                 ({"exact_accumulate": 1, "shade_wave": 0}, True), ({"exact_accumulate": 1, "shade_wave_from": 0}, True),
                 ({"shade_wave": 0, "stage_lds": 0, "samples_per_batch": 3}, False), ({"shade_wave_from": 1, "samples_per_batch": 2}, False),
                 # shading order: never sorted by class / sorted from bounce 2 / sorted with the tables in global memory
+                # bounce rays class by class across 16 chunks (k_shade_group) instead of per chunk (k_shade sorted / unsorted, k_shade_wave)
+                ({"exact_accumulate": 1, "shade_group": 1}, True), ({"shade_group": 1, "samples_per_batch": 3}, False), ({"shade_group": 1, "stage_lds": 0, "overlap": 1}, False),
                 ({"exact_accumulate": 1, "shade_sort": 32}, True), ({"exact_accumulate": 1, "shade_sort": 2}, True),
                 ({"exact_accumulate": 1, "stage_lds": 0}, True), ({"shade_sort": 32, "shade_wave": 0, "samples_per_batch": 3}, False))
     for opts, exact in variants:
