@@ -188,12 +188,13 @@ def main() -> None:
     ap.add_argument("--same-device", action="store_true", help="testing aid: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--emulate-rank", default="", help="R/N: on ONE GPU, trace only the row block rank R of N would own "
                     "(tuning aid for the strong-scaling path; not a valid bench line)")
+    ap.add_argument("--rows", default="", help="with --emulate-rank: the N block heights to use instead of the naive scheduler's (comma separated)")
     ap.add_argument("--inproc", action="store_true", help="ONE process, one worker thread per GPU, blocks merged into the primary over peer access "
                     "(polaris_hip_merge): the reference renderer's own model (renderer/default.go:106-196); no torch.distributed, no RCCL")
     ap.add_argument("--devices", default="", help="--inproc: comma separated device index per tracer (default 0..N-1; repeating a device, "
                     "e.g. 0,0,0, runs several tracers on one GPU: a testing aid)")
-    ap.add_argument("--scheduler", default="naive", choices=("naive", "perfect"), help="--inproc: block scheduler (tracer/scheduler.go); "
-                    "`polaris render` uses the naive one (cmd/render.go:65)")
+    ap.add_argument("--scheduler", default="perfect", choices=("naive", "perfect"), help="block scheduler for N > 1 (tracer/scheduler.go): `naive` = equal "
+                    "rows (what `polaris render` passes, cmd/render.go:65), `perfect` = rows from the previous frames' times (scheduler.go:50-80)")
     ap.add_argument("--test-seeds", action="store_true", help="testing aid: fixed host PRNG draws -- --inproc: tracer t of frame f draws from "
                     "make_seeds(base = 1000 f + 17 t); default mode: frame f uses make_seeds(base = 0xC0FFEE + f) instead of one list for every frame")
     args = ap.parse_args()
@@ -247,7 +248,7 @@ def main() -> None:
 
     from polaris_amd import ctypes_api as T
     from polaris_amd import scenes
-    from polaris_amd.distributed import StripExchange, block_of, naive_rows
+    from polaris_amd.distributed import SchedulerFeedback, StripExchange, block_of, naive_rows
     from polaris_amd.tracer import ChangeType, HipTracer, UpdateMode
 
     W, H, spp, B = args.width, args.height, args.spp, args.bounces
@@ -257,7 +258,10 @@ def main() -> None:
     block_y, block_h = block_of(rank, rows)
     if args.emulate_rank:
         er, en = (int(v) for v in args.emulate_rank.split("/"))
-        block_y, block_h = block_of(er, naive_rows(en, H))
+        erows = [int(v) for v in args.rows.split(",")] if args.rows else naive_rows(en, H)
+        if len(erows) != en or sum(erows) != H or min(erows) < 1:
+            raise SystemExit(f"bench.py --rows: need {en} positive block heights that add up to {H}")
+        block_y, block_h = block_of(er, erows)
         rows = [block_h]
 
     tr = HipTracer(f"hip-{rank}", local_rank)
@@ -279,17 +283,21 @@ def main() -> None:
         r.exposure, r.seed, r.accumulated_samples = 1.2, 0, 0
         return r
 
-    # The path's one exchange step (renderer/default.go:191): gather of the blocks' strips to the primary.  It runs one
-    # frame behind the tracing (polaris_amd/distributed.py): frame i's gather / merge / tone-map overlap frame i+1's Trace.
-    ex = StripExchange(dist, rank, rows, W, dev, via_host=args.backend != "nccl") if world > 1 else None
+    # The path's one exchange step (renderer/default.go:191): the blocks' strips travel to the primary.  It runs one frame
+    # behind the tracing (polaris_amd/distributed.py): frame i's transfers / merge / tone-map overlap frame i+1's Trace.  The
+    # block scheduler runs identically on every rank from all-gathered (rows, time) pairs, also one frame behind.
+    xdev = dev if args.backend == "nccl" else torch.device("cpu")
+    ex = StripExchange(dist, rank, world, W, H, dev, via_host=args.backend != "nccl") if world > 1 else None
+    fb = SchedulerFeedback(dist, rank, world, H, xdev, kind=args.scheduler) if world > 1 else None
     totals = {k: 0 for k in ("primary_rays", "indirect_rays", "occlusion_rays", "shaded_hits", "shaded_misses", "emitter_hits", "unoccluded")}
     pending = []
+    rows_log = []
 
     def finish_frame(ticket):
         parts = ex.wait(ticket)
         if rank == 0:
             tr.reset_frame()                       # the Reset stage: this frame's blocks land on a cleared accumulator
-            for y, h, t in parts:                  # ONE merge over the whole frame when the blocks are equally tall
+            for y, h, t in parts:                  # ONE merge over the assembled frame
                 tr.merge_device(t.data_ptr(), make_req(y, h))
             tr.SyncFramebuffer(make_req(0, H))     # default.go:159-161
 
@@ -300,6 +308,10 @@ def main() -> None:
     frame_no = [0]
 
     def frame(count: bool):
+        nonlocal rows, block_y, block_h
+        if fb is not None and not args.emulate_rank:
+            rows = fb.next_rows()                  # Schedule (default.go:124): the same rows on every rank
+            block_y, block_h = block_of(rank, rows)
         req = make_req(block_y, block_h)
         fseeds = seeds
         if args.test_seeds:                        # a different frame every step: a strip merged one frame late or early shows
@@ -310,12 +322,14 @@ def main() -> None:
             st = tr.last_trace_stats
             for k in totals:
                 totals[k] += int(getattr(st, k))
+            rows_log.append(list(rows))
         if world == 1:
             tr.MergeOutput(tr, req)                # primary merges its own block (default.go:191)
             tr.SyncFramebuffer(make_req(0, H) if not args.emulate_rank else req)
         else:
-            ticket = ex.post(lambda strip: tr.export_block(req, strip.data_ptr()))
-            flush()                                # the PREVIOUS frame: its gather ran beside this frame's Trace
+            fb.publish(rows, float(tr.last_trace_stats.device_ms))
+            ticket = ex.post(lambda strip: tr.export_block(req, strip.data_ptr()), rows)
+            flush()                                # the PREVIOUS frame: its transfers ran beside this frame's Trace
             pending.append(ticket)
 
     def fence():
@@ -334,6 +348,8 @@ def main() -> None:
     flush()                                        # all K frames merged and tone-mapped inside the timed region
     fence()
     elapsed = time.perf_counter() - t0
+    if fb is not None:
+        fb.drain()
     if args.save_accumulator and rank == 0:
         np.save(args.save_accumulator, tr.read_accumulator(1))  # the primary's frame accumulator of the last frame (tests)
 
@@ -364,8 +380,11 @@ def main() -> None:
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{sc.name} {W}x{H} {spp}spp {B} bounces rr>={args.rr}, {sc.num_triangles} tris, "
-                                   f"row blocks {rows} (naive scheduler), gather-to-primary + tonemap",
-                       "ranks": world, "exchange": "none (1 GPU)" if world == 1 else f"{args.backend} gather of the row-block strips to rank 0, one frame behind the tracing",
+                                   f"row blocks {rows} ({'naive' if world == 1 else args.scheduler} scheduler{'' if world == 1 else ', rows of the last frame'}), "
+                                   f"strips to the primary + tonemap",
+                       "ranks": world, "scheduler": "naive" if world == 1 else args.scheduler,
+                       "rows_first_timed_frame": rows_log[0] if rows_log else None, "rows_last_frame": rows_log[-1] if rows_log else None,
+                       "exchange": "none (1 GPU)" if world == 1 else f"{args.backend} point-to-point transfers of the row-block strips to rank 0, one frame behind the tracing",
                        "frame": [W, H], "spp": spp, "bounces": B, "rays_per_frame": rays // args.steps,
                        "paths_per_s": W * H * spp * args.steps / elapsed},
         }

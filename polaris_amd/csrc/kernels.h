@@ -1255,13 +1255,19 @@ constexpr int kShadeClasses = 16; // classes 0 (missed) .. 15
 // Everything the kernel needs, in device memory (written by k_store_group_args in front of the launch): the shading of one
 // pass is a REAL function call (below), and the callee reads what it needs from here with scalar loads, on demand, exactly as
 // a kernel reads its arguments -- instead of the caller keeping ~70 scalar registers of pointers alive around the call.
-struct GroupArgs { Streams st; SceneDev Sg; ShadeArgs A; };
+struct GroupArgs { Streams st; SceneDev Sg; ShadeArgs A; uint32_t tex_bytes; };
 __global__ void k_store_group_args(GroupArgs a, GroupArgs *dst) { if (threadIdx.x == 0) *dst = a; }
 
 // LDS of k_shade_group (namespace scope: the pass function below uses it too)
 static __shared__ ShadeLds g_lds;
 static __shared__ uint32_t g_o_cnt[kShadeGroup][3];  // per chunk: bounce rays emitted, shadow rays emitted, event word (hits | misses << 10 | emitter hits << 20)
 static __shared__ uint32_t g_o_emit[kShadeGroup][8]; // per chunk: this step's emit mask
+// A/B build (-DPOLARIS_TEXELS_LDS, scripts/build_variant.sh): the scene's whole texture blob staged in LDS for the lifetime of the
+// persistent workgroup (north_star: "texture tiles staged in LDS") where it fits -- measured, not adopted: DESIGN.md 3.4
+#ifdef POLARIS_TEXELS_LDS
+constexpr uint32_t kTexelsLdsBytes = 24 * 1024;
+static __shared__ uint32_t g_texels[kTexelsLdsBytes / 4];
+#endif
 
 // One pass: the wave's 64 sorted rays (entry e = chunk within the group << 8 | slot within the chunk, 0xFFFF = padding).
 // NOT inlined on purpose.  Inside k_shade_group's persistent loops the inlined shading code needed 135 vector registers (the
@@ -1296,6 +1302,9 @@ void shade_group_pass(const GroupArgs *__restrict__ ga_in, uint32_t e, uint32_t 
 		} else {
 			S.nodes = Sg.nodes; S.emissives = Sg.emissives; S.tex_meta = Sg.tex_meta; S.light_geo = Sg.light_geo;
 		}
+#ifdef POLARIS_TEXELS_LDS
+		if (ga->tex_bytes + 16u <= kTexelsLdsBytes) S.tex_data = reinterpret_cast<const uint8_t *>(g_texels);
+#endif
 	}
 	const bool live = e != 0xFFFFu;
 	const uint32_t k = live ? e >> 8 : 0u;
@@ -1341,6 +1350,10 @@ void k_shade_group(const GroupArgs *__restrict__ ga, uint32_t num_chunks, uint32
 	const uint32_t tid = threadIdx.x, lane = tid & 63;
 	const uint32_t tri_bits = ga->Sg.tri_bits;
 	uint32_t *const cnt_ray = ga->st.cnt_ray, *const cnt_occ = ga->st.cnt_occ, *const wg_stat = ga->st.wg_stat;
+#ifdef POLARIS_TEXELS_LDS
+	if (ga->tex_bytes + 16u <= kTexelsLdsBytes)
+		for (uint32_t i = tid; i < (ga->tex_bytes + 16u) / 4u; i += WG) g_texels[i] = reinterpret_cast<const uint32_t *>(ga->Sg.tex_data)[i];
+#endif
 	(void)stage_scene<LDS>(ga->Sg, g_lds); // (ends in a barrier)
 	const uint32_t num_groups = (num_chunks + G - 1) / G;
 	const int *hit_words = reinterpret_cast<const int *>(ga->st.hit);

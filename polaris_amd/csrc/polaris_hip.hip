@@ -84,6 +84,7 @@ struct polaris_hip_tracer {
 	// four lanes per ray over the four-wide tree (kernels_quad.h); an A/B alternative to k_trace, off by default
 	Bvh4Dev bvh4{};
 	int quad_stack = 0;  // stack entries the collapsed tree needs (0 = not available)
+	uint32_t tex_bytes = 0; // size of the uploaded texture blob (without its padding)
 	int opt_wide = 0;    // option "wide": 1 = k_trace4 wherever the collapsed tree is available, 0 = k_trace
 	bool wide = false;   // resolved at upload
 	int trace_resident_per_cu = 6, occl_resident_per_cu = 6; // workgroups of the selected k_trace<closest | any hit> variant a CU holds at once (occupancy API, at upload)
@@ -448,7 +449,7 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 				const uint32_t grid = std::max(1u, std::min<uint32_t>(groups, (uint32_t)h->num_cus * (uint32_t)std::max(1, h->shade_group_resident_per_cu)));
 				uint32_t *ticket = P.tickets + b;
 				GroupArgs *ga = P.group_args + b;
-				hipLaunchKernelGGL(k_store_group_args, dim3(1), dim3(64), 0, q, GroupArgs{S, h->scene, A}, ga);
+				hipLaunchKernelGGL(k_store_group_args, dim3(1), dim3(64), 0, q, GroupArgs{S, h->scene, A, h->tex_bytes}, ga);
 				if (staged) hipLaunchKernelGGL(k_shade_group<true>, dim3(grid), dim3(WG), 0, q, (const GroupArgs *)ga, wgs, ticket);
 				else hipLaunchKernelGGL(k_shade_group<false>, dim3(grid), dim3(WG), 0, q, (const GroupArgs *)ga, wgs, ticket);
 			} else if (wave) {
@@ -716,6 +717,7 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 	h->scene = SceneDev{vertices, normals, uvs, mat_index, nodes, emissives, tex_meta, tex_data, sc->num_emissives,
 	                    sc->scene_diffuse_mat_index, sc->num_material_nodes, sc->num_textures, light_geo, sc->num_emissives ? pm_rcp((float)(int)sc->num_emissives) : 0.0f, L.tri_bits};
 	h->max_stack = L.max_stack;
+	h->tex_bytes = sc->texture_data_bytes;
 	// camera rays: the wave-packet kernel where a packet stays together -- one instance, a tree of moderate size.  Since the
 	// per-ray kernel's instruction diet the two are level on those scenes (headline 1.2 vs 1.0 ms of 11.3, sphere
 	// +-0, 58 K-triangle ball +-0); in a scene of many instances the packet's lanes part ways inside the instances: per-ray
@@ -817,10 +819,35 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 		else K = std::min<uint32_t>(std::max<uint32_t>(1u, (uint32_t)((32u << 20) / Npad)), std::max(1u, (spp + 1) / 2));
 		K = std::max<uint32_t>(1u, std::min(K, std::max(spp, 1u)));
 	}
-	const uint32_t n_batches = spp ? (spp + K - 1) / K : 0;
-	const int n_pipes = exact ? 1 : (int)std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)h->opt_overlap, n_batches));
-	for (int p = 0; p < n_pipes; p++)
-		if (int rc = ensure_streams(h, p, (size_t)K * Npad, false)) return rc;
+	// The batch buffers are 176 bytes per path slot and up to `overlap` batches are in flight: ~5.9 GB per pipeline at 33.5 M
+	// slots, nothing on a 288 GB MI355X but not on a smaller or shared device.  K chosen automatically is first clamped by the
+	// free device memory and, if an allocation still fails, halved and retried (a caller-chosen samples_per_batch is kept as it
+	// is: its failure is reported).
+	if (!exact && h->opt_samples_per_batch <= 0 && K > 1) {
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+			size_t have = 0; // what the pipelines already hold counts as available
+			for (auto &P : h->pipe) have += P.slots * (size_t)192;
+			const size_t pipes = (size_t)std::max(1, std::min(h->opt_overlap, (int)polaris_hip_tracer::kMaxPipes));
+			const size_t per_slot = 192 * std::min<size_t>(pipes, (spp + K - 1) / K);
+			const size_t budget = (free_b + have) / 10 * 9;
+			while (K > 1 && (size_t)K * Npad * per_slot > budget) K = (K + 1) / 2;
+		}
+	}
+	uint32_t n_batches = 0;
+	int n_pipes = 1;
+	for (;;) {
+		n_batches = spp ? (spp + K - 1) / K : 0;
+		n_pipes = exact ? 1 : (int)std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)h->opt_overlap, n_batches));
+		int rc = POLARIS_OK;
+		for (int p = 0; p < n_pipes && rc == POLARIS_OK; p++) rc = ensure_streams(h, p, (size_t)K * Npad, false);
+		if (rc == POLARIS_OK) break;
+		if (exact || h->opt_samples_per_batch > 0 || K == 1) return rc;
+		(void)hipGetLastError(); // out of memory: release every pipeline's buffers, halve the batch, try again
+		for (auto &P : h->pipe)
+			if (P.q && P.slots) { (void)hipStreamSynchronize(P.q); free_pool(P.bufs); P.st = Streams{}; P.alt_o = P.alt_d = P.alt_thr = nullptr; P.tickets = nullptr; P.group_args = nullptr; P.slots = 0; }
+		K = (K + 1) / 2;
+	}
 	if (need_seeds > h->seeds_cap) {
 		if (h->d_seeds) (void)hipFree(h->d_seeds);
 		h->d_seeds = nullptr;

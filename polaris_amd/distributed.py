@@ -3,13 +3,16 @@
 The reference renders a frame on N devices inside one process: `Schedule` -> one worker per tracer
 `Trace`s its row block -> `primary.MergeOutput(tracer)` (renderer/default.go:106-196,
 tracer/opencl/resources.go:108-124).  Under the driver's launch contract every GPU has its own
-process, so the single exchange step of the path -- the gather of the blocks' accumulator strips to
-the primary -- is a `torch.distributed` gather (backend nccl = RCCL on the GPU box, gloo in the CPU
-tests); there is no other data-path collective.
+process, so the single exchange step of the path -- the blocks' accumulator strips travelling to
+the primary -- is a set of `torch.distributed` point-to-point transfers (backend nccl = RCCL on the GPU
+box, gloo in the CPU tests): every rank sends exactly its rows, the primary receives them at their place
+in the frame.  There is no other data-path transfer; the scheduler feedback below is 16 bytes per rank.
 
-`StripExchange` keeps that gather OFF the critical path: `post()` starts the gather of frame i
+`StripExchange` keeps the transfers OFF the critical path: `post()` starts those of frame i
 asynchronously and returns at once, so every rank goes straight on to trace frame i + 1; `wait()`
-(called one frame later) hands rank 0 the gathered strips of frame i.  Two sets of buffers alternate.
+(called one frame later) hands rank 0 the assembled frame i.  Two sets of buffers alternate.
+`SchedulerFeedback` runs the reference's block scheduler identically on every rank from all-gathered
+(rows, time) pairs, also one frame behind.
 """
 from __future__ import annotations
 
@@ -32,81 +35,135 @@ def block_of(rank: int, rows: list[int]) -> tuple[int, int]:
 class StripExchange:
     """Gather-to-primary of the per-rank accumulator strips, one frame of look-ahead.
 
-    rows[r] = block height of rank r; a strip is (rows[r] * frame_w, 4) float32.  Collectives want
-    equally sized pieces, so strips travel padded to the tallest block (the naive scheduler gives the
-    remainder rows to tracer 0, tracer/scheduler.go:101-103).
+    A frame's blocks are row ranges of the frame, so rank dst keeps whole-FRAME buffers and every strip lands at its own
+    rows: rank r sends exactly rows[r] * frame_w float4 (point-to-point: nothing is padded, the blocks may be as uneven as the
+    scheduler likes and may change from frame to frame), dst receives each at row offset sum(rows[:r]), and its own block is
+    exported straight into the buffer.  The assembled frame is merged with ONE polaris_hip_merge_device.  Several sets of
+    buffers alternate (`depth`); a set is reused only after its exchange has completed ON THE DEVICE on every rank.
 
-    device: torch device of the strip buffers ("cpu" in the gloo tests).  `via_host=True` stages
-    device strips through host memory (gloo cannot move device tensors): test mode for two ranks
-    sharing one GPU.
+    device: torch device of the buffers ("cpu" in the gloo tests).  `via_host=True` stages device strips through host memory
+    (gloo cannot move device tensors): test mode for ranks sharing one GPU.
     """
 
-    def __init__(self, dist, rank: int, rows: list[int], frame_w: int, device, dst: int = 0, via_host: bool = False, depth: int = 2):
+    def __init__(self, dist, rank: int, world: int, frame_w: int, frame_h: int, device, dst: int = 0, via_host: bool = False, depth: int = 2):
         import torch
 
-        self.dist, self.rank, self.rows, self.W, self.dst = dist, rank, list(rows), frame_w, dst
-        self.world = len(rows)
+        self.dist, self.rank, self.world, self.W, self.H, self.dst = dist, rank, world, frame_w, frame_h, dst
         self.via_host = via_host
-        self.max_rows = max(rows)
-        n = self.max_rows * frame_w
-        self.strips = [torch.zeros((n, 4), dtype=torch.float32, device=device) for _ in range(depth)]
-        self.gathered = None
-        if rank == dst:
-            self.gathered = [torch.empty((self.world, n, 4), dtype=torch.float32, device=device) for _ in range(depth)]
-        self._host = None
-        if via_host:
-            self._host = [torch.empty((n, 4), dtype=torch.float32) for _ in range(depth)]
-            self._host_g = [[torch.empty((n, 4), dtype=torch.float32) for _ in range(self.world)] for _ in range(depth)] if rank == dst else None
-        self._turn = 0
-        self.uniform = len(set(rows)) == 1
-
-    def post(self, fill):
-        """fill(strip_tensor) must leave this rank's block rows in strip_tensor[: rows[rank] * W] before it
-        returns (bench.py: polaris_hip_export_block, which synchronises its own stream).  Starts the gather
-        and returns a ticket for wait()."""
-        i = self._turn % len(self.strips)
-        self._turn += 1
-        strip = self.strips[i]
-        fill(strip)
-        if self.world == 1:
-            return (i, None)
-        if self.via_host:
-            self._host[i].copy_(strip)  # synchronous D2H
-            work = self.dist.gather(self._host[i], self._host_g[i] if self.rank == self.dst else None, dst=self.dst, async_op=True)
+        n = frame_h * frame_w
+        if rank == dst:  # whole frames; elsewhere one strip (at most the whole frame: the scheduler decides)
+            self.bufs = [torch.zeros((n, 4), dtype=torch.float32, device=device) for _ in range(depth)]
         else:
-            glist = [self.gathered[i][r] for r in range(self.world)] if self.rank == self.dst else None
-            work = self.dist.gather(strip, glist, dst=self.dst, async_op=True)
-        return (i, work)
+            self.bufs = [torch.zeros((n, 4), dtype=torch.float32, device=device) for _ in range(depth)]
+        self._host = [torch.zeros((n, 4), dtype=torch.float32) for _ in range(depth)] if via_host else None
+        self._turn = 0
+
+    def post(self, fill, rows):
+        """rows[r] = block height of rank r in THIS frame (the same list on every rank).  fill(tensor) must leave this
+        rank's block rows in tensor[: rows[rank] * W] before it returns (bench.py: polaris_hip_export_block, which
+        synchronises its own stream).  Starts the exchange and returns a ticket for wait()."""
+        import torch
+
+        rows = list(rows)
+        assert len(rows) == self.world and sum(rows) == self.H and min(rows) >= 1, rows
+        i = self._turn % len(self.bufs)
+        self._turn += 1
+        buf = self.bufs[i]
+        W = self.W
+        y = sum(rows[: self.rank])
+        mine = buf[y * W:(y + rows[self.rank]) * W] if self.rank == self.dst else buf[: rows[self.rank] * W]
+        fill(mine)
+        if self.world == 1:
+            return (i, [], rows)
+        wire = buf
+        if self.via_host:
+            wire = self._host[i]
+            if self.rank == self.dst:
+                wire[y * W:(y + rows[self.rank]) * W].copy_(mine)  # synchronous D2H
+            else:
+                wire[: rows[self.rank] * W].copy_(mine)
+        ops = []
+        if self.rank == self.dst:
+            yy = 0
+            for r in range(self.world):
+                if r != self.dst:
+                    ops.append(self.dist.P2POp(self.dist.irecv, wire[yy * W:(yy + rows[r]) * W], r))
+                yy += rows[r]
+        else:
+            ops.append(self.dist.P2POp(self.dist.isend, wire[: rows[self.rank] * W], self.dst))
+        works = self.dist.batch_isend_irecv(ops)  # (nccl: one grouped launch; gloo: the individual operations)
+        return (i, works, rows)
 
     def wait(self, ticket):
-        """Completes the gather of `ticket`.  On dst returns [(block_y, block_h, tensor)] -- ONE entry
-        covering the whole frame when all blocks are equally tall (the gathered buffer IS the frame then),
-        else one per rank; elsewhere returns None."""
+        """Completes the exchange of `ticket`.  On dst returns [(0, frame_h, frame tensor)] -- the assembled frame; elsewhere
+        None."""
         import torch
 
-        i, work = ticket
-        if self.world == 1:
-            return [(0, self.rows[0], self.strips[i])]
-        if work is not None:
-            work.wait()
-        # On the nccl backend Work.wait() only makes torch's CURRENT STREAM wait for the collective; the host returns at once.
-        # The strip buffer is refilled two posts later from the tracer's own (non-blocking) HIP stream, which has no ordering
-        # against RCCL's stream -- so EVERY rank, not only dst, blocks here until its part of the gather has really finished.
+        i, works, rows = ticket
+        buf = self.bufs[i]
+        for w in works:
+            w.wait()
+        # On the nccl backend Work.wait() only makes torch's CURRENT STREAM wait for the transfer; the host returns at once.
+        # The buffers are refilled `depth` posts later from the tracer's own (non-blocking) HIP stream, which has no ordering
+        # against RCCL's stream -- so EVERY rank, not only dst, blocks here until its part of the exchange has really finished.
         # That also bounds the skew between ranks to the depth of the exchange.
-        if self.strips[i].is_cuda and not self.via_host:
-            torch.cuda.current_stream(self.strips[i].device).synchronize()
+        if buf.is_cuda and not self.via_host:
+            torch.cuda.current_stream(buf.device).synchronize()
         if self.rank != self.dst:
             return None
-        g = self.gathered[i]
-        if self.via_host:
-            for r in range(self.world):
-                g[r].copy_(self._host_g[i][r])
-        if g.is_cuda:
-            torch.cuda.current_stream(g.device).synchronize()  # the tracer merges on its own HIP stream: data must have landed
-        if self.uniform:
-            return [(0, self.rows[0] * self.world, g)]
-        out, y = [], 0
-        for r in range(self.world):
-            out.append((y, self.rows[r], g[r]))
-            y += self.rows[r]
-        return out
+        if self.via_host and self.world > 1:
+            buf.copy_(self._host[i])
+            if buf.is_cuda:
+                torch.cuda.current_stream(buf.device).synchronize()  # the tracer merges on its own HIP stream: data must have landed
+        return [(0, self.H, buf)]
+
+
+class SchedulerFeedback:
+    """The reference's perfect scheduler (tracer/scheduler.go:50-80, restated in polaris_amd/host/scheduler.cpp) across
+    processes: every rank publishes (block height, trace time) of a frame with an asynchronous all_gather -- 16 bytes per rank,
+    completed one frame later like the strips -- and every rank feeds the same numbers to the same scheduler, so all arrive at
+    the same rows without a synchronous step.  Frame f + 2 is scheduled from frame f's times; the first two frames use the
+    naive split (the scheduler's own first frame, scheduler.go:52-56)."""
+
+    def __init__(self, dist, rank: int, world: int, frame_h: int, device, kind: str = "perfect"):
+        import torch
+
+        from . import host_api
+
+        self.dist, self.rank, self.world, self.H, self.kind = dist, rank, world, frame_h, kind
+        self.rows = naive_rows(world, frame_h)
+        self._sched = None
+        if kind == "perfect" and world > 1:
+            self._sched = host_api.Scheduler(host_api.PERFECT, [1] * world)
+            self._sched.schedule(frame_h)  # its first frame: the naive split
+        self._dev = device
+        self._torch = torch
+        self._pending = []
+
+    def publish(self, rows, trace_ms: float):
+        """After a frame's Trace: this rank's block height and time go out (asynchronously)."""
+        if self._sched is None:
+            return
+        t = self._torch
+        mine = t.tensor([int(rows[self.rank]), int(trace_ms * 1e6)], dtype=t.int64, device=self._dev)
+        out = [t.zeros(2, dtype=t.int64, device=self._dev) for _ in range(self.world)]
+        work = self.dist.all_gather(out, mine, async_op=True)
+        self._pending.append((work, out, mine))
+
+    def next_rows(self):
+        """The rows of the NEXT frame: from the newest feedback that has been published at least one frame ago."""
+        if self._sched is None:
+            return self.rows
+        while len(self._pending) > 1:  # everything but the frame just published has had a whole frame's time to complete
+            work, out, _ = self._pending.pop(0)
+            work.wait()
+            if out[0].is_cuda:
+                self._torch.cuda.current_stream(out[0].device).synchronize()
+            got = [o.cpu().tolist() for o in out]
+            self.rows = self._sched.schedule(self.H, block_h=[g[0] for g in got], render_ns=[max(1, g[1]) for g in got])
+        return self.rows
+
+    def drain(self):
+        for work, out, _ in self._pending:
+            work.wait()
+        self._pending = []

@@ -1,9 +1,10 @@
 """The N>1 path of bench.py on CPU: 2 ranks over gloo partition the frame by row block, each renders
 its block (the CPU oracle stands in for the GPU tracer -- it is the checker, used here as test
 infrastructure only), and the strips travel to rank 0 through polaris_amd.distributed.StripExchange
--- the SAME class, used the same way (post -> trace the next frame -> wait), that bench.py runs over
-RCCL.  Three frames with different seeds are in flight one behind the other; every assembled frame
-must equal the per-block oracle results bit for bit (uneven blocks: 31 rows -> [16, 15])."""
+-- the SAME classes, used the same way (next_rows -> trace -> publish -> post -> wait one frame later),
+that bench.py runs over RCCL.  Several frames with different seeds are in flight one behind the other;
+every assembled frame must equal the per-block oracle results bit for bit (uneven blocks: 31 rows ->
+[16, 15]; with the perfect scheduler the rows change from frame to frame with the ranks' made-up times)."""
 import os
 import socket
 import sys
@@ -12,7 +13,7 @@ import numpy as np
 
 from conftest import ROOT
 
-W, H, SPP, B, FRAMES = 40, 31, 2, 4, 3
+W, H, SPP, B, FRAMES = 40, 31, 2, 4, 5
 
 
 def _free_port():
@@ -23,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, scheduler):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch
@@ -31,44 +32,53 @@ def _worker(rank, world, port, out_path):
 
     from oracle import pybind as ob
     from polaris_amd import scenes
-    from polaris_amd.distributed import StripExchange, block_of, naive_rows
+    from polaris_amd.distributed import SchedulerFeedback, StripExchange, block_of
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sc = scenes.SCENES["cornell-diffuse"](W / H)
-    rows = naive_rows(world, H)
-    by, bh = block_of(rank, rows)
-    ex = StripExchange(dist, rank, rows, W, "cpu")
+    ex = StripExchange(dist, rank, world, W, H, "cpu")
+    fb = SchedulerFeedback(dist, rank, world, H, "cpu", kind=scheduler)
     orc = ob.Oracle("oracle")
-    frames, pending = [], []
+    frames, pending, all_rows = [], [], []
 
     def finish(ticket):
         parts = ex.wait(ticket)
         if rank == 0:
             frame = np.zeros((H, W, 4), np.float32)
             for y, h, t in parts:  # what bench.py hands to polaris_hip_merge_device
-                frame[y:y + h] += t.numpy().reshape(-1, W, 4)[:h] if t.dim() == 2 else t.numpy().reshape(-1, 4)[: h * W].reshape(h, W, 4)
+                frame[y:y + h] += t.numpy().reshape(-1, 4)[: h * W].reshape(h, W, 4)
             frames.append(frame)
 
     for f in range(FRAMES):
+        rows = fb.next_rows()
+        all_rows.append(list(rows))
+        by, bh = block_of(rank, rows)
         seeds = scenes.make_seeds(SPP, B, base=100 + f)
         acc, _, _ = orc.trace(sc, ob.make_request(W, H, spp=SPP, bounces=B, block_y=by, block_h=bh), seeds)
+        fb.publish(rows, (3.0 if rank == 1 else 1.0) * bh)  # made-up times: rank 1 takes three times as long per row
 
-        def fill(strip, acc=acc):
+        def fill(strip, acc=acc, by=by, bh=bh):
             strip[: bh * W].copy_(torch.from_numpy(np.ascontiguousarray(acc[by:by + bh].reshape(-1, 4))))
 
-        ticket = ex.post(fill)
+        ticket = ex.post(fill, rows)
         while pending:
             finish(pending.pop(0))
         pending.append(ticket)
     while pending:
         finish(pending.pop(0))
+    fb.drain()
     if rank == 0:
         np.save(out_path, np.stack(frames))
+        np.save(out_path + ".rows.npy", np.array(all_rows))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_row_block_gather(built, tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("scheduler", ["naive", "perfect"])
+def test_two_rank_row_block_gather(built, tmp_path, scheduler):
     import torch.multiprocessing as mp
 
     from oracle import pybind as ob
@@ -76,18 +86,23 @@ def test_two_rank_row_block_gather(built, tmp_path):
     from polaris_amd.distributed import block_of, naive_rows
 
     out = str(tmp_path / "frames.npy")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, scheduler), nprocs=2, join=True)
     frames = np.load(out)
+    all_rows = np.load(out + ".rows.npy").tolist()
     assert frames.shape == (FRAMES, H, W, 4)
     sc = scenes.SCENES["cornell-diffuse"](W / H)
-    rows = naive_rows(2, H)
-    assert rows == [16, 15]
+    assert all_rows[0] == naive_rows(2, H) == [16, 15] and all_rows[1] == [16, 15]   # feedback arrives two frames later
+    if scheduler == "naive":
+        assert all(r == [16, 15] for r in all_rows)
+    else:  # rank 1 reported three times the time per row: from frame 2 on it gets about a quarter of the frame (scheduler.go:50-80)
+        assert all(sum(r) == H and min(r) >= 1 for r in all_rows)
+        assert all_rows[2][1] < 12 and all_rows[-1][1] <= 9, all_rows
     orc = ob.Oracle("oracle")
     for f in range(FRAMES):
         seeds = scenes.make_seeds(SPP, B, base=100 + f)
         expect = np.zeros((H, W, 3), np.float32)
         for r in range(2):
-            by, bh = block_of(r, rows)
+            by, bh = block_of(r, all_rows[f])
             a, _, _ = orc.trace(sc, ob.make_request(W, H, spp=SPP, bounces=B, block_y=by, block_h=bh), seeds)
             expect[by:by + bh] = a[by:by + bh, :, :3]
         assert np.array_equal(frames[f][..., :3].view(np.uint32), expect.view(np.uint32)), f

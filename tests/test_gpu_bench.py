@@ -80,13 +80,45 @@ def test_bench_two_ranks_bare_launch_and_frame(built, tmp_path):
     acc = str(tmp_path / "frame.npy")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--backend", "gloo", "--same-device", "--no-cpu-baseline",
-           "--opt", "exact_accumulate=1", "--save-accumulator", acc]
+           "--scheduler", "naive", "--opt", "exact_accumulate=1", "--save-accumulator", acc]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert "row blocks [49, 48]" in d["config"]["workload"]
     _two_rank_frame_matches_the_oracle(d, acc)
+
+
+def test_bench_two_ranks_perfect_scheduler(built, tmp_path):
+    """The default for N > 1: the reference's perfect scheduler (tracer/scheduler.go:50-80) fed by all-gathered (rows, time)
+    pairs -- every rank must arrive at the same rows every frame, or the strips would not fit together.  The last frame, with
+    whatever rows the scheduler had settled on, must be the per-block oracle result bit for bit."""
+    import numpy as np
+
+    from oracle import pybind as ob
+    from polaris_amd import scenes
+
+    acc = str(tmp_path / "frame.npy")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    small = ["--width", "128", "--height", "97", "--spp", "8", "--steps", "4", "--warmup", "3"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *small, "--backend", "gloo", "--same-device", "--no-cpu-baseline", "--no-kernel-timers",
+           "--opt", "exact_accumulate=1", "--save-accumulator", acc]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    rows = d["config"]["rows_last_frame"]
+    assert d["config"]["scheduler"] == "perfect" and "perfect scheduler" in d["config"]["workload"] and sum(rows) == 97 and min(rows) >= 1
+    W, H, spp, B = 128, 97, 8, 5
+    sc = scenes.SCENES["cornell"](W / H)
+    seeds = scenes.make_seeds(spp, B)
+    orc = ob.Oracle("oracle")
+    expect = np.zeros((H, W, 3), np.float32)
+    y = 0
+    for r in range(2):
+        a, _, _ = orc.trace(sc, ob.make_request(W, H, spp=spp, bounces=B, rr=3, block_y=y, block_h=rows[r]), seeds)
+        expect[y:y + rows[r]] = a[y:y + rows[r], :, :3]
+        y += rows[r]
+    assert np.array_equal(np.load(acc)[..., :3].view(np.uint32), expect.view(np.uint32))
 
 
 def test_bench_two_ranks_with_a_different_frame_every_step(built, tmp_path):
@@ -104,7 +136,7 @@ def test_bench_two_ranks_with_a_different_frame_every_step(built, tmp_path):
     steps, warmup = 3, 2
     small = ["--width", "128", "--height", "97", "--spp", "8", "--steps", str(steps), "--warmup", str(warmup)]
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *small, "--backend", "gloo", "--same-device", "--no-cpu-baseline",
-           "--no-kernel-timers", "--opt", "exact_accumulate=1", "--save-accumulator", acc, "--test-seeds"]
+           "--no-kernel-timers", "--scheduler", "naive", "--opt", "exact_accumulate=1", "--save-accumulator", acc, "--test-seeds"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     W, H, spp, B = 128, 97, 8, 5
@@ -171,7 +203,7 @@ def test_bench_refuses_more_gpus_than_visible(built):
 def test_bench_two_ranks_under_the_drivers_launcher(built):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--backend", "gloo", "--same-device",
-           "--no-cpu-baseline"]
+           "--no-cpu-baseline", "--scheduler", "naive"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
