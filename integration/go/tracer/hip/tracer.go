@@ -226,6 +226,20 @@ func (tr *Tracer) MergeOutput(other tracer.Tracer, blockReq *tracer.BlockRequest
 	return time.Since(start), tr.check(C.polaris_hip_merge(tr.handle, src.handle, &creq))
 }
 
+// ResetEpoch / WaitReset order a merge from another goroutine behind this tracer's Reset stage (Trace clears the frame
+// accumulator when it starts, tracer/opencl/tracer.go:208-213) without waiting for its whole Trace: read the primary's
+// epoch before the frame's blocks are handed out, and WaitReset(epoch) in a secondary's worker before it merges
+// (INTEGRATION.md section 3).
+func (tr *Tracer) ResetEpoch() uint64 {
+	var e C.uint64_t
+	C.polaris_hip_reset_epoch(tr.handle, &e)
+	return uint64(e)
+}
+
+func (tr *Tracer) WaitReset(epoch uint64) {
+	C.polaris_hip_wait_reset(tr.handle, C.uint64_t(epoch))
+}
+
 // SyncFramebuffer mirrors tracer/opencl/tracer.go:250-276 (wait, then tone-map).
 func (tr *Tracer) SyncFramebuffer(blockReq *tracer.BlockRequest) (time.Duration, error) {
 	start := time.Now()

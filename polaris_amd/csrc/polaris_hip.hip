@@ -124,6 +124,7 @@ struct polaris_hip_tracer {
 	bool packet_primary = true;  // resolved at upload
 	int opt_time_kernels = 0;
 	int opt_trace_wgs_per_cu = 0; // 0 = auto (what the LDS stack admits)
+	int opt_trace_grid = 0;       // 0 = auto; > 0: the persistent traversal grid in workgroups (A/B aid)
 	int opt_max_leaf_tris = -1;   // subdivide bigger triangle leaves at upload (0 = keep the caller's leaves, -1 = by scene size)
 	int opt_stage_lds = 1;    // k_shade stages material nodes / lights / texture metadata in LDS when they fit
 	int opt_shade_wave = 1;   // 1 = persistent wave-per-chunk shading (k_shade_wave), 0 = one workgroup per chunk (k_shade)
@@ -257,7 +258,9 @@ hipError_t sync_all(polaris_hip_tracer *h) { // every pipeline of the handle idl
 
 int ensure_streams(polaris_hip_tracer *h, int p, size_t slots, bool want_inst) {
 	polaris_hip_tracer::Pipe &P = h->pipe[p];
-	if (slots <= P.slots && (!want_inst || P.st.hit_inst)) return POLARIS_OK;
+	const bool want_alt = h->opt_shade_group != 0; // the second set of bounce-ray buffers: only k_shade_group writes out of place
+	if (slots <= P.slots && (!want_inst || P.st.hit_inst) && (!want_alt || P.alt_o)) return POLARIS_OK;
+	slots = std::max(slots, P.slots);
 	HIP_TRY(h, hipStreamSynchronize(P.q));
 	free_pool(P.bufs);
 	P.st = Streams{};
@@ -270,9 +273,11 @@ int ensure_streams(polaris_hip_tracer *h, int p, size_t slots, bool want_inst) {
 	rc |= dev_alloc(h, P.bufs, &P.st.ray_o, slots);
 	rc |= dev_alloc(h, P.bufs, &P.st.ray_d, slots);
 	rc |= dev_alloc(h, P.bufs, &P.st.thr, slots);
-	rc |= dev_alloc(h, P.bufs, &P.alt_o, slots);
-	rc |= dev_alloc(h, P.bufs, &P.alt_d, slots);
-	rc |= dev_alloc(h, P.bufs, &P.alt_thr, slots);
+	if (want_alt) {
+		rc |= dev_alloc(h, P.bufs, &P.alt_o, slots);
+		rc |= dev_alloc(h, P.bufs, &P.alt_d, slots);
+		rc |= dev_alloc(h, P.bufs, &P.alt_thr, slots);
+	}
 	rc |= dev_alloc(h, P.bufs, &P.tickets, (size_t)POLARIS_MAX_BOUNCES);
 	rc |= dev_alloc(h, P.bufs, &P.group_args, (size_t)POLARIS_MAX_BOUNCES);
 	rc |= dev_alloc(h, P.bufs, &P.st.hit, slots);
@@ -392,6 +397,7 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 		    (uint64_t)wgs < 4ull * (uint64_t)h->num_cus * per_cu * (kTinyBlock / 64))
 			per_cu = 1;
 		if (h->opt_trace_wgs_per_cu > 0) per_cu = (uint32_t)h->opt_trace_wgs_per_cu;
+		if (h->opt_trace_grid > 0) return std::min<uint32_t>(wgs, (uint32_t)h->opt_trace_grid); // (A/B aid: an absolute persistent grid)
 		return std::min<uint32_t>(wgs, (uint32_t)h->num_cus * per_cu);
 	};
 	const uint32_t persistent = grid_of(h->trace_resident_per_cu), persistent_occl = grid_of(h->occl_resident_per_cu);
@@ -776,6 +782,7 @@ int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value
 	else if (k == "shade_group_wgs_per_cu") h->shade_group_resident_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(value, 16));
 	else if (k == "shade_sort") h->opt_shade_sort = (int)std::max<int64_t>(-1, std::min<int64_t>(value, POLARIS_MAX_BOUNCES));
 	else if (k == "overlap") h->opt_overlap = (int)std::max<int64_t>(1, std::min<int64_t>(value, polaris_hip_tracer::kMaxPipes));
+	else if (k == "trace_grid") h->opt_trace_grid = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20));
 	else if (k == "trace_wgs_per_cu") h->opt_trace_wgs_per_cu = (int)std::max<int64_t>(0, std::min<int64_t>(value, 64));
 	else if (k == "max_leaf_tris") h->opt_max_leaf_tris = (int)std::max<int64_t>(-1, std::min<int64_t>(value, 1 << 20)); // next upload
 	else return fail(h, POLARIS_E_BAD_ARGUMENT, "unknown option '%s'", key);
@@ -819,8 +826,8 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 		else K = std::min<uint32_t>(std::max<uint32_t>(1u, (uint32_t)((32u << 20) / Npad)), std::max(1u, (spp + 1) / 2));
 		K = std::max<uint32_t>(1u, std::min(K, std::max(spp, 1u)));
 	}
-	// The batch buffers are 176 bytes per path slot and up to `overlap` batches are in flight: ~5.9 GB per pipeline at 33.5 M
-	// slots, nothing on a 288 GB MI355X but not on a smaller or shared device.  K chosen automatically is first clamped by the
+	// The batch buffers are 128 bytes per path slot (176 with k_shade_group's second set of ray buffers) and up to `overlap`
+	// batches are in flight: 4.3 GB per pipeline at 33.5 M slots, nothing on a 288 GB MI355X but not on a smaller or shared device.  K chosen automatically is first clamped by the
 	// free device memory and, if an allocation still fails, halved and retried (a caller-chosen samples_per_batch is kept as it
 	// is: its failure is reported).
 	if (!exact && h->opt_samples_per_batch <= 0 && K > 1) {
