@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define POLARIS_HIP_ABI_VERSION 1
+#define POLARIS_HIP_ABI_VERSION 2 /* 2: + reset_epoch / wait_reset, kernel_symbol, shade_counts (additions only: a version-1 caller keeps working) */
 
 /* status codes (0 = ok).  The first three mirror tracer/opencl/errors.go sentinels. */
 #define POLARIS_OK                0

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol(built):
     for name in declared:
         assert hasattr(lib, name), f"libpolaris_hip.so does not export {name}"
     assert sorted(T.C_ABI_SYMBOLS) == declared, "ctypes_api.C_ABI_SYMBOLS is out of sync with polaris_hip.h"
-    assert lib.polaris_hip_abi_version() == 1
+    assert lib.polaris_hip_abi_version() == 2
 
 
 def test_struct_sizes_match_header(built):
