@@ -51,10 +51,9 @@ class StripExchange:
         self.dist, self.rank, self.world, self.W, self.H, self.dst = dist, rank, world, frame_w, frame_h, dst
         self.via_host = via_host
         n = frame_h * frame_w
-        if rank == dst:  # whole frames; elsewhere one strip (at most the whole frame: the scheduler decides)
-            self.bufs = [torch.zeros((n, 4), dtype=torch.float32, device=device) for _ in range(depth)]
-        else:
-            self.bufs = [torch.zeros((n, 4), dtype=torch.float32, device=device) for _ in range(depth)]
+        # dst: whole frames.  Elsewhere: one strip -- sized for the whole frame too, because the scheduler, not this class,
+        # decides how many rows a rank gets (16 bytes per pixel: 4 MB at 512 x 512)
+        self.bufs = [torch.zeros((n, 4), dtype=torch.float32, device=device) for _ in range(depth)]
         self._host = [torch.zeros((n, 4), dtype=torch.float32) for _ in range(depth)] if via_host else None
         self._turn = 0
 

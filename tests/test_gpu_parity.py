@@ -312,6 +312,33 @@ def test_merge_does_not_wait_for_a_trace_on_the_destination(built, oracle):
     assert frame[:128, :, :3].sum() > 0
 
 
+@pytest.mark.parametrize("name,W,H,spp", [("cornell", 512, 512, 32), ("instanced", 1024, 1024, 4), ("material-ball", 960, 540, 8)])
+def test_optional_kernels_at_bench_sizes_equal_the_default_path(built, name, W, H, spp):
+    """The kernels that are off by default -- four lanes per ray over the four-wide tree (wide=1), bounce rays shaded class by
+    class across 16 chunks (shade_group=1) -- on frames of the bench configurations' width (tens of millions of rays, every
+    persistent-grid / ticket / refill path under load): counters and the batched accumulator must equal the default path's
+    BIT FOR BIT (per-path sums are resolved in sample order whatever kernel produced them)."""
+    from oracle import pybind as ob
+    from polaris_amd import scenes
+
+    sc = scenes.SCENES[name](W / H)
+    B = 5
+    seeds = scenes.make_seeds(spp, B, base=4242)
+    results = []
+    for opts in ({}, {"wide": 1}, {"shade_group": 1}, {"wide": 1, "shade_group": 1, "overlap": 1}):
+        tr = make_hip_tracer(sc, W, H, **opts)
+        try:
+            tr.Trace(ob.make_request(W, H, spp=spp, bounces=B), seeds)
+            results.append((opts, tr.read_accumulator(0), counters(tr.last_trace_stats, B), tr.last_trace_stats.emitter_hits))
+        finally:
+            tr.Close()
+    base = results[0]
+    assert base[1][..., :3].sum() > 0 and base[2][2] == W * H * spp
+    for opts, acc, cnt, emit in results[1:]:
+        assert cnt == base[2] and emit == base[3], opts
+        assert np.array_equal(bits(acc[..., :3]), bits(base[1][..., :3])), opts
+
+
 def test_progressive_accumulation(built, oracle):
     """accumulated_samples > 0 keeps the frame accumulator (tracer.go:208-213) and the tone-map
     weight is 1/(accumulated+spp) (resources.go:347)."""
