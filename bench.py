@@ -293,13 +293,17 @@ def main() -> None:
     pending = []
     rows_log = []
 
+    own_work = [0.0]                               # seconds of this rank's OWN work in the current frame (what the scheduler balances)
+
     def finish_frame(ticket):
-        parts = ex.wait(ticket)
+        parts = ex.wait(ticket)                    # (waiting for the others' strips is not this rank's work)
         if rank == 0:
+            t = time.perf_counter()
             tr.reset_frame()                       # the Reset stage: this frame's blocks land on a cleared accumulator
-            for y, h, t in parts:                  # ONE merge over the assembled frame
-                tr.merge_device(t.data_ptr(), make_req(y, h))
+            for y, h, buf in parts:                # ONE merge over the assembled frame
+                tr.merge_device(buf.data_ptr(), make_req(y, h))
             tr.SyncFramebuffer(make_req(0, H))     # default.go:159-161
+            own_work[0] += time.perf_counter() - t
 
     def flush():
         while pending:
@@ -317,6 +321,7 @@ def main() -> None:
         if args.test_seeds:                        # a different frame every step: a strip merged one frame late or early shows
             fseeds = scenes.make_seeds(spp, B, base=0xC0FFEE + frame_no[0])
             frame_no[0] += 1
+        t_own = time.perf_counter()
         tr.Trace(req, fseeds)                      # Trace (tracer.go:194-247)
         if count:
             st = tr.last_trace_stats
@@ -327,10 +332,13 @@ def main() -> None:
             tr.MergeOutput(tr, req)                # primary merges its own block (default.go:191)
             tr.SyncFramebuffer(make_req(0, H) if not args.emulate_rank else req)
         else:
-            fb.publish(rows, float(tr.last_trace_stats.device_ms))
             ticket = ex.post(lambda strip: tr.export_block(req, strip.data_ptr()), rows)
+            own_work[0] = time.perf_counter() - t_own
             flush()                                # the PREVIOUS frame: its transfers ran beside this frame's Trace
             pending.append(ticket)
+            # what this rank spent on the frame itself -- its Trace, its strip and, on the primary, assembling and tone-mapping
+            # the previous frame -- is what the scheduler balances (the reference feeds Tracer.Stats().RenderTime, scheduler.go:58-62)
+            fb.publish(rows, own_work[0] * 1e3)
 
     def fence():
         torch.cuda.synchronize()
