@@ -49,6 +49,7 @@ extern "C" {
 #define POLARIS_E_DEVICE          4  /* a HIP runtime call failed; text in last_error */
 #define POLARIS_E_BAD_SCENE       5  /* scene arrays inconsistent (index out of range, BVH deeper than the traversal stack) */
 #define POLARIS_E_UNSUPPORTED     6  /* e.g. merge between handles that cannot reach each other */
+#define POLARIS_E_TIMEOUT         7  /* polaris_hip_wait_reset: the awaited Reset stage did not arrive within 120 s */
 
 typedef struct polaris_hip_tracer polaris_hip_tracer; /* opaque */
 
@@ -140,7 +141,7 @@ int polaris_hip_reset_frame(polaris_hip_tracer *h);
  * merge then lands behind this frame's clear, while the primary is still tracing (the reference leaves this to chance,
  * renderer/default.go:188-191 against tracer.go:208-213; polaris_amd/host/renderer.cpp shows the use). */
 int polaris_hip_reset_epoch(polaris_hip_tracer *h, uint64_t *epoch);
-int polaris_hip_wait_reset(polaris_hip_tracer *h, uint64_t epoch);
+int polaris_hip_wait_reset(polaris_hip_tracer *h, uint64_t epoch); /* POLARIS_E_TIMEOUT after 120 s without that Reset */
 
 /* Tracer.SyncFramebuffer: wait for pending merges, then tonemapSimpleReinhard over rows of
  * req with weight 1/(accumulated_samples+samples_per_pixel) into the RGBA8 frame buffer. */

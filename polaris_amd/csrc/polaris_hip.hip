@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cmath>
 #include <cstdarg>
@@ -1040,7 +1041,12 @@ int polaris_hip_reset_epoch(polaris_hip_tracer *h, uint64_t *epoch) {
 int polaris_hip_wait_reset(polaris_hip_tracer *h, uint64_t epoch) {
 	if (!h) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "handle is null");
 	std::unique_lock<std::mutex> lk(h->merge_mu);
-	h->reset_cv.wait(lk, [&] { return h->reset_epoch > epoch; });
+	// (bounded: a caller that waits for a Trace nobody will issue gets an error instead of a hung thread)
+	if (!h->reset_cv.wait_for(lk, std::chrono::seconds(120), [&] { return h->reset_epoch > epoch; })) {
+		h->merge_error = "wait_reset: no Trace with accumulated_samples == 0 (or reset_frame) arrived within 120 s";
+		h->merge_error_seq = ++g_error_seq;
+		return POLARIS_E_TIMEOUT;
+	}
 	return POLARIS_OK;
 }
 
