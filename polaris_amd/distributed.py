@@ -145,8 +145,12 @@ class SchedulerFeedback:
             return
         t = self._torch
         mine = t.tensor([int(rows[self.rank]), int(trace_ms * 1e6)], dtype=t.int64, device=self._dev)
-        out = [t.zeros(2, dtype=t.int64, device=self._dev) for _ in range(self.world)]
-        work = self.dist.all_gather(out, mine, async_op=True)
+        if mine.is_cuda:  # nccl: one output tensor, so that reading the result back is ONE device-to-host copy
+            out = t.zeros((self.world, 2), dtype=t.int64, device=self._dev)
+            work = self.dist.all_gather_into_tensor(out, mine, async_op=True)
+        else:             # gloo (tests)
+            out = [t.zeros(2, dtype=t.int64) for _ in range(self.world)]
+            work = self.dist.all_gather(out, mine, async_op=True)
         self._pending.append((work, out, mine))
 
     def next_rows(self):
@@ -156,9 +160,7 @@ class SchedulerFeedback:
         while len(self._pending) > 1:  # everything but the frame just published has had a whole frame's time to complete
             work, out, _ = self._pending.pop(0)
             work.wait()
-            if out[0].is_cuda:
-                self._torch.cuda.current_stream(out[0].device).synchronize()
-            got = [o.cpu().tolist() for o in out]
+            got = out.cpu().tolist() if not isinstance(out, list) else [o.tolist() for o in out]  # (.cpu() orders itself behind the collective on the current stream)
             self.rows = self._sched.schedule(self.H, block_h=[g[0] for g in got], render_ns=[max(1, g[1]) for g in got])
         return self.rows
 
