@@ -9,12 +9,19 @@ rendered the way renderer/default.go:106-171 renders a frame:
     -> every tracer Trace()s its row block -> the primary MergeOutput()s every block
     -> primary SyncFramebuffer() (tone-map)
 
-One process per GPU (torch.distributed, backend nccl = RCCL): rank r owns row block r; the single
-exchange step of the path -- the gather of the blocks' accumulator strips to the primary
-(renderer/default.go:191, tracer/opencl/resources.go:108-124) -- is a dist.gather of
-block_h*frame_w float4 per rank (512 KiB per peer at 8 GPUs).  The frame is fixed, so scaling is
-STRONG.  Scene and seeds are synthetic (polaris_amd/scenes.py); inputs are resident in HBM before
-the timed region starts.
+One process per GPU: rank r owns row block r; the single exchange step of the path -- the primary adds
+every block's rows of the trace accumulators into its frame accumulator (renderer/default.go:191,
+tracer/opencl/resources.go:108-124) -- is a PEER READ, as in the reference (whose devices share one
+OpenCL context, renderer/default.go:225-229): every rank publishes HIP-IPC handles of its trace
+accumulator ring once, rank 0 maps them and its merge stream runs the aggregate kernel straight over the
+peer-mapped rows (polaris_hip_merge_ipc; xGMI).  No RCCL on the data path ("independent tiles, so no
+RCCL"): torch.distributed (gloo) carries control only -- the handles at set-up and 32 bytes per rank and
+frame.  If a mapping cannot be opened the run falls back, in the same processes, to point-to-point strip
+transfers (`--exchange strips`: backend nccl = RCCL); `config.exchange` names which ran.  The block
+scheduler for N > 1 is `naive` (what `polaris render` passes, cmd/render.go:65); the same run then times
+the perfect scheduler (tracer/scheduler.go:50-80) as a second region -> `config.perfect_scheduler`.
+The frame is fixed, so scaling is STRONG.  Scene and seeds are synthetic (polaris_amd/scenes.py); inputs
+are resident in HBM before the timed region starts.
 
 Prints ONE JSON line (rank 0).  `value` = rays traced by all ranks in the K timed frames / wall
 time (max over ranks); rays = primary + indirect + occlusion rays handed to an intersection kernel
@@ -43,7 +50,7 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-SHADE_TIMERS = ("shade_first", "shade_group", "shade_sort", "shade_plain", "shade_wave")  # one library timer per shade kernel symbol
+SHADE_TIMERS = ("shade_first", "shade_sort", "shade_plain", "shade_wave")  # one library timer per shade kernel symbol
 KERNELS = ("generate", "intersect_packet", "intersect", *SHADE_TIMERS, "scan", "occlusion", "resolve", "aggregate", "tonemap")
 PRICED = ("generate", "intersect_packet", "intersect", *SHADE_TIMERS, "occlusion")  # the kernels that move ray streams
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
@@ -184,7 +191,11 @@ def main() -> None:
     ap.add_argument("--save-png", default="")
     ap.add_argument("--save-accumulator", default="", help="rank 0 writes its frame accumulator of the last frame as .npy (tests)")
     ap.add_argument("--opt", action="append", default=[], help="tracer option key=value (polaris_hip_set_option)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to test the N>1 flow on one GPU)")
+    ap.add_argument("--exchange", default="ipc", choices=("ipc", "strips"), help="N > 1: how the blocks reach the primary -- `ipc`: peer reads of every rank's "
+                    "trace accumulator through HIP IPC mappings (polaris_hip_merge_ipc; falls back to `strips` if a mapping cannot be opened), "
+                    "`strips`: point-to-point transfers of the strips on --backend")
+    ap.add_argument("--backend", default="nccl", help="--exchange strips: torch.distributed backend of the strip transfers (nccl = RCCL; gloo only to test that flow on one GPU)")
+    ap.add_argument("--no-second-scheduler", action="store_true", help="N > 1: skip the second timed region (the perfect scheduler when --scheduler naive)")
     ap.add_argument("--same-device", action="store_true", help="testing aid: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--emulate-rank", default="", help="R/N: on ONE GPU, trace only the row block rank R of N would own "
                     "(tuning aid for the strong-scaling path; not a valid bench line)")
@@ -193,8 +204,8 @@ def main() -> None:
                     "(polaris_hip_merge): the reference renderer's own model (renderer/default.go:106-196); no torch.distributed, no RCCL")
     ap.add_argument("--devices", default="", help="--inproc: comma separated device index per tracer (default 0..N-1; repeating a device, "
                     "e.g. 0,0,0, runs several tracers on one GPU: a testing aid)")
-    ap.add_argument("--scheduler", default="perfect", choices=("naive", "perfect"), help="block scheduler for N > 1 (tracer/scheduler.go): `naive` = equal "
-                    "rows (what `polaris render` passes, cmd/render.go:65), `perfect` = rows from the previous frames' times (scheduler.go:50-80)")
+    ap.add_argument("--scheduler", default="naive", choices=("naive", "perfect"), help="block scheduler for N > 1 (tracer/scheduler.go): `naive` = equal "
+                    "rows (what `polaris render` passes, cmd/render.go:65: the default), `perfect` = rows from the previous frames' times (scheduler.go:50-80)")
     ap.add_argument("--test-seeds", action="store_true", help="testing aid: fixed host PRNG draws -- --inproc: tracer t of frame f draws from "
                     "make_seeds(base = 1000 f + 17 t); default mode: frame f uses make_seeds(base = 0xC0FFEE + f) instead of one list for every frame")
     args = ap.parse_args()
@@ -238,10 +249,7 @@ def main() -> None:
         if args.same_device:
             local_rank = 0
         torch.cuda.set_device(local_rank)
-        if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=args.backend)
+        dist.init_process_group(backend="gloo")  # CONTROL plane only (handles, 32 bytes per rank and frame, the final reductions)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the tracer has no CPU fallback")
     dev = torch.device("cuda", local_rank)
@@ -249,6 +257,8 @@ def main() -> None:
     from polaris_amd import ctypes_api as T
     from polaris_amd import scenes
     from polaris_amd.distributed import SchedulerFeedback, StripExchange, block_of, naive_rows
+
+    xdev = strip_group = None
     from polaris_amd.tracer import ChangeType, HipTracer, UpdateMode
 
     W, H, spp, B = args.width, args.height, args.spp, args.bounces
@@ -283,12 +293,30 @@ def main() -> None:
         r.exposure, r.seed, r.accumulated_samples = 1.2, 0, 0
         return r
 
-    # The path's one exchange step (renderer/default.go:191): the blocks' strips travel to the primary.  It runs one frame
-    # behind the tracing (polaris_amd/distributed.py): frame i's transfers / merge / tone-map overlap frame i+1's Trace.  The
-    # block scheduler runs identically on every rank from all-gathered (rows, time) pairs, also one frame behind.
-    xdev = dev if args.backend == "nccl" else torch.device("cpu")
-    ex = StripExchange(dist, rank, world, W, H, dev, via_host=args.backend != "nccl") if world > 1 else None
-    fb = SchedulerFeedback(dist, rank, world, H, xdev, kind=args.scheduler) if world > 1 else None
+    # The path's one exchange step (renderer/default.go:191): the primary adds every block's rows into its frame accumulator.
+    # It runs one frame behind the tracing (polaris_amd/distributed.py): frame i's merge / tone-map overlap frame i+1's Trace.
+    # The block scheduler runs identically on every rank from all-gathered (rows, time) pairs, also one frame behind.
+    px = ex = fb = None
+    exchange = "none (1 GPU)"
+    if world > 1:
+        from polaris_amd.distributed import HipPort, PeerExchange
+
+        if args.exchange == "ipc":
+            px = PeerExchange(dist, rank, world, W, H, HipPort(tr, make_req), scheduler=args.scheduler)
+            if px.setup():
+                exchange = (f"hip-ipc: rank 0's merge stream reads every rank's rows through an IPC mapping of its trace accumulator ring "
+                            f"(depth {px.depth}), one frame behind the tracing; control = 32 B per rank and frame over gloo; no RCCL")
+            else:
+                if rank == 0:
+                    print(f"bench.py: HIP IPC mapping failed ({px.why_not}); falling back to strip transfers on {args.backend}", file=sys.stderr)
+                exchange = f"fallback after a failed IPC mapping ({px.why_not[:120]}): "
+                px = None
+        if px is None:
+            strip_group = dist.new_group(backend="nccl") if args.backend == "nccl" else None   # (RCCL communicators only exist on this path)
+            xdev = dev if args.backend == "nccl" else torch.device("cpu")
+            ex = StripExchange(dist, rank, world, W, H, dev, via_host=args.backend != "nccl", group=strip_group)
+            fb = SchedulerFeedback(dist, rank, world, H, xdev, kind=args.scheduler, group=strip_group)
+            exchange = (exchange if args.exchange == "ipc" else "") + f"{args.backend} point-to-point transfers of the row-block strips to rank 0, one frame behind the tracing"
     totals = {k: 0 for k in ("primary_rays", "indirect_rays", "occlusion_rays", "shaded_hits", "shaded_misses", "emitter_hits", "unoccluded")}
     pending = []
     rows_log = []
@@ -296,6 +324,12 @@ def main() -> None:
     own_work = [0.0]                               # seconds of this rank's OWN work in the current frame (what the scheduler balances)
 
     def finish_frame(ticket):
+        if px is not None:
+            t = time.perf_counter()
+            px.finish(ticket)                      # rank 0: Reset stage, one peer-read merge per block, tone-map (default.go:159-161)
+            if rank == 0:
+                own_work[0] += time.perf_counter() - t
+            return
         parts = ex.wait(ticket)                    # (waiting for the others' strips is not this rank's work)
         if rank == 0:
             t = time.perf_counter()
@@ -313,8 +347,8 @@ def main() -> None:
 
     def frame(count: bool):
         nonlocal rows, block_y, block_h
-        if fb is not None and not args.emulate_rank:
-            rows = fb.next_rows()                  # Schedule (default.go:124): the same rows on every rank
+        if world > 1 and not args.emulate_rank:
+            rows = px.next_rows() if px is not None else fb.next_rows()   # Schedule (default.go:124): the same rows on every rank
             block_y, block_h = block_of(rank, rows)
         req = make_req(block_y, block_h)
         fseeds = seeds
@@ -331,6 +365,10 @@ def main() -> None:
         if world == 1:
             tr.MergeOutput(tr, req)                # primary merges its own block (default.go:191)
             tr.SyncFramebuffer(make_req(0, H) if not args.emulate_rank else req)
+        elif px is not None:
+            own_work[0] = time.perf_counter() - t_own
+            flush()                                # the PREVIOUS frame, BEFORE this frame is announced (PeerExchange: why depth 3 is enough)
+            pending.append(px.post(rows, own_work[0] * 1e3))
         else:
             ticket = ex.post(lambda strip: tr.export_block(req, strip.data_ptr()), rows)
             own_work[0] = time.perf_counter() - t_own
@@ -346,29 +384,53 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        frame(False)
-    flush()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        frame(True)
-    flush()                                        # all K frames merged and tone-mapped inside the timed region
-    fence()
-    elapsed = time.perf_counter() - t0
+    def timed_region(steps: int, warmup: int, count: bool):
+        for _ in range(warmup):
+            frame(False)
+        flush()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            frame(count)
+        flush()                                    # all K frames merged and tone-mapped inside the timed region
+        fence()
+        return time.perf_counter() - t0
+
+    elapsed = timed_region(args.steps, args.warmup, True)
     if fb is not None:
         fb.drain()
+    main_rows = list(rows)                         # (the second region below schedules its own)
     if args.save_accumulator and rank == 0:
         np.save(args.save_accumulator, tr.read_accumulator(1))  # the primary's frame accumulator of the last frame (tests)
 
-    rdev = dev if args.backend == "nccl" else torch.device("cpu")
-    el = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
-    cnt = torch.tensor([totals[k] for k in sorted(totals)], dtype=torch.int64, device=rdev)
+    # N > 1: the same frames under the OTHER block scheduler, as a second timed region (reported beside the headline, never as it)
+    second = None
+    if world > 1 and not args.no_second_scheduler and not args.emulate_rank:
+        other = "perfect" if args.scheduler == "naive" else "naive"
+        if px is not None:
+            px.set_scheduler(other)
+        else:
+            fb = SchedulerFeedback(dist, rank, world, H, xdev, kind=other, group=strip_group)
+        keep_totals, keep_rows_log = dict(totals), list(rows_log)
+        rows_log.clear()
+        el2 = timed_region(args.steps, max(args.warmup, 4), True)   # (the perfect scheduler needs a few frames to settle on its rows)
+        if fb is not None:
+            fb.drain()
+        rays2 = sum(totals[k] - keep_totals[k] for k in ("primary_rays", "indirect_rays", "occlusion_rays"))
+        second = (other, el2, rays2, list(rows_log[-1]) if rows_log else None)
+        totals.update(keep_totals)
+        rows_log[:] = keep_rows_log
+
+    el = torch.tensor([elapsed, second[1] if second else 0.0], dtype=torch.float64)       # (CPU tensors: gloo)
+    cnt = torch.tensor([totals[k] for k in sorted(totals)] + [second[2] if second else 0], dtype=torch.int64)
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-    elapsed = float(el.item())
+    elapsed = float(el[0].item())
     tot = {k: int(v) for k, v in zip(sorted(totals), cnt.tolist())}
+    if second:
+        second = {"scheduler": second[0], "value": int(cnt[-1].item()) / float(el[1].item()) / 1e6, "unit": "Mrays/s", "ms_per_step": float(el[1].item()) / args.steps * 1e3,
+                  "steps": args.steps, "rows_last_frame": second[3]}
     rays = tot["primary_rays"] + tot["indirect_rays"] + tot["occlusion_rays"]
 
     if rank == 0:
@@ -388,11 +450,11 @@ def main() -> None:
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{sc.name} {W}x{H} {spp}spp {B} bounces rr>={args.rr}, {sc.num_triangles} tris, "
-                                   f"row blocks {rows} ({'naive' if world == 1 else args.scheduler} scheduler{'' if world == 1 else ', rows of the last frame'}), "
+                                   f"row blocks {main_rows} ({'naive' if world == 1 else args.scheduler} scheduler{'' if world == 1 else ', rows of the last frame'}), "
                                    f"strips to the primary + tonemap",
                        "ranks": world, "scheduler": "naive" if world == 1 else args.scheduler,
                        "rows_first_timed_frame": rows_log[0] if rows_log else None, "rows_last_frame": rows_log[-1] if rows_log else None,
-                       "exchange": "none (1 GPU)" if world == 1 else f"{args.backend} point-to-point transfers of the row-block strips to rank 0, one frame behind the tracing",
+                       "exchange": exchange, "perfect_scheduler" if (second or {}).get("scheduler") == "perfect" else "second_scheduler": second,
                        "frame": [W, H], "spp": spp, "bounces": B, "rays_per_frame": rays // args.steps,
                        "paths_per_s": W * H * spp * args.steps / elapsed},
         }
@@ -434,7 +496,7 @@ def main() -> None:
             out["kernels_isolated_ms_per_frame"] = {**{k: round(v[0], 3) for k, v in iso.items() if k not in ("aggregate", "tonemap")}, "shade": round(shade_ms, 3)}
             mine = {k: totals[k] // args.steps for k in totals}     # per-frame counters of rank 0
             whole = (112 * mine["primary_rays"] + 68 * mine["shaded_hits"] + 92 * mine["indirect_rays"] + 80 * mine["occlusion_rays"]
-                     + 44 * mine["unoccluded"] + 60 * mine["shaded_misses"] + 24 * mine["emitter_hits"] + (48 + 16) * rows[0] * W)
+                     + 44 * mine["unoccluded"] + 60 * mine["shaded_misses"] + 24 * mine["emitter_hits"] + (48 + 16) * main_rows[0] * W)
             out["whole_path_algorithmic_GBps_rank0"] = whole / (elapsed / args.steps) / 1e9
         # ---- CPU baseline: the oracle (checker) on a bounded sample of the same workload ----
         # Sample-parallel mode of the restatement (threads take whole samples; same paths as the
@@ -470,9 +532,14 @@ def main() -> None:
 
             Image.fromarray(tr.read_framebuffer()[..., :3]).save(args.save_png)
         print(json.dumps(out))
-    tr.Close()
+    if dist is not None:
+        dist.barrier()                             # every rank's ring stays mapped until the primary has closed its mappings
+    if px is not None:
+        px.close()
     if dist is not None:
         dist.barrier()
+    tr.Close()
+    if dist is not None:
         dist.destroy_process_group()
 
 

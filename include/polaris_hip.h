@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define POLARIS_HIP_ABI_VERSION 2 /* 2: + reset_epoch / wait_reset, kernel_symbol, shade_counts (additions only: a version-1 caller keeps working) */
+#define POLARIS_HIP_ABI_VERSION 3 /* 2: + reset_epoch / wait_reset, kernel_symbol, shade_counts; 3: + ipc_export / ipc_open / ipc_close / merge_ipc / merge_slot / trace_slot (additions only: older callers keep working) */
 
 /* status codes (0 = ok).  The first three mirror tracer/opencl/errors.go sentinels. */
 #define POLARIS_OK                0
@@ -91,9 +91,12 @@ int polaris_hip_set_camera(polaris_hip_tracer *h, const float eye[3], const floa
  *                        2 up to 32 K triangles, 4 above; 0 = keep the caller's leaves).  Never
  *                        changes a result: DESIGN.md 2 (HBM data layout)
  *   further A/B switches of the kernels ("traversal", "node_mode", "packet_shadow", "shade_wave",
- *   "shade_wave_from", "shade_group", "shade_sort", "wide", "shade_wgs_per_cu", "stage_lds", "trace_wgs_per_cu"): see
+ *   "shade_wave_from", "shade_sort", "shade_wgs_per_cu", "stage_lds", "trace_wgs_per_cu"): see
  *   DESIGN.md 3.  Apart from "exact_accumulate" (the order of the float sums) no option changes a
- *   result; an unknown key is POLARIS_E_BAD_ARGUMENT. */
+ *   result; an unknown key is POLARIS_E_BAD_ARGUMENT.  The batch size chosen automatically
+ *   ("samples_per_batch" = 0) is clamped by the FREE device memory, and with it the order of the
+ *   batched per-pixel float sums: non-exact output is bit-reproducible on one machine state, not
+ *   across machines (exact_accumulate = 1 is, everywhere). */
 int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value);
 
 /*
@@ -118,7 +121,9 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *req, con
  * after src's Trace (synchronous) and after the START of dst's Trace of the same frame, which clears the
  * frame accumulator when accumulated_samples == 0 (the reference races there; polaris_amd/host/renderer.cpp
  * waits).  src may live on another GPU of the same process (peer access over xGMI, falling back to a
- * staged peer copy). */
+ * staged peer copy).  src must not be handed its next Trace's rows to overwrite before this merge has read them: the
+ * library orders that on the device (src's next Trace waits for an event dst's merge stream records behind the read), so
+ * the host need not sync in between. */
 int polaris_hip_merge(polaris_hip_tracer *dst, polaris_hip_tracer *src, const PolarisBlockRequest *req);
 
 /* One-process-per-GPU variant of the same exchange (bench.py under torch.distributed):
@@ -127,6 +132,54 @@ int polaris_hip_merge(polaris_hip_tracer *dst, polaris_hip_tracer *src, const Po
  * dst's frame accumulator. */
 int polaris_hip_export_block(polaris_hip_tracer *h, const PolarisBlockRequest *req, void *device_dst);
 int polaris_hip_merge_device(polaris_hip_tracer *dst, const void *device_rows, const PolarisBlockRequest *req);
+
+/*
+ * Cross-PROCESS merge: peer reads over HIP IPC (one process per GPU, the driver's launch contract).
+ *
+ * The reference gives all devices ONE shared OpenCL context, so the primary's aggregateAccumulator kernel reads a
+ * secondary's traceAccumulator cl_mem directly (renderer/default.go:225-229, tracer/opencl/tracer.go:279-286,
+ * resources.go:108-124).  Across processes the same read goes through an IPC mapping of the secondary's buffer:
+ *
+ *   secondary                                             primary
+ *   polaris_hip_ipc_export(h, depth, &blob)   -- once, after resize; the blob is plain bytes for any channel -->
+ *                                                         polaris_hip_ipc_open(dst, &blob, &peer)
+ *   polaris_hip_trace(h, ..)      writes ring slot s = polaris_hip_trace_slot(h)
+ *      -- "frame f is in slot s" (a host message AFTER Trace returned: Trace is synchronous) -->
+ *                                                         polaris_hip_merge_ipc(dst, peer, s, req)   k_aggregate over the
+ *                                                             peer-mapped rows, on dst's merge stream (xGMI peer read)
+ *
+ * ipc_export turns the tracer's trace accumulator into a RING of `depth` frame-sized buffers (1..POLARIS_IPC_MAX_DEPTH):
+ * every later Trace writes the next slot, so the primary may still be reading frame f's rows while the secondary traces
+ * frame f + 1 -- no copy, no staging strip.  The caller's protocol must guarantee that the primary has finished reading a
+ * slot (its merge completed: sync_framebuffer) before the secondary's Trace comes round to it again; with the exchange one
+ * frame behind the tracing that needs depth 3 (polaris_amd/distributed.py: PeerExchange states the argument).  The blob
+ * also carries an inter-process event recorded at the end of every Trace; merge_ipc makes the merge stream wait for it
+ * (device-side ordering on top of the host message; has_event = 0 if the runtime could not export one).  A resize
+ * invalidates the export: peers close, the tracer exports again.  hipIpcOpenMemHandle cannot open a handle in the process
+ * that created it: tracers of ONE process use polaris_hip_merge / polaris_hip_merge_slot.
+ */
+#define POLARIS_IPC_MAX_DEPTH 4
+typedef struct PolarisIpcExport {
+	uint32_t abi_version, depth, frame_w, frame_h;
+	int32_t device;     /* HIP device index in the exporting process */
+	uint32_t pid;       /* exporting process (diagnostics; opening in the same process is refused) */
+	uint32_t has_event; /* 1: `event` holds a hipIpcEventHandle_t */
+	uint32_t reserved;
+	uint8_t mem[POLARIS_IPC_MAX_DEPTH][64]; /* hipIpcMemHandle_t per ring slot */
+	uint8_t event[64];                      /* hipIpcEventHandle_t: recorded at the end of every Trace */
+} PolarisIpcExport;
+typedef struct polaris_hip_peer polaris_hip_peer; /* opaque: another process's trace accumulator ring, mapped here */
+
+int polaris_hip_ipc_export(polaris_hip_tracer *h, uint32_t depth, PolarisIpcExport *out);
+int polaris_hip_ipc_open(polaris_hip_tracer *dst, const PolarisIpcExport *peer_export, polaris_hip_peer **out);
+int polaris_hip_ipc_close(polaris_hip_tracer *dst, polaris_hip_peer *peer); /* waits for dst's merge stream first */
+/* dst.frameAccumulator[rows of req] += peer.traceAccumulator ring[slot][rows of req]; asynchronous on dst's merge stream
+ * like polaris_hip_merge, completed by polaris_hip_sync_framebuffer(dst). */
+int polaris_hip_merge_ipc(polaris_hip_tracer *dst, polaris_hip_peer *peer, uint32_t slot, const PolarisBlockRequest *req);
+/* The ring slot the last Trace wrote (0 without a ring), and polaris_hip_merge from a given slot of a tracer of THIS
+ * process (a primary that merges its own block one frame late reads the slot of that frame, not the newest). */
+int polaris_hip_trace_slot(polaris_hip_tracer *h, uint32_t *slot);
+int polaris_hip_merge_slot(polaris_hip_tracer *dst, polaris_hip_tracer *src, uint32_t slot, const PolarisBlockRequest *req);
 
 /* The pipeline's Reset stage on its own (tracer/opencl/tracer.go:208-213: clearAccumulator(frameAccumulator)).
  * Trace runs it whenever accumulated_samples == 0.  A host that merges a frame's blocks only after the NEXT
@@ -193,7 +246,7 @@ int polaris_hip_selftest_rcp(polaris_hip_tracer *h, float lo, float hi, uint64_t
 
 /* With option time_kernels=1: accumulated device milliseconds and launch count of the named
  * timer since the last call for that name.  Timers: "generate", "intersect_packet" (camera rays through
- * the wave-packet kernel), "intersect" (closest hit), "shade_first" / "shade_group" / "shade_sort" /
+ * the wave-packet kernel), "intersect" (closest hit), "shade_first" / "shade_sort" /
  * "shade_plain" / "shade_wave" (one per shade kernel symbol), "scan", "occlusion", "resolve", "aggregate", "tonemap". */
 int polaris_hip_kernel_ms(polaris_hip_tracer *h, const char *kernel, double *ms, uint64_t *launches);
 
@@ -203,7 +256,7 @@ int polaris_hip_kernel_symbol(polaris_hip_tracer *h, const char *kernel, char sy
 
 /* Shading events of the last Trace per bounce: counts[4 b + 0..2] = shaded hits, shaded misses, emitter
  * hits of the shade step of bounce b (their sums are PolarisTraceStats' totals), counts[4 b + 3] = which
- * shade timer that step ran under (0 shade_first, 1 shade_sort, 2 shade_plain, 3 shade_wave, 4 shade_group).
+ * shade timer that step ran under (0 shade_first, 1 shade_sort, 2 shade_plain, 3 shade_wave).
  * n_counts >= 4 * POLARIS_MAX_BOUNCES.  Measurement aid: algorithmic bytes per shade kernel symbol. */
 int polaris_hip_shade_counts(polaris_hip_tracer *h, uint64_t *counts, size_t n_counts);
 

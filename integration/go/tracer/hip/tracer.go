@@ -236,8 +236,10 @@ func (tr *Tracer) ResetEpoch() uint64 {
 	return uint64(e)
 }
 
-func (tr *Tracer) WaitReset(epoch uint64) {
-	C.polaris_hip_wait_reset(tr.handle, C.uint64_t(epoch))
+// A non-nil error (POLARIS_E_TIMEOUT: the awaited Reset never came) means the block must NOT be merged: it would land on
+// an accumulator that was not cleared for this frame.
+func (tr *Tracer) WaitReset(epoch uint64) error {
+	return tr.check(C.polaris_hip_wait_reset(tr.handle, C.uint64_t(epoch)))
 }
 
 // SyncFramebuffer mirrors tracer/opencl/tracer.go:250-276 (wait, then tone-map).

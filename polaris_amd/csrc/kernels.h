@@ -71,11 +71,6 @@ struct BvhDev {
 
 struct Streams {
 	float4 *ray_o, *ray_d, *thr, *hit;
-	// where a shade step writes the bounce rays it emits.  The host alternates two sets of (ray_o, ray_d, thr) from bounce to
-	// bounce, so a shade kernel never overwrites rays that are still to be read -- whatever the order it shades them in
-	// (k_shade_group shades a group of chunks class by class).  (Equal to the input set: in place, which only kernels that
-	// read a chunk's rays before they write into it may use -- k_shade, k_shade_wave.)
-	float4 *out_o, *out_d, *out_thr;
 	float4 *occ_o, *occ_d, *occ_e;
 	float4 *lsum;
 	uint32_t *cnt_ray, *cnt_occ, *pfx;
@@ -1136,7 +1131,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(POLARIS_SHAD
 			atomicOr(&s_emit[canon >> 5], 1u << (canon & 31));
 			const size_t d = base + at_ind + __popcll(m_ind & below);
 			R.thr.w = ibits((int)canon); // the child's parent, in canonical order
-			st.out_o[d] = R.ro; st.out_d[d] = R.rd; st.out_thr[d] = R.thr;
+			st.ray_o[d] = R.ro; st.ray_d[d] = R.rd; st.thr[d] = R.thr;
 		}
 	}
 	// ---- the last wave to get here publishes the chunk's counts and emit mask -------------------
@@ -1230,7 +1225,7 @@ void k_shade_wave(Streams st, SceneDev Sg, ShadeArgs A, uint32_t num_chunks) {
 				atomicOr(&w_emit[wave][k][canon >> 5], 1u << (canon & 31));
 				const size_t d = base + atomicAdd(&w_cnt[wave][k][0], 1u); // any free slot of the ray's chunk: the order is in thr.w
 				R.thr.w = ibits((int)canon);
-				st.out_o[d] = R.ro; st.out_d[d] = R.rd; st.out_thr[d] = R.thr;
+				st.ray_o[d] = R.ro; st.ray_d[d] = R.rd; st.thr[d] = R.thr;
 			}
 			if (live && (R.hit | R.miss | R.emit) != 0) atomicAdd(&w_cnt[wave][k][2], R.hit | (R.miss << 10) | (R.emit << 20));
 		}
@@ -1245,236 +1240,6 @@ void k_shade_wave(Streams st, SceneDev Sg, ShadeArgs A, uint32_t num_chunks) {
 			if (chunk0 + i / 8 < num_chunks) A.emask_out[(size_t)chunk0 * 8 + i] = (&w_emit[wave][0][0])[i];
 			(&w_emit[wave][0][0])[i] = 0;
 		}
-	}
-}
-
-// k_shade_group: bounce rays shaded CLASS BY CLASS across a group of kShadeGroup chunks (round 3).
-//
-// k_shade sorts the rays of ONE chunk by shading class; with ~6 classes among ~150 live rays, every class boundary falls
-// inside a wave and most waves still execute two or three classes' code (PMC: 40 % of the lanes of a VALU instruction live,
-// k_shade_wave on the sparse bounces 20 %).  Here a persistent workgroup takes 16 chunks at a time (up to 4 096 rays),
-// counting-sorts their SLOT INDICES by class in LDS -- two passes over the hit records' last words, 4 bytes per ray each --
-// with every class starting on a wave boundary, and its waves then draw 64 consecutive sorted rays at a time: a wave runs
-// one class's code, and within a big class consecutive sorted rays are consecutive slots of one chunk (coalesced loads).
-// What makes that legal: a ray's identity is DATA, not its place (Streams::emask: parent's canonical index + the chunk's
-// emit mask -> reference position, exactly as in k_shade), and the rays a step emits go to the OTHER set of ray buffers
-// (Streams::out_*), appended to their parent's chunk through per-chunk LDS counters -- nothing that is still to be read is
-// overwritten, in whatever order the rays are shaded.  Sparse late bounces cost what their rays cost (a group of 16 chunks
-// with 300 survivors is five waves' work), so this kernel also replaces k_shade_wave.
-constexpr int kShadeGroup = 16;
-constexpr int kShadeClasses = 16; // classes 0 (missed) .. 15
-#ifndef POLARIS_SHADE_GROUP_WAVES
-#define POLARIS_SHADE_GROUP_WAVES 5
-#endif
-// Everything the kernel needs, in device memory (written by k_store_group_args in front of the launch): the shading of one
-// pass is a REAL function call (below), and the callee reads what it needs from here with scalar loads, on demand, exactly as
-// a kernel reads its arguments -- instead of the caller keeping ~70 scalar registers of pointers alive around the call.
-struct GroupArgs { Streams st; SceneDev Sg; ShadeArgs A; uint32_t tex_bytes; };
-__global__ void k_store_group_args(GroupArgs a, GroupArgs *dst) { if (threadIdx.x == 0) *dst = a; }
-
-// LDS of k_shade_group (namespace scope: the pass function below uses it too)
-static __shared__ ShadeLds g_lds;
-static __shared__ uint32_t g_o_cnt[kShadeGroup][3];  // per chunk: bounce rays emitted, shadow rays emitted, event word (hits | misses << 10 | emitter hits << 20)
-static __shared__ uint32_t g_o_emit[kShadeGroup][8]; // per chunk: this step's emit mask
-// A/B build (-DPOLARIS_TEXELS_LDS, scripts/build_variant.sh): the scene's whole texture blob staged in LDS for the lifetime of the
-// persistent workgroup (north_star: "texture tiles staged in LDS") where it fits -- measured, not adopted: DESIGN.md 3.4
-#ifdef POLARIS_TEXELS_LDS
-constexpr uint32_t kTexelsLdsBytes = 24 * 1024;
-static __shared__ uint32_t g_texels[kTexelsLdsBytes / 4];
-#endif
-
-// One pass: the wave's 64 sorted rays (entry e = chunk within the group << 8 | slot within the chunk, 0xFFFF = padding).
-// NOT inlined on purpose.  Inside k_shade_group's persistent loops the inlined shading code needed 135 vector registers (the
-// compiler hoists the loop-invariant halves of ~9 000 instructions -- constants, table addresses -- out of the loops and keeps
-// them alive): 4 waves per SIMD with spills, and the kernel, though it issues 31 % fewer vector instructions than k_shade +
-// k_shade_wave, was SLOWER (latency bound).  As a function of its own the same code is allocated like k_shade's loop-free
-// body.
-template <bool LDS>
-#ifdef POLARIS_GROUP_PASS_CALL
-__device__ __attribute__((noinline))
-#else
-__device__ __forceinline__
-#endif
-void shade_group_pass(const GroupArgs *__restrict__ ga_in, uint32_t e, uint32_t chunk0) {
-	// the argument record's address is made opaque per pass: nothing derived from it (some 70 scalar registers of pointers and
-	// parameters) can be hoisted out of the caller's loops and kept alive across them; each pass re-reads what it uses
-	const GroupArgs *ga = ga_in;
-	asm volatile("" : "+s"(ga));
-	const Streams &st = ga->st;
-	const ShadeArgs &A = ga->A;
-	SceneT<LDS> S;
-	{
-		const SceneDev &Sg = ga->Sg;
-		S.vertices = Sg.vertices; S.normals = Sg.normals; S.uvs = Sg.uvs; S.mat_index = Sg.mat_index; S.tex_data = Sg.tex_data;
-		S.num_emissives = Sg.num_emissives; S.bg_node = Sg.bg_node; S.num_nodes = Sg.num_nodes; S.num_textures = Sg.num_textures;
-		S.tri_bits = Sg.tri_bits; S.sel_pdf = Sg.sel_pdf;
-		if constexpr (LDS) {
-			S.light_geo = (typename Tbl<true>::F)(reinterpret_cast<float *>(g_lds.light_geo));
-			S.nodes = (typename Tbl<true>::Node)(g_lds.nodes);
-			S.emissives = (typename Tbl<true>::Light)(g_lds.lights);
-			S.tex_meta = (typename Tbl<true>::TexMeta)(g_lds.texmeta);
-		} else {
-			S.nodes = Sg.nodes; S.emissives = Sg.emissives; S.tex_meta = Sg.tex_meta; S.light_geo = Sg.light_geo;
-		}
-#ifdef POLARIS_TEXELS_LDS
-		if (ga->tex_bytes + 16u <= kTexelsLdsBytes) S.tex_data = reinterpret_cast<const uint8_t *>(g_texels);
-#endif
-	}
-	const bool live = e != 0xFFFFu;
-	const uint32_t k = live ? e >> 8 : 0u;
-	const uint32_t chunk = chunk0 + k;
-	// every per-lane address is a scalar base + a 32-bit byte offset (one VGPR, not a pair): slot * 16 < 2^32 for any batch
-	const uint32_t slot16 = (chunk * (uint32_t)WG + (e & 255u)) * 16u, base16 = chunk * (uint32_t)(WG * 16);
-	auto f4 = [](float4 *p, uint32_t byte_off) -> float4 & { return *reinterpret_cast<float4 *>(reinterpret_cast<char *>(p) + byte_off); };
-	ShadeOut R;
-	R.emit_ind = false;
-	R.hit = R.miss = R.emit = 0;
-	uint32_t canon = 0;
-	if (live) {
-		const float4 t4 = f4(st.thr, slot16), d4 = f4(st.ray_d, slot16), h4 = f4(st.hit, slot16);
-		const char *mb = reinterpret_cast<const char *>(A.emask_in) + chunk * 32u;
-		const uint4 m0 = *reinterpret_cast<const uint4 *>(mb), m1 = *reinterpret_cast<const uint4 *>(mb + 16);
-		const uint32_t pmask[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
-		canon = canonical_index(pmask, (uint32_t)fbits(t4.w));
-		const uint32_t s = chunk / (A.Npad / WG);
-		const uint32_t seed = A.seeds[(A.first_sample + s) * A.seed_stride + 1u + A.bounce];
-		shade_ray(S, A, s, seed, st.pfx[chunk] + canon, d4, t4, h4, R, [&](float4 oo, float4 od, float4 oe) {
-			const uint32_t d = base16 + atomicAdd(&g_o_cnt[k][1], 1u) * 16u; // (shadow rays have no order to keep)
-			f4(st.occ_o, d) = oo; f4(st.occ_d, d) = od; f4(st.occ_e, d) = oe;
-		});
-	}
-	if (R.emit_ind) {
-		atomicOr(&g_o_emit[k][canon >> 5], 1u << (canon & 31));
-		const uint32_t d = base16 + atomicAdd(&g_o_cnt[k][0], 1u) * 16u; // any free slot of the parent's chunk, in the OTHER buffer set: the order is in thr.w
-		R.thr.w = ibits((int)canon);
-		f4(st.out_o, d) = R.ro; f4(st.out_d, d) = R.rd; f4(st.out_thr, d) = R.thr;
-	}
-	if (live && (R.hit | R.miss | R.emit) != 0) atomicAdd(&g_o_cnt[k][2], R.hit | (R.miss << 10) | (R.emit << 20));
-}
-
-template <bool LDS>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(POLARIS_SHADE_GROUP_WAVES, POLARIS_SHADE_GROUP_WAVES)))
-void k_shade_group(const GroupArgs *__restrict__ ga, uint32_t num_chunks, uint32_t *ticket) {
-	constexpr int G = kShadeGroup;
-	constexpr uint32_t kOrderCap = G * WG + kShadeClasses * 64; // every class region starts on a multiple of 64
-	__shared__ uint16_t order[kOrderCap];      // chunk within the group << 8 | slot within the chunk; 0xFFFF = padding
-	__shared__ uint32_t g_base[G + 1];         // exclusive prefix of the chunks' live counts
-	__shared__ uint32_t c_cnt[kShadeClasses], c_pos[kShadeClasses]; // rays per class; write cursor of the class's region
-	__shared__ uint32_t s_total, s_cursor, s_group;
-	const uint32_t tid = threadIdx.x, lane = tid & 63;
-	const uint32_t tri_bits = ga->Sg.tri_bits;
-	uint32_t *const cnt_ray = ga->st.cnt_ray, *const cnt_occ = ga->st.cnt_occ, *const wg_stat = ga->st.wg_stat;
-#ifdef POLARIS_TEXELS_LDS
-	if (ga->tex_bytes + 16u <= kTexelsLdsBytes)
-		for (uint32_t i = tid; i < (ga->tex_bytes + 16u) / 4u; i += WG) g_texels[i] = reinterpret_cast<const uint32_t *>(ga->Sg.tex_data)[i];
-#endif
-	(void)stage_scene<LDS>(ga->Sg, g_lds); // (ends in a barrier)
-	const uint32_t num_groups = (num_chunks + G - 1) / G;
-	const int *hit_words = reinterpret_cast<const int *>(ga->st.hit);
-	// the first group of a workgroup is its block index, further ones are drawn from a ticket counter (one draw per 16 chunks:
-	// a few thousand per launch, far below what one address sustains) -- groups cost very different amounts of work
-	uint32_t group = blockIdx.x;
-	while (group < num_groups) {
-		const uint32_t chunk0 = group * G;
-		// ---- the group's live rays, and its class histogram ---------------------------------------------------------
-		if (tid < 64) {
-			const uint32_t c = (tid < (uint32_t)G && chunk0 + tid < num_chunks) ? cnt_ray[chunk0 + tid] : 0u;
-			uint32_t incl = c;
-#pragma unroll
-			for (int d = 1; d < G; d <<= 1) {
-				const uint32_t up = __shfl_up(incl, d);
-				if ((int)lane >= d) incl += up;
-			}
-			if (tid < (uint32_t)G) g_base[tid] = incl - c;
-			if (tid == (uint32_t)G - 1) { g_base[G] = incl; s_total = incl; }
-			if (tid < (uint32_t)kShadeClasses) c_cnt[tid] = 0;
-		}
-		if (tid < (uint32_t)G * 3) (&g_o_cnt[0][0])[tid] = 0;
-		if (tid < (uint32_t)G * 8) (&g_o_emit[0][0])[tid] = 0;
-		__syncthreads();
-		const uint32_t total = s_total;
-		if (total == 0) { // nothing live in the whole group (uniform)
-			if (tid < (uint32_t)G && chunk0 + tid < num_chunks) { cnt_ray[chunk0 + tid] = 0; cnt_occ[chunk0 + tid] = 0; wg_stat[chunk0 + tid] = 0; }
-			if (tid == 0) s_group = gridDim.x + atomicAdd(ticket, 1u);
-			__syncthreads();
-			group = s_group;
-			continue;
-		}
-		// Thread t looks after slot t of each of the group's 16 chunks: its 16 class keys (4 bits each; 0xF... "no ray" is told by
-		// the live count) are read once and kept in two registers for the second pass.
-		unsigned long long keys = 0ull;
-#pragma unroll 1
-		for (int k = 0; k < G; k++) { // (g_base[k + 1] - g_base[k] = the chunk's live count: uniform)
-			const bool has = tid < g_base[k + 1] - g_base[k];
-			uint32_t key = kShadeClasses;
-			if (has) {
-				const int w = hit_words[((size_t)(chunk0 + k) * WG + tid) * 4 + 3];
-				key = w < 0 ? 0u : min((uint32_t)w >> tri_bits, (uint32_t)kShadeClasses - 1u);
-				keys |= (unsigned long long)key << (4 * k);
-			}
-			unsigned long long todo = __ballot(has);
-			while (todo != 0ull) { // one LDS atomic per wave and class present
-				const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)key, __ffsll((long long)todo) - 1);
-				const unsigned long long m = __ballot(key == c);
-				if (lane == 0) atomicAdd(&c_cnt[c], (uint32_t)__popcll(m));
-				todo &= ~m;
-			}
-		}
-		__syncthreads();
-		if (tid < 64) { // class regions, each starting on a wave boundary; the padding is marked
-			const uint32_t c = tid < (uint32_t)kShadeClasses ? c_cnt[tid] : 0u;
-			const uint32_t padded = (c + 63u) & ~63u;
-			uint32_t incl = padded;
-#pragma unroll
-			for (int d = 1; d < kShadeClasses; d <<= 1) {
-				const uint32_t up = __shfl_up(incl, d);
-				if ((int)lane >= d) incl += up;
-			}
-			const uint32_t start = incl - padded;
-			if (tid < (uint32_t)kShadeClasses) c_pos[tid] = start;
-			if (tid == (uint32_t)kShadeClasses - 1) { s_total = incl; s_cursor = 0; } // (s_total: now the padded length)
-			if (tid < (uint32_t)kShadeClasses) for (uint32_t i = start + c; i < start + padded; i++) order[i] = 0xFFFFu;
-		}
-		__syncthreads();
-		{
-			const unsigned long long below = (1ull << lane) - 1ull;
-#pragma unroll 1
-			for (int k = 0; k < G; k++) { // scatter the slot indices into their class regions
-				const bool has = tid < g_base[k + 1] - g_base[k];
-				const uint32_t key = has ? (uint32_t)(keys >> (4 * k)) & 15u : (uint32_t)kShadeClasses;
-				unsigned long long todo = __ballot(has);
-				while (todo != 0ull) {
-					const int leader = __ffsll((long long)todo) - 1;
-					const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
-					const unsigned long long m = __ballot(key == c);
-					uint32_t at = 0;
-					if ((int)lane == leader) at = atomicAdd(&c_pos[c], (uint32_t)__popcll(m));
-					at = (uint32_t)__builtin_amdgcn_readlane((int)at, leader);
-					if (key == c) order[at + __popcll(m & below)] = (uint16_t)((uint32_t)k << 8 | tid);
-					todo &= ~m;
-				}
-			}
-		}
-		__syncthreads();
-		// ---- shade: a wave draws 64 consecutive sorted rays at a time ---------------------------------------------------
-		const uint32_t padded_total = s_total;
-		for (;;) {
-			uint32_t j = 0;
-			if (lane == 0) j = atomicAdd(&s_cursor, 64u);
-			j = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
-			if (j >= padded_total) break;
-			shade_group_pass<LDS>(ga, order[j + lane], chunk0);
-		}
-		__syncthreads(); // every wave is done with the group
-		if (tid < (uint32_t)G && chunk0 + tid < num_chunks) {
-			cnt_ray[chunk0 + tid] = g_o_cnt[tid][0];
-			cnt_occ[chunk0 + tid] = g_o_cnt[tid][1];
-			wg_stat[chunk0 + tid] = g_o_cnt[tid][2];
-		}
-		if (tid < (uint32_t)G * 8 && chunk0 + tid / 8 < num_chunks) ga->A.emask_out[(size_t)chunk0 * 8 + tid] = (&g_o_emit[0][0])[tid];
-		if (tid == 0) s_group = gridDim.x + atomicAdd(ticket, 1u);
-		__syncthreads(); // (the next group's set-up reuses the LDS words)
-		group = s_group;
 	}
 }
 

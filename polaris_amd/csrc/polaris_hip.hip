@@ -23,8 +23,9 @@
 #include <string>
 #include <vector>
 
+#include <unistd.h>
+
 #include "kernels.h"
-#include "kernels_quad.h"
 #include "polaris_hip.h"
 
 using namespace pol;
@@ -71,8 +72,18 @@ struct polaris_hip_tracer {
 
 	// frame-sized state (buffers.go:127-174)
 	uint32_t W = 0, H = 0;
-	float4 *trace_acc = nullptr, *frame_acc = nullptr;
+	float4 *trace_acc = nullptr, *frame_acc = nullptr; // trace_acc == ring[ring_pos]
 	uchar4 *framebuffer = nullptr;
+	// The trace accumulator as a ring (polaris_hip_ipc_export): with depth > 1 every Trace writes the next slot, so a peer
+	// process may still read frame f's rows while frame f + 1 is traced.  Depth 1 = the reference's single buffer.
+	float4 *ring[POLARIS_IPC_MAX_DEPTH] = {};
+	uint32_t ring_depth = 1, ring_pos = 0;
+	hipEvent_t ev_ipc_done = nullptr; // inter-process event, recorded at the end of every Trace once exported
+	// Events recorded by OTHER handles' merge streams behind their reads of this handle's trace accumulator
+	// (polaris_hip_merge with dst != src): this handle's next Trace waits for them before it clears the rows.
+	struct Reader { hipEvent_t ev; int device; };
+	std::mutex readers_mu;
+	std::vector<Reader> readers, reader_pool;
 
 	// scene (buffers.go:180-201), re-laid out by scene_layout.h
 	bool have_scene = false;
@@ -82,12 +93,7 @@ struct polaris_hip_tracer {
 	int max_stack = 0;
 	int node_mode = kNodesGlobal; // where k_trace reads node records from (kernels.h NodeMode), resolved at upload
 	int opt_node_mode = -1;       // -1 = by scene size
-	// four lanes per ray over the four-wide tree (kernels_quad.h); an A/B alternative to k_trace, off by default
-	Bvh4Dev bvh4{};
-	int quad_stack = 0;  // stack entries the collapsed tree needs (0 = not available)
 	uint32_t tex_bytes = 0; // size of the uploaded texture blob (without its padding)
-	int opt_wide = 0;    // option "wide": 1 = k_trace4 wherever the collapsed tree is available, 0 = k_trace
-	bool wide = false;   // resolved at upload
 	int trace_resident_per_cu = 6, occl_resident_per_cu = 6; // workgroups of the selected k_trace<closest | any hit> variant a CU holds at once (occupancy API, at upload)
 
 	// camera (tracer.go:175-179)
@@ -101,9 +107,6 @@ struct polaris_hip_tracer {
 		hipStream_t q = nullptr;
 		size_t slots = 0; // capacity in slots
 		Streams st{};
-		float4 *alt_o = nullptr, *alt_d = nullptr, *alt_thr = nullptr; // the second set of bounce-ray buffers (launch_batch alternates the two)
-		uint32_t *tickets = nullptr;                                   // one work-queue counter per bounce (k_shade_group), zeroed per batch
-		GroupArgs *group_args = nullptr;                               // k_shade_group's arguments, one record per bounce (k_store_group_args)
 		std::vector<DevBuf> bufs;
 		hipEvent_t done = nullptr; // recorded after the pipe's last resolve
 	};
@@ -132,8 +135,6 @@ struct polaris_hip_tracer {
 	int opt_shade_wgs_per_cu = 4;
 	int opt_shade_wave_from = -1; // first bounce shaded by k_shade_wave; -1 = the bounce AFTER Russian roulette starts thinning the
 	                              // chunks (min_bounces_for_rr + 1: the RR bounce itself still shades dense chunks); earlier bounces use k_shade
-	int opt_shade_group = 0; // 1 = bounce rays shaded class by class across groups of chunks (k_shade_group: fewer vector instructions, more time -- DESIGN.md 3.2), 0 = per chunk (k_shade / k_shade_wave)
-	int shade_group_resident_per_cu = 5; // workgroups of k_shade_group a CU holds at once (occupancy API, at upload)
 	int opt_shade_sort = -1; // first bounce whose rays k_shade groups by shading class; -1 = default (1), POLARIS_MAX_BOUNCES = never
 	int opt_traversal = 1; // 1 = persistent waves with lane refill (k_trace), 0 = one ray per lane (k_intersect/k_occlusion)
 
@@ -144,9 +145,17 @@ struct polaris_hip_tracer {
 	std::vector<hipEvent_t> event_pool;
 	std::map<std::string, KernelTimer> timers;
 	std::map<std::string, std::string> timer_symbol; // timer name -> the kernel symbol it last bracketed (polaris_hip_kernel_symbol)
-	int last_shade_timer[POLARIS_MAX_BOUNCES] = {};            // per bounce of the last Trace: 0 shade_first, 1 shade_sort, 2 shade_plain, 3 shade_wave, 4 shade_group
+	int last_shade_timer[POLARIS_MAX_BOUNCES] = {};            // per bounce of the last Trace: 0 shade_first, 1 shade_sort, 2 shade_plain, 3 shade_wave
 	uint64_t last_shade_counts[3 * POLARIS_MAX_BOUNCES] = {}; // per bounce of the last Trace: shaded hits, shaded misses, emitter hits
 	hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_fork = nullptr;
+};
+
+// Another process's trace accumulator ring, opened through HIP IPC on `owner`'s device.
+struct polaris_hip_peer {
+	polaris_hip_tracer *owner = nullptr;
+	uint32_t depth = 0, W = 0, H = 0;
+	void *mem[POLARIS_IPC_MAX_DEPTH] = {};
+	hipEvent_t ev = nullptr; // the peer's "Trace done" event (null: the exporter had none)
 };
 
 namespace {
@@ -247,6 +256,44 @@ hipError_t join_merges(polaris_hip_tracer *h, hipStream_t q) {
 	return e;
 }
 
+// Whatever other handles' merge streams still read of this handle's trace accumulator happens before what is queued on `q`
+// next (caller holds mu).  The events go back to the pool: a later record simply re-arms them.
+hipError_t wait_readers(polaris_hip_tracer *h, hipStream_t q) {
+	std::lock_guard<std::mutex> lk(h->readers_mu);
+	hipError_t first = hipSuccess;
+	for (auto &r : h->readers) {
+		const hipError_t e = hipStreamWaitEvent(q, r.ev, 0);
+		if (first == hipSuccess) first = e;
+		h->reader_pool.push_back(r);
+	}
+	h->readers.clear();
+	return first;
+}
+
+// An event on `device` (the current device) for a read of src's trace accumulator; recorded by the caller, then handed to src.
+hipEvent_t reader_event(polaris_hip_tracer *src, int device) {
+	std::lock_guard<std::mutex> lk(src->readers_mu);
+	for (size_t i = 0; i < src->reader_pool.size(); i++)
+		if (src->reader_pool[i].device == device) {
+			hipEvent_t e = src->reader_pool[i].ev;
+			src->reader_pool.erase(src->reader_pool.begin() + (long)i);
+			return e;
+		}
+	hipEvent_t e = nullptr;
+	if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+	return e;
+}
+
+void free_ring(polaris_hip_tracer *h) { // caller holds mu + merge_mu, every stream idle
+	for (uint32_t i = 0; i < POLARIS_IPC_MAX_DEPTH; i++) {
+		if (h->ring[i]) (void)hipFree(h->ring[i]);
+		h->ring[i] = nullptr;
+	}
+	h->trace_acc = nullptr;
+	h->ring_depth = 1;
+	h->ring_pos = 0;
+}
+
 hipError_t sync_all(polaris_hip_tracer *h) { // every pipeline of the handle idle (before anything the kernels use is freed)
 	hipError_t first = h->merge_stream ? hipStreamSynchronize(h->merge_stream) : hipSuccess;
 	for (int p = 0; p < polaris_hip_tracer::kMaxPipes; p++)
@@ -259,28 +306,17 @@ hipError_t sync_all(polaris_hip_tracer *h) { // every pipeline of the handle idl
 
 int ensure_streams(polaris_hip_tracer *h, int p, size_t slots, bool want_inst) {
 	polaris_hip_tracer::Pipe &P = h->pipe[p];
-	const bool want_alt = h->opt_shade_group != 0; // the second set of bounce-ray buffers: only k_shade_group writes out of place
-	if (slots <= P.slots && (!want_inst || P.st.hit_inst) && (!want_alt || P.alt_o)) return POLARIS_OK;
+	if (slots <= P.slots && (!want_inst || P.st.hit_inst)) return POLARIS_OK;
 	slots = std::max(slots, P.slots);
 	HIP_TRY(h, hipStreamSynchronize(P.q));
 	free_pool(P.bufs);
 	P.st = Streams{};
-	P.alt_o = P.alt_d = P.alt_thr = nullptr;
-	P.tickets = nullptr;
-	P.group_args = nullptr;
 	P.slots = 0;
 	const size_t wgs = slots / WG;
 	int rc = 0;
 	rc |= dev_alloc(h, P.bufs, &P.st.ray_o, slots);
 	rc |= dev_alloc(h, P.bufs, &P.st.ray_d, slots);
 	rc |= dev_alloc(h, P.bufs, &P.st.thr, slots);
-	if (want_alt) {
-		rc |= dev_alloc(h, P.bufs, &P.alt_o, slots);
-		rc |= dev_alloc(h, P.bufs, &P.alt_d, slots);
-		rc |= dev_alloc(h, P.bufs, &P.alt_thr, slots);
-	}
-	rc |= dev_alloc(h, P.bufs, &P.tickets, (size_t)POLARIS_MAX_BOUNCES);
-	rc |= dev_alloc(h, P.bufs, &P.group_args, (size_t)POLARIS_MAX_BOUNCES);
 	rc |= dev_alloc(h, P.bufs, &P.st.hit, slots);
 	rc |= dev_alloc(h, P.bufs, &P.st.occ_o, slots);
 	rc |= dev_alloc(h, P.bufs, &P.st.occ_d, slots);
@@ -294,7 +330,6 @@ int ensure_streams(polaris_hip_tracer *h, int p, size_t slots, bool want_inst) {
 	rc |= dev_alloc(h, P.bufs, &P.st.emask[1], wgs * 8);
 	if (want_inst) rc |= dev_alloc(h, P.bufs, &P.st.hit_inst, slots);
 	if (rc) { free_pool(P.bufs); P.st = Streams{}; return rc; }
-	P.st.out_o = P.st.ray_o; P.st.out_d = P.st.ray_d; P.st.out_thr = P.st.thr; // (in place unless a caller alternates the sets)
 	P.slots = slots;
 	return POLARIS_OK;
 }
@@ -317,10 +352,6 @@ inline uint32_t grid_for(size_t n) { return (uint32_t)((n + WG - 1) / WG); }
 // (kernels.h, NodeMode).  fn = the kernel (for the occupancy query), block = its workgroup size.
 template <bool ANY_HIT>
 const void *trace_kernel(polaris_hip_tracer *h, int *block) {
-	if (h->wide) { // k_trace4<ANY_HIT, STACK>: one LDS stack column per RAY, so even the 64-entry variant keeps 8 workgroups per CU
-		*block = WG;
-		return h->quad_stack <= 32 ? (const void *)k_trace4<ANY_HIT, 32> : (const void *)k_trace4<ANY_HIT, 64>;
-	}
 	*block = h->node_mode == kNodesLdsAll ? kTinyBlock : WG;
 	if (h->node_mode == kNodesLdsAll) return (const void *)k_trace<ANY_HIT, 16, kNodesLdsAll>;
 	const bool top = h->node_mode == kNodesLdsTop;
@@ -334,18 +365,17 @@ template <bool ANY_HIT>
 std::string trace_symbol(polaris_hip_tracer *h) {
 	char buf[96];
 	const char *a = ANY_HIT ? "true" : "false";
-	if (h->wide) snprintf(buf, sizeof buf, "pol::k_trace4<%s, %d>", a, h->quad_stack <= 32 ? 32 : 64);
-	else if (h->node_mode == kNodesLdsAll) snprintf(buf, sizeof buf, "pol::k_trace<%s, 16, %d>", a, (int)kNodesLdsAll);
+	if (h->node_mode == kNodesLdsAll) snprintf(buf, sizeof buf, "pol::k_trace<%s, 16, %d>", a, (int)kNodesLdsAll);
 	else snprintf(buf, sizeof buf, "pol::k_trace<%s, %d, %d>", a, h->max_stack <= 16 ? 16 : (h->max_stack <= 24 ? 24 : 32), h->node_mode);
 	return buf;
 }
 
 template <bool ANY_HIT>
-void launch_trace(polaris_hip_tracer *h, polaris_hip_tracer::Pipe &P, const Streams &st, uint32_t grid, uint32_t chunks, float4 *acc) {
+hipError_t launch_trace(polaris_hip_tracer *h, polaris_hip_tracer::Pipe &P, const Streams &st, uint32_t grid, uint32_t chunks, float4 *acc) {
 	int block = WG;
 	const void *fn = trace_kernel<ANY_HIT>(h, &block);
-	void *args[] = {(void *)&st, h->wide ? (void *)&h->bvh4 : (void *)&h->bvh, (void *)&chunks, (void *)&acc, (void *)&h->d_stats};
-	(void)hipLaunchKernel(fn, dim3(grid), dim3(block), args, 0, P.q);
+	void *args[] = {(void *)&st, (void *)&h->bvh, (void *)&chunks, (void *)&acc, (void *)&h->d_stats};
+	return hipLaunchKernel(fn, dim3(grid), dim3(block), args, 0, P.q);
 }
 
 // Resident workgroups per CU of the k_trace variant launch_trace<ANY_HIT> picks.
@@ -359,8 +389,12 @@ int trace_occupancy(polaris_hip_tracer *h) {
 }
 
 // One wavefront batch: K samples starting at sample s0, on pipeline p.
-void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, uint32_t s0, uint32_t K, uint32_t N, uint32_t Npad,
-                  bool exact, hipEvent_t resolve_after) {
+// Returns the first launch error of the batch (checked after every batch by the caller: a failed launch in batch 1 is reported
+// before batch 2 is queued behind it).
+hipError_t launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, uint32_t s0, uint32_t K, uint32_t N, uint32_t Npad,
+                        bool exact, hipEvent_t resolve_after) {
+	hipError_t first_err = hipSuccess;
+	auto note = [&](hipError_t e) { if (first_err == hipSuccess && e != hipSuccess) first_err = e; };
 	polaris_hip_tracer::Pipe &P = h->pipe[p];
 	const uint32_t B = r->num_bounces, stride = 1 + B;
 	const uint32_t wgs_per_sample = Npad / WG, wgs = K * wgs_per_sample;
@@ -402,16 +436,8 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 		return std::min<uint32_t>(wgs, (uint32_t)h->num_cus * per_cu);
 	};
 	const uint32_t persistent = grid_of(h->trace_resident_per_cu), persistent_occl = grid_of(h->occl_resident_per_cu);
-	// with k_shade_group, bounce rays alternate between two sets of buffers: the shade step of bounce b reads set b & 1 and
-	// writes the rays it emits to the other one (kernels.h, Streams::out_*)
-	if (h->opt_shade_group) (void)hipMemsetAsync(P.tickets, 0, POLARIS_MAX_BOUNCES * sizeof(uint32_t), q);
-	float4 *const set_o[2] = {P.st.ray_o, P.alt_o}, *const set_d[2] = {P.st.ray_d, P.alt_d}, *const set_t[2] = {P.st.thr, P.alt_thr};
 	for (uint32_t b = 0; b < B; b++) {
 		Streams S = P.st; // (in place: k_shade / k_shade_wave read a chunk's rays before they write into it)
-		if (h->opt_shade_group) { // k_shade_group shades in class order: its outputs go to the other set
-			S.ray_o = set_o[b & 1]; S.ray_d = set_d[b & 1]; S.thr = set_t[b & 1];
-			S.out_o = set_o[(b + 1) & 1]; S.out_d = set_d[(b + 1) & 1]; S.out_thr = set_t[(b + 1) & 1];
-		}
 		{
 			Timed t(h, (b == 0 && h->packet_primary) ? "intersect_packet" : "intersect", q);
 			if (h->opt_time_kernels) {
@@ -421,7 +447,7 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 			if (b == 0 && h->packet_primary)
 				hipLaunchKernelGGL((k_trace_packet<false, true>), dim3(wgs), dim3(WG), 0, q, S, h->bvh, (float4 *)nullptr, h->d_stats, h->cam.eye);
 			else if (h->opt_traversal)
-				launch_trace<false>(h, P, S, persistent, wgs, nullptr);
+				note(launch_trace<false>(h, P, S, persistent, wgs, nullptr));
 			else
 				hipLaunchKernelGGL(k_intersect, dim3(wgs), dim3(WG), 0, q, S, h->bvh);
 		}
@@ -436,30 +462,18 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 			// bounce rays are shaded in the order of their material's shading class (kernels.h, k_shade SORT); camera rays are
 			// coherent as they come (64 neighbouring pixels per wave)
 			const bool sorted = b > 0 && h->scene.tri_bits < 31 && (int)b >= (h->opt_shade_sort >= 0 ? h->opt_shade_sort : 1);
-			// bounce rays: class by class across a group of chunks (k_shade_group) unless switched off; it also serves the sparse bounces
-			const bool grouped = b > 0 && h->opt_shade_group != 0 && h->scene.tri_bits < 31;
-			const int which = grouped ? 4 : (wave ? 3 : (b == 0 ? 0 : (sorted ? 1 : 2)));
-			static const char *const kShadeTimer[5] = {"shade_first", "shade_sort", "shade_plain", "shade_wave", "shade_group"};
+			const int which = wave ? 3 : (b == 0 ? 0 : (sorted ? 1 : 2));
+			static const char *const kShadeTimer[4] = {"shade_first", "shade_sort", "shade_plain", "shade_wave"};
 			h->last_shade_timer[b] = which;
 			Timed t(h, kShadeTimer[which], q);
 			if (h->opt_time_kernels) {
 				const char *l = staged ? "true" : "false";
 				char buf[64];
-				if (grouped) snprintf(buf, sizeof buf, "pol::k_shade_group<%s>", l);
-				else if (wave) snprintf(buf, sizeof buf, "pol::k_shade_wave<%s>", l);
+				if (wave) snprintf(buf, sizeof buf, "pol::k_shade_wave<%s>", l);
 				else snprintf(buf, sizeof buf, "pol::k_shade<%s, %s, %s>", l, which == 1 ? "true" : "false", which == 0 ? "true" : "false");
 				h->timer_symbol[kShadeTimer[which]] = buf;
 			}
-			if (grouped) {
-				// persistent workgroups draw groups of kShadeGroup chunks: no more of them than the GPU holds at once, nor than groups
-				const uint32_t groups = (wgs + kShadeGroup - 1) / kShadeGroup;
-				const uint32_t grid = std::max(1u, std::min<uint32_t>(groups, (uint32_t)h->num_cus * (uint32_t)std::max(1, h->shade_group_resident_per_cu)));
-				uint32_t *ticket = P.tickets + b;
-				GroupArgs *ga = P.group_args + b;
-				hipLaunchKernelGGL(k_store_group_args, dim3(1), dim3(64), 0, q, GroupArgs{S, h->scene, A, h->tex_bytes}, ga);
-				if (staged) hipLaunchKernelGGL(k_shade_group<true>, dim3(grid), dim3(WG), 0, q, (const GroupArgs *)ga, wgs, ticket);
-				else hipLaunchKernelGGL(k_shade_group<false>, dim3(grid), dim3(WG), 0, q, (const GroupArgs *)ga, wgs, ticket);
-			} else if (wave) {
+			if (wave) {
 				// persistent waves pull groups of kSparseGroup chunks: no more workgroups than the GPU holds at once (4 per CU at
 				// the kernel's register count) nor than there are groups for their 4 waves
 				const uint32_t groups = (wgs + kSparseGroup - 1) / kSparseGroup;
@@ -472,7 +486,7 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 				else if (sorted) fn = staged ? (const void *)k_shade<true, true, false> : (const void *)k_shade<false, true, false>;
 				else fn = staged ? (const void *)k_shade<true, false, false> : (const void *)k_shade<false, false, false>;
 				void *args[] = {(void *)&S, (void *)&h->scene, (void *)&A};
-				(void)hipLaunchKernel(fn, dim3(wgs), dim3(WG), args, 0, q);
+				note(hipLaunchKernel(fn, dim3(wgs), dim3(WG), args, 0, q));
 			}
 		}
 		{
@@ -485,18 +499,20 @@ void launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, ui
 			if ((int)b < h->opt_packet_shadow)
 				hipLaunchKernelGGL(k_trace_packet<true>, dim3(wgs), dim3(WG), 0, q, S, h->bvh, A.acc, h->d_stats, h->cam.eye);
 			else if (h->opt_traversal)
-				launch_trace<true>(h, P, S, persistent_occl, wgs, A.acc);
+				note(launch_trace<true>(h, P, S, persistent_occl, wgs, A.acc));
 			else
 				hipLaunchKernelGGL(k_occlusion, dim3(wgs), dim3(WG), 0, q, S, h->bvh, A.acc, h->d_stats);
 		}
 	}
 	if (!exact) {
 		// batches resolve into the trace accumulator in sample order: wait for the previous batch's resolve
-		if (resolve_after) (void)hipStreamWaitEvent(q, resolve_after, 0);
+		if (resolve_after) note(hipStreamWaitEvent(q, resolve_after, 0));
 		Timed t(h, "resolve", q);
 		hipLaunchKernelGGL(k_resolve, dim3(grid_for(N)), dim3(WG), 0, q, P.st.lsum, h->trace_acc, K, N, Npad, r->block_y * h->W);
 	}
-	(void)hipEventRecord(P.done, q);
+	note(hipEventRecord(P.done, q));
+	note(hipGetLastError()); // (launches through hipLaunchKernelGGL report here)
+	return first_err;
 }
 
 } // namespace
@@ -580,7 +596,15 @@ void polaris_hip_destroy(polaris_hip_tracer *h) {
 		for (int p = 1; p < polaris_hip_tracer::kMaxPipes; p++)
 			if (h->pipe[p].q) (void)hipStreamDestroy(h->pipe[p].q);
 		free_pool(h->scene_bufs);
-		if (h->trace_acc) (void)hipFree(h->trace_acc);
+		free_ring(h);
+		if (h->ev_ipc_done) (void)hipEventDestroy(h->ev_ipc_done);
+		{
+			std::lock_guard<std::mutex> lk_r(h->readers_mu);
+			for (auto &r : h->readers) (void)hipEventDestroy(r.ev);
+			for (auto &r : h->reader_pool) (void)hipEventDestroy(r.ev);
+			h->readers.clear();
+			h->reader_pool.clear();
+		}
 		if (h->frame_acc) (void)hipFree(h->frame_acc);
 		if (h->framebuffer) (void)hipFree(h->framebuffer);
 		if (h->d_seeds) (void)hipFree(h->d_seeds);
@@ -617,14 +641,15 @@ int polaris_hip_resize(polaris_hip_tracer *h, uint32_t frame_w, uint32_t frame_h
 	HIP_TRY(h, hipSetDevice(h->device));
 	std::lock_guard<std::mutex> lk_merge(h->merge_mu); // (the frame accumulator is the merge stream's)
 	HIP_TRY(h, sync_all(h));
-	if (h->trace_acc) (void)hipFree(h->trace_acc);
+	free_ring(h); // (an IPC export dies with the buffers: peers close, the tracer exports again)
 	if (h->frame_acc) (void)hipFree(h->frame_acc);
 	if (h->framebuffer) (void)hipFree(h->framebuffer);
-	h->trace_acc = h->frame_acc = nullptr;
+	h->frame_acc = nullptr;
 	h->framebuffer = nullptr;
 	h->W = h->H = 0;
 	const size_t F = (size_t)frame_w * frame_h;
-	HIP_TRY(h, hipMalloc((void **)&h->trace_acc, F * sizeof(float4)));
+	HIP_TRY(h, hipMalloc((void **)&h->ring[0], F * sizeof(float4)));
+	h->trace_acc = h->ring[0];
 	HIP_TRY(h, hipMalloc((void **)&h->frame_acc, F * sizeof(float4)));
 	HIP_TRY(h, hipMalloc((void **)&h->framebuffer, F * sizeof(uchar4)));
 	HIP_TRY(h, hipMemsetAsync(h->trace_acc, 0, F * sizeof(float4), h->stream));
@@ -656,8 +681,7 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 	free_pool(h->scene_bufs);
 	h->have_scene = false;
 	int rc = 0;
-	PairNode *pairs; int2 *leaves; TriRec *tris; InstRec *insts; QuadNode *quads;
-	rc |= dev_upload(h, h->scene_bufs, &quads, L.quads.data(), L.quads.size());
+	PairNode *pairs; int2 *leaves; TriRec *tris; InstRec *insts;
 	rc |= dev_upload(h, h->scene_bufs, &pairs, L.pairs.data(), L.pairs.size());
 	rc |= dev_upload(h, h->scene_bufs, &leaves, L.leaves.data(), L.leaves.size());
 	rc |= dev_upload(h, h->scene_bufs, &tris, L.tris.data(), L.tris.size());
@@ -719,8 +743,6 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 			h->bvh.root_inst.meta = make_int4(I.root_ref, (int)I.rank, (int)I.pad[0], 0);
 		}
 	}
-	h->bvh4 = Bvh4Dev{quads, leaves, tris, insts, L.quad_root_ref, h->bvh.root_is_instance, h->bvh.root_inst};
-	h->quad_stack = L.quad_stack;
 	h->scene = SceneDev{vertices, normals, uvs, mat_index, nodes, emissives, tex_meta, tex_data, sc->num_emissives,
 	                    sc->scene_diffuse_mat_index, sc->num_material_nodes, sc->num_textures, light_geo, sc->num_emissives ? pm_rcp((float)(int)sc->num_emissives) : 0.0f, L.tri_bits};
 	h->max_stack = L.max_stack;
@@ -734,15 +756,6 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 	const bool tiny_ok = L.pairs.size() <= (size_t)kTinyPairs && L.tris.size() <= kTinyMaxIndex && L.leaves.size() <= kTinyMaxIndex && L.max_stack <= 16;
 	h->node_mode = tiny_ok ? kNodesLdsAll : (L.pairs.size() <= (size_t)(POLARIS_LDS_TOP_MAX_PAIRS) ? kNodesLdsTop : kNodesGlobal);
 	if (h->opt_node_mode >= 0 && (h->opt_node_mode != kNodesLdsAll || tiny_ok)) h->node_mode = h->opt_node_mode;
-	// four lanes per ray over the four-wide tree (kernels_quad.h): bit-exact, measured, and slower than one lane per ray on
-	// every scene tried -- so only on request (option "wide" = 1)
-	h->wide = h->quad_stack > 0 && h->opt_wide > 0;
-	{
-		const bool staged_tables = h->opt_stage_lds && sc->num_material_nodes <= kLdsMatNodes && sc->num_emissives <= kLdsLights && sc->num_textures <= kLdsTextures;
-		int n = 0;
-		const void *fn = staged_tables ? (const void *)k_shade_group<true> : (const void *)k_shade_group<false>;
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, WG, 0) == hipSuccess && n >= 1) h->shade_group_resident_per_cu = std::min(n, 8);
-	}
 	h->trace_resident_per_cu = trace_occupancy<false>(h);
 	h->occl_resident_per_cu = trace_occupancy<true>(h);
 	h->have_scene = true;
@@ -773,14 +786,11 @@ int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value
 	else if (k == "packet_shadow") h->opt_packet_shadow = (int)std::max<int64_t>(0, std::min<int64_t>(value, POLARIS_MAX_BOUNCES));
 	else if (k == "time_kernels") h->opt_time_kernels = value != 0;
 	else if (k == "node_mode") h->opt_node_mode = (int)std::max<int64_t>(-1, std::min<int64_t>(value, 2)); // next upload; 2 only where the scene is tiny enough
-	else if (k == "wide") h->opt_wide = value != 0; // next upload
 	else if (k == "traversal") h->opt_traversal = value != 0; // 0 = one ray per lane (k_intersect / k_occlusion), 1 = persistent waves with lane refill (k_trace)
 	else if (k == "shade_wave") h->opt_shade_wave = value != 0;
 	else if (k == "shade_wave_from") h->opt_shade_wave_from = (int)std::max<int64_t>(-1, std::min<int64_t>(value, POLARIS_MAX_BOUNCES));
 	else if (k == "shade_wgs_per_cu") h->opt_shade_wgs_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(value, 64));
 	else if (k == "stage_lds") h->opt_stage_lds = value != 0;
-	else if (k == "shade_group") h->opt_shade_group = value != 0;
-	else if (k == "shade_group_wgs_per_cu") h->shade_group_resident_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(value, 16));
 	else if (k == "shade_sort") h->opt_shade_sort = (int)std::max<int64_t>(-1, std::min<int64_t>(value, POLARIS_MAX_BOUNCES));
 	else if (k == "overlap") h->opt_overlap = (int)std::max<int64_t>(1, std::min<int64_t>(value, polaris_hip_tracer::kMaxPipes));
 	else if (k == "trace_grid") h->opt_trace_grid = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20));
@@ -815,6 +825,10 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 	const uint32_t N = (uint32_t)N64, Npad = (N + WG - 1) / WG * WG;
 
 	HIP_TRY(h, hipSetDevice(h->device));
+	if (h->ring_depth > 1) { // the next slot of the ring: a peer may still be reading the previous frame's rows (polaris_hip_ipc_export)
+		h->ring_pos = (h->ring_pos + 1) % h->ring_depth;
+		h->trace_acc = h->ring[h->ring_pos];
+	}
 	const bool exact = h->opt_exact != 0;
 	uint32_t K = 1;
 	if (!exact) {
@@ -827,7 +841,7 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 		else K = std::min<uint32_t>(std::max<uint32_t>(1u, (uint32_t)((32u << 20) / Npad)), std::max(1u, (spp + 1) / 2));
 		K = std::max<uint32_t>(1u, std::min(K, std::max(spp, 1u)));
 	}
-	// The batch buffers are 128 bytes per path slot (176 with k_shade_group's second set of ray buffers) and up to `overlap`
+	// The batch buffers are 128 bytes per path slot and up to `overlap`
 	// batches are in flight: 4.3 GB per pipeline at 33.5 M slots, nothing on a 288 GB MI355X but not on a smaller or shared device.  K chosen automatically is first clamped by the
 	// free device memory and, if an allocation still fails, halved and retried (a caller-chosen samples_per_batch is kept as it
 	// is: its failure is reported).
@@ -837,9 +851,10 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 			size_t have = 0; // what the pipelines already hold counts as available
 			for (auto &P : h->pipe) have += P.slots * (size_t)192;
 			const size_t pipes = (size_t)std::max(1, std::min(h->opt_overlap, (int)polaris_hip_tracer::kMaxPipes));
-			const size_t per_slot = 192 * std::min<size_t>(pipes, (spp + K - 1) / K);
 			const size_t budget = (free_b + have) / 10 * 9;
-			while (K > 1 && (size_t)K * Npad * per_slot > budget) K = (K + 1) / 2;
+			// (batches in flight = min(overlap, #batches): it grows towards `overlap` as K shrinks, so it is recomputed per step)
+			auto need = [&](uint32_t k) { return (size_t)k * Npad * 192 * std::min<size_t>(pipes, (spp + k - 1) / k); };
+			while (K > 1 && need(K) > budget) K = (K + 1) / 2;
 		}
 	}
 	uint32_t n_batches = 0;
@@ -853,7 +868,7 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 		if (exact || h->opt_samples_per_batch > 0 || K == 1) return rc;
 		(void)hipGetLastError(); // out of memory: release every pipeline's buffers, halve the batch, try again
 		for (auto &P : h->pipe)
-			if (P.q && P.slots) { (void)hipStreamSynchronize(P.q); free_pool(P.bufs); P.st = Streams{}; P.alt_o = P.alt_d = P.alt_thr = nullptr; P.tickets = nullptr; P.group_args = nullptr; P.slots = 0; }
+			if (P.q && P.slots) { (void)hipStreamSynchronize(P.q); free_pool(P.bufs); P.st = Streams{}; P.slots = 0; }
 		K = (K + 1) / 2;
 	}
 	if (need_seeds > h->seeds_cap) {
@@ -874,6 +889,12 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 		}
 		announce.now(); // merges queued from here on land on the cleared accumulator
 	}
+	// A merge that still READS this tracer's trace accumulator (MergeOutput(self) runs on the merge stream; Trace -> MergeOutput(self)
+	// -> Trace without a SyncFramebuffer in between is the progressive loop) must be done before the rows are cleared and
+	// rewritten: a device-side wait, the host does not block.  (A merge queued by ANOTHER handle onto its own merge stream
+	// -- dst != src -- is ordered by the peer-read fence in polaris_hip_merge: src's `readers` event, below.)
+	HIP_TRY(h, join_merges(h, q));
+	HIP_TRY(h, wait_readers(h, q));
 	HIP_TRY(h, hipMemsetAsync(h->trace_acc, 0, F * sizeof(float4), q)); // ClearTraceAccumulator (tracer.go:215)
 	HIP_TRY(h, hipMemsetAsync(h->d_stats, 0, ST_COUNT * sizeof(unsigned long long), q));
 	if (need_seeds) HIP_TRY(h, hipMemcpyAsync(h->d_seeds, seeds, need_seeds * sizeof(uint32_t), hipMemcpyHostToDevice, q));
@@ -890,12 +911,13 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 	uint32_t bi = 0;
 	for (uint32_t s0 = 0; s0 < spp; s0 += K, bi++) {
 		const int p = (int)(bi % (uint32_t)n_pipes), prev = (int)((bi + (uint32_t)n_pipes - 1) % (uint32_t)n_pipes);
-		launch_batch(h, p, r, s0, std::min(K, spp - s0), N, Npad, exact, (n_pipes > 1 && bi > 0) ? h->pipe[prev].done : nullptr);
+		HIP_TRY(h, launch_batch(h, p, r, s0, std::min(K, spp - s0), N, Npad, exact, (n_pipes > 1 && bi > 0) ? h->pipe[prev].done : nullptr));
 	}
 	for (int p = 1; p < n_pipes; p++) HIP_TRY(h, hipStreamWaitEvent(q, h->pipe[p].done, 0)); // join
 	HIP_TRY(h, hipGetLastError());
 	unsigned long long hs[ST_COUNT];
 	HIP_TRY(h, hipMemcpyAsync(hs, h->d_stats, sizeof hs, hipMemcpyDeviceToHost, q));
+	if (h->ev_ipc_done) HIP_TRY(h, hipEventRecord(h->ev_ipc_done, q)); // what a peer process's merge stream waits for (polaris_hip_merge_ipc)
 	HIP_TRY(h, hipEventRecord(h->ev_stop, q));
 	HIP_TRY(h, hipStreamSynchronize(q));
 	drain.armed = false; // the join above made q wait for every pipeline
@@ -930,18 +952,23 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 	return POLARIS_OK;
 }
 
-int polaris_hip_merge(polaris_hip_tracer *dst, polaris_hip_tracer *src, const PolarisBlockRequest *r) {
-	if (!dst || !src) return fail(dst, POLARIS_E_BAD_ARGUMENT, "merge: null tracer handle");
+// MergeOutput, shared by polaris_hip_merge / _merge_slot (a tracer of this process) and polaris_hip_merge_ipc (another
+// process's ring, mapped here).  Everything on dst's merge stream, under dst->merge_mu only.
+static int merge_rows(polaris_hip_tracer *dst, polaris_hip_tracer *src, polaris_hip_peer *peer, int slot, const PolarisBlockRequest *r) {
 	// The source's trace accumulator is complete (its Trace is synchronous and has returned): snapshot what is needed of the
 	// source under ITS lock, briefly.  The destination is touched under merge_mu only -- never under dst->mu, which the
 	// destination's own Trace holds from start to end: a secondary's MergeOutput overlaps the primary's Trace
 	// (renderer/default.go:188-191 calls it from the secondaries' goroutines; Exec1DNoWait, resources.go:119).
-	int src_device;
-	uint32_t src_w, src_h;
-	const float4 *src_acc;
-	{
+	int src_device = dst->device;
+	uint32_t src_w = 0, src_h = 0;
+	const float4 *src_acc = nullptr;
+	bool bad_slot = false;
+	if (src) {
 		std::lock_guard<std::mutex> lk_src(src->mu);
-		src_device = src->device; src_w = src->W; src_h = src->H; src_acc = src->trace_acc;
+		src_device = src->device; src_w = src->W; src_h = src->H;
+		if (slot < 0) src_acc = src->trace_acc;
+		else if ((uint32_t)slot < src->ring_depth) src_acc = src->ring[slot];
+		else bad_slot = true;
 	}
 	std::lock_guard<std::mutex> lk(dst->merge_mu);
 	auto fail_merge = [&](int code, const char *msg) { // (dst->error belongs to dst->mu, which a running Trace holds)
@@ -950,6 +977,13 @@ int polaris_hip_merge(polaris_hip_tracer *dst, polaris_hip_tracer *src, const Po
 		g_thread_error = msg;
 		return code;
 	};
+	if (peer) {
+		if (peer->owner != dst) return fail_merge(POLARIS_E_BAD_ARGUMENT, "merge_ipc: the peer was opened by another tracer");
+		if (slot < 0 || (uint32_t)slot >= peer->depth) bad_slot = true;
+		else src_acc = (const float4 *)peer->mem[slot];
+		src_w = peer->W; src_h = peer->H;
+	}
+	if (bad_slot) return fail_merge(POLARIS_E_BAD_ARGUMENT, "merge: ring slot out of range");
 	if (!r) return fail_merge(POLARIS_E_BAD_ARGUMENT, "block request is null");
 	if (dst->W == 0 || dst->H == 0) return fail_merge(POLARIS_E_BAD_ARGUMENT, "frame dimensions not set (UpdateState FrameDimensions)");
 	if (r->frame_w != dst->W || r->frame_h != dst->H) return fail_merge(POLARIS_E_BAD_ARGUMENT, "merge: request frame does not match the tracer's");
@@ -960,7 +994,8 @@ int polaris_hip_merge(polaris_hip_tracer *dst, polaris_hip_tracer *src, const Po
 	const size_t off = (size_t)r->block_y * dst->W, n = (size_t)r->block_h * dst->W;
 	const float4 *rows = src_acc + off;
 	hipStream_t q = dst->merge_stream;
-	if (src_device != dst->device) {
+	if (peer && peer->ev && hipStreamWaitEvent(q, peer->ev, 0) != hipSuccess) return fail_merge(POLARIS_E_DEVICE, "merge_ipc: waiting for the peer's Trace event failed");
+	if (!peer && src_device != dst->device) {
 		int can = 0;
 		if (hipDeviceCanAccessPeer(&can, dst->device, src_device) != hipSuccess) return fail_merge(POLARIS_E_DEVICE, "merge: hipDeviceCanAccessPeer failed");
 		bool direct = false;
@@ -987,7 +1022,150 @@ int polaris_hip_merge(polaris_hip_tracer *dst, polaris_hip_tracer *src, const Po
 		hipLaunchKernelGGL(k_aggregate, dim3(grid_for(n)), dim3(WG), 0, q, rows, dst->frame_acc + off, (uint32_t)n);
 	}
 	if (hipGetLastError() != hipSuccess) return fail_merge(POLARIS_E_DEVICE, "merge: kernel launch failed");
+	// src's next Trace clears and rewrites the rows just queued for reading: it waits (on the device) for this event.  With
+	// src == dst the merge stream itself is joined by Trace (join_merges).
+	if (src && src != dst && slot < 0) {
+		hipEvent_t e = reader_event(src, dst->device);
+		if (!e || hipEventRecord(e, q) != hipSuccess) { // cannot fence on the device: finish the read now
+			(void)hipGetLastError();
+			if (e) (void)hipEventDestroy(e);
+			if (hipStreamSynchronize(q) != hipSuccess) return fail_merge(POLARIS_E_DEVICE, "merge: hipStreamSynchronize failed");
+		} else {
+			std::lock_guard<std::mutex> lk_r(src->readers_mu);
+			src->readers.push_back({e, dst->device});
+		}
+	}
 	return POLARIS_OK; // asynchronous like Exec1DNoWait (resources.go:119); completed by sync_framebuffer
+}
+
+int polaris_hip_merge(polaris_hip_tracer *dst, polaris_hip_tracer *src, const PolarisBlockRequest *r) {
+	if (!dst || !src) return fail(dst, POLARIS_E_BAD_ARGUMENT, "merge: null tracer handle");
+	return merge_rows(dst, src, nullptr, -1, r);
+}
+
+int polaris_hip_merge_slot(polaris_hip_tracer *dst, polaris_hip_tracer *src, uint32_t slot, const PolarisBlockRequest *r) {
+	if (!dst || !src) return fail(dst, POLARIS_E_BAD_ARGUMENT, "merge_slot: null tracer handle");
+	if (slot >= POLARIS_IPC_MAX_DEPTH) return fail(dst, POLARIS_E_BAD_ARGUMENT, "merge_slot: ring slot out of range");
+	return merge_rows(dst, src, nullptr, (int)slot, r);
+}
+
+int polaris_hip_merge_ipc(polaris_hip_tracer *dst, polaris_hip_peer *peer, uint32_t slot, const PolarisBlockRequest *r) {
+	if (!dst || !peer) return fail(dst, POLARIS_E_BAD_ARGUMENT, "merge_ipc: null handle");
+	if (slot >= POLARIS_IPC_MAX_DEPTH) return fail(dst, POLARIS_E_BAD_ARGUMENT, "merge_ipc: ring slot out of range");
+	return merge_rows(dst, nullptr, peer, (int)slot, r);
+}
+
+int polaris_hip_trace_slot(polaris_hip_tracer *h, uint32_t *slot) {
+	if (!h || !slot) return fail(h, POLARIS_E_BAD_ARGUMENT, "trace_slot: null argument");
+	std::lock_guard<std::mutex> lk(h->mu);
+	*slot = h->ring_pos;
+	return POLARIS_OK;
+}
+
+// The trace accumulator becomes a ring of `depth` IPC-exportable buffers; `out` = what a peer process needs to map them.
+int polaris_hip_ipc_export(polaris_hip_tracer *h, uint32_t depth, PolarisIpcExport *out) {
+	if (!h) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "handle is null");
+	std::lock_guard<std::mutex> lk(h->mu);
+	if (!out) return fail(h, POLARIS_E_BAD_ARGUMENT, "ipc_export: out is null");
+	if (depth < 1 || depth > POLARIS_IPC_MAX_DEPTH) return fail(h, POLARIS_E_BAD_ARGUMENT, "ipc_export: depth must be 1..%d", POLARIS_IPC_MAX_DEPTH);
+	if (h->W == 0 || h->H == 0 || !h->ring[0]) return fail(h, POLARIS_E_BAD_ARGUMENT, "frame dimensions not set (UpdateState FrameDimensions)");
+	static_assert(sizeof(hipIpcMemHandle_t) == 64 && sizeof(hipIpcEventHandle_t) == 64, "PolarisIpcExport holds 64-byte handles");
+	HIP_TRY(h, hipSetDevice(h->device));
+	std::lock_guard<std::mutex> lk_merge(h->merge_mu);
+	HIP_TRY(h, sync_all(h));
+	const size_t F = (size_t)h->W * h->H;
+	for (uint32_t i = 0; i < POLARIS_IPC_MAX_DEPTH; i++) { // grow or shrink the ring to `depth` slots (slot 0 always exists)
+		if (i < depth && !h->ring[i]) {
+			HIP_TRY(h, hipMalloc((void **)&h->ring[i], F * sizeof(float4)));
+			HIP_TRY(h, hipMemsetAsync(h->ring[i], 0, F * sizeof(float4), h->stream));
+		} else if (i >= depth && h->ring[i]) {
+			(void)hipFree(h->ring[i]);
+			h->ring[i] = nullptr;
+		}
+	}
+	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	h->ring_depth = depth;
+	h->ring_pos = h->ring_pos % depth;
+	h->trace_acc = h->ring[h->ring_pos];
+	memset(out, 0, sizeof *out);
+	out->abi_version = POLARIS_HIP_ABI_VERSION; out->depth = depth; out->frame_w = h->W; out->frame_h = h->H;
+	out->device = h->device; out->pid = (uint32_t)getpid();
+	for (uint32_t i = 0; i < depth; i++) {
+		hipIpcMemHandle_t mh;
+		HIP_TRY(h, hipIpcGetMemHandle(&mh, h->ring[i]));
+		memcpy(out->mem[i], &mh, 64);
+	}
+	// the "Trace done" event: optional (a runtime that cannot export events still has the host-side ordering: Trace is synchronous)
+	if (!h->ev_ipc_done) {
+		hipEvent_t e = nullptr;
+		if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventInterprocess) == hipSuccess) h->ev_ipc_done = e;
+		else (void)hipGetLastError();
+	}
+	if (h->ev_ipc_done) {
+		hipIpcEventHandle_t eh;
+		if (hipEventRecord(h->ev_ipc_done, h->stream) == hipSuccess && hipStreamSynchronize(h->stream) == hipSuccess &&
+		    hipIpcGetEventHandle(&eh, h->ev_ipc_done) == hipSuccess) {
+			memcpy(out->event, &eh, 64);
+			out->has_event = 1;
+		} else {
+			(void)hipGetLastError();
+			(void)hipEventDestroy(h->ev_ipc_done);
+			h->ev_ipc_done = nullptr;
+		}
+	}
+	return POLARIS_OK;
+}
+
+int polaris_hip_ipc_open(polaris_hip_tracer *dst, const PolarisIpcExport *x, polaris_hip_peer **out) {
+	if (!dst) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "handle is null");
+	std::lock_guard<std::mutex> lk(dst->mu);
+	if (!x || !out) return fail(dst, POLARIS_E_BAD_ARGUMENT, "ipc_open: null argument");
+	*out = nullptr;
+	if (x->abi_version != POLARIS_HIP_ABI_VERSION) return fail(dst, POLARIS_E_BAD_ARGUMENT, "ipc_open: the export was made by ABI version %u, this library is %d", x->abi_version, POLARIS_HIP_ABI_VERSION);
+	if (x->depth < 1 || x->depth > POLARIS_IPC_MAX_DEPTH) return fail(dst, POLARIS_E_BAD_ARGUMENT, "ipc_open: bad ring depth %u", x->depth);
+	if (x->frame_w != dst->W || x->frame_h != dst->H || dst->W == 0) return fail(dst, POLARIS_E_BAD_ARGUMENT, "ipc_open: the peer's frame %ux%u does not match the tracer's %ux%u", x->frame_w, x->frame_h, dst->W, dst->H);
+	if (x->pid == (uint32_t)getpid()) return fail(dst, POLARIS_E_UNSUPPORTED, "ipc_open: the export comes from this process (HIP cannot open its own IPC handle): use polaris_hip_merge / polaris_hip_merge_slot");
+	HIP_TRY(dst, hipSetDevice(dst->device));
+	polaris_hip_peer *p = new polaris_hip_peer();
+	p->owner = dst; p->depth = x->depth; p->W = x->frame_w; p->H = x->frame_h;
+	auto undo = [&]() {
+		for (uint32_t i = 0; i < POLARIS_IPC_MAX_DEPTH; i++)
+			if (p->mem[i]) (void)hipIpcCloseMemHandle(p->mem[i]);
+		if (p->ev) (void)hipEventDestroy(p->ev);
+		delete p;
+		(void)hipGetLastError();
+	};
+	for (uint32_t i = 0; i < x->depth; i++) {
+		hipIpcMemHandle_t mh;
+		memcpy(&mh, x->mem[i], 64);
+		const hipError_t e = hipIpcOpenMemHandle(&p->mem[i], mh, hipIpcMemLazyEnablePeerAccess);
+		if (e != hipSuccess) {
+			p->mem[i] = nullptr;
+			undo();
+			return fail(dst, POLARIS_E_UNSUPPORTED, "ipc_open: hipIpcOpenMemHandle (slot %u, peer pid %u device %d): %s", i, x->pid, x->device, hipGetErrorString(e));
+		}
+	}
+	if (x->has_event) { // optional: without it the host message that follows the peer's synchronous Trace is the only ordering
+		hipIpcEventHandle_t eh;
+		memcpy(&eh, x->event, 64);
+		if (hipIpcOpenEventHandle(&p->ev, eh) != hipSuccess) { p->ev = nullptr; (void)hipGetLastError(); }
+	}
+	*out = p;
+	return POLARIS_OK;
+}
+
+int polaris_hip_ipc_close(polaris_hip_tracer *dst, polaris_hip_peer *p) {
+	if (!dst || !p) return fail(dst, POLARIS_E_BAD_ARGUMENT, "ipc_close: null argument");
+	if (p->owner != dst) return fail(dst, POLARIS_E_BAD_ARGUMENT, "ipc_close: the peer was opened by another tracer");
+	std::lock_guard<std::mutex> lk(dst->merge_mu);
+	(void)hipSetDevice(dst->device);
+	(void)hipStreamSynchronize(dst->merge_stream); // a merge may still be reading the mapping
+	for (uint32_t i = 0; i < POLARIS_IPC_MAX_DEPTH; i++)
+		if (p->mem[i]) (void)hipIpcCloseMemHandle(p->mem[i]);
+	if (p->ev) (void)hipEventDestroy(p->ev);
+	(void)hipGetLastError();
+	delete p;
+	return POLARIS_OK;
 }
 
 int polaris_hip_export_block(polaris_hip_tracer *h, const PolarisBlockRequest *r, void *device_dst) {
@@ -1202,11 +1380,11 @@ int polaris_hip_probe_intersect(polaris_hip_tracer *h, const float *rays, uint32
 		// probes through the wave-packet kernel instead
 		if (any_hit) {
 			if (h->opt_packet_shadow > 0) hipLaunchKernelGGL(k_trace_packet<true>, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, P.st.lsum, h->d_stats, h->cam.eye);
-			else if (h->opt_traversal) launch_trace<true>(h, P, P.st, std::min<uint32_t>(wgs, (uint32_t)h->num_cus * (uint32_t)std::max(1, h->occl_resident_per_cu)), wgs, P.st.lsum);
+			else if (h->opt_traversal) (void)launch_trace<true>(h, P, P.st, std::min<uint32_t>(wgs, (uint32_t)h->num_cus * (uint32_t)std::max(1, h->occl_resident_per_cu)), wgs, P.st.lsum);
 			else hipLaunchKernelGGL(k_occlusion, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, P.st.lsum, h->d_stats);
 		} else {
 			if (h->opt_packet_primary == 1) hipLaunchKernelGGL(k_trace_packet<false>, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh, (float4 *)nullptr, h->d_stats, h->cam.eye);
-			else if (h->opt_traversal) launch_trace<false>(h, P, P.st, std::min<uint32_t>(wgs, (uint32_t)h->num_cus * (uint32_t)std::max(1, h->trace_resident_per_cu)), wgs, nullptr);
+			else if (h->opt_traversal) (void)launch_trace<false>(h, P, P.st, std::min<uint32_t>(wgs, (uint32_t)h->num_cus * (uint32_t)std::max(1, h->trace_resident_per_cu)), wgs, nullptr);
 			else hipLaunchKernelGGL(k_intersect, dim3(wgs), dim3(WG), 0, q, P.st, h->bvh);
 		}
 		e = hipGetLastError();

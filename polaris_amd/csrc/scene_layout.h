@@ -41,13 +41,7 @@ struct PairNodeH { float lo0[3]; int32_t ref0; float hi0[3]; int32_t pad0; float
 struct LeafInfoH { int32_t ldata, rdata; };
 struct TriH { float v0[3]; uint32_t rank; float e1[3]; uint32_t orig; float e2[3]; uint32_t pad2; };
 struct InstH { float r0[4], r1[4], r2[4]; int32_t root_ref; uint32_t rank; uint32_t pad[2]; };
-// Four-wide nodes for the quad-ray kernel (kernels_quad.h, k_trace4): child-major, so that lane p of a quad of lanes reads
-// child p's 32 bytes and the four lanes together read ONE 128-byte line.  An unused slot holds a NaN box (never hit).
-struct QuadChildH { float lo[3]; int32_t ref; float hi[3]; float cull; };
-struct QuadNodeH { QuadChildH c[4]; };
-static_assert(sizeof(PairNodeH) == 64 && sizeof(TriH) == 48 && sizeof(InstH) == 64 && sizeof(QuadNodeH) == 128, "layout");
-constexpr int32_t kQuadEmptyRef = (int32_t)0x80000002; // ref word of an unused child slot (never followed: its box is NaN)
-constexpr int kQuadStackMax = 64; // entries per ray the widest k_trace4 variant holds
+static_assert(sizeof(PairNodeH) == 64 && sizeof(TriH) == 48 && sizeof(InstH) == 64, "layout");
 
 constexpr float kCullMargin = 1.001f; // a subtree is skipped when its box starts beyond kCullMargin x the best hit distance
 constexpr float kSplitCost = 1.0f;  // cost of one added pair-of-boxes step, in triangle tests (leaf subdivision)
@@ -67,144 +61,7 @@ struct SceneLayout {
 	// triangles, else 31 = no class).  The traversal kernels hand the word through to the hit record untouched; k_shade
 	// sorts a workgroup's rays by the class and masks it off.
 	uint32_t tri_bits = 31;
-	// The same tree with (up to) four children per node: `quads` replaces `pairs` for the quad-ray kernel, refs >= 0 index
-	// `quads`, leaf codes are the pair tree's.  quad_stack = 0: not available (a scene whose collapsed tree needs more than
-	// kQuadStackMax entries; the pair kernels serve it).
-	std::vector<QuadNodeH> quads;
-	int32_t quad_root_ref = 0;
-	std::vector<int32_t> inst_quad_root; // per mesh instance
-	int quad_stack = 0;
-	uint32_t quad_children = 0;          // used child slots over all quads (statistics: / quads.size() = average width)
 };
-
-// Collapse the pair tree two levels at a time.
-//
-// A quad node is made for a pair node X; a child C of X that is itself an inner node is REPLACED by its own two children --
-// its box is then never tested -- wherever that cannot change which leaves a ray reaches, until the node's four slots are used.  The reference visits
-// a grandchild G of X iff the ray passes C's slab test AND G's (intersect.cl:296-328); testing G alone is the same thing when
-// hit(G) implies hit(C) for every ray.  The slab test (kernels.h slab_hit_hw: t = (bound - o) * inv per axis, min / max that
-// ignore a NaN, `minmax >= 0 && maxmin <= minmax && maxmin < maxDist`) is monotone in the bounds -- float subtraction and
-// multiplication are monotone, so a box that contains G in float yields per-axis intervals that contain G's -- with ONE
-// exception: an axis on which the ray runs exactly parallel (inv = +-inf) from a point exactly ON a face (bound - o = 0)
-// gives 0 * inf = NaN, which min / max drop.  G flat on that axis (lo = hi = the ray's coordinate) then ignores the axis
-// while a C with just one face on that plane rejects the ray.  So a child is expanded only if, on every axis,
-//     C.lo <= G.lo <= G.hi <= C.hi       (containment in float; also rejects NaN and inverted boxes), and
-//     G.lo == G.hi  implies  C.lo == C.hi  or  C.lo < G.lo && G.hi < C.hi    (a flat G: C flat too, or strictly around it)
-// for both grandchildren.  (Vertex coordinates and ray origins are finite and bounded, so bound - o never overflows and
-// inv is never 0 or NaN: no other NaN source exists.)  Distance culling is per box and conservative by itself: every child
-// slot keeps its own cull factor.  tests/test_scene_layout.py checks the collapsed tree against the oracle's
-// rayIntersectionQuery / rayIntersectionTest on random, axis-parallel and on-the-face rays.
-inline void build_quads(SceneLayout &L) {
-	L.quads.clear();
-	L.inst_quad_root.assign(L.insts.size(), 0);
-	L.quad_stack = 0;
-	L.quad_children = 0;
-	const size_t np = L.pairs.size();
-	std::vector<int32_t> quad_of(np, -1), order;
-	auto want = [&](int32_t ref) -> int32_t { // quad index of an inner pair node (assigned breadth-first); leaf codes pass through
-		if (ref < 0) return ref;
-		if (quad_of[ref] < 0) { quad_of[ref] = (int32_t)order.size(); order.push_back(ref); }
-		return quad_of[ref];
-	};
-	auto cull_of = [](int32_t pad) { float f; memcpy(&f, &pad, 4); return f; };
-	auto expandable = [](const float *Clo, const float *Chi, const PairNodeH &G) {
-		const float *glo[2] = {G.lo0, G.lo1}, *ghi[2] = {G.hi0, G.hi1};
-		for (int k = 0; k < 2; k++)
-			for (int a = 0; a < 3; a++) {
-				const float l = glo[k][a], h = ghi[k][a], Lo = Clo[a], Hi = Chi[a];
-				if (!(Lo <= l && l <= h && h <= Hi)) return false;
-				if (l == h && !(Lo == Hi || (Lo < l && h < Hi))) return false;
-			}
-		return true;
-	};
-	L.quad_root_ref = want(L.root_ref);
-	for (size_t i = 0; i < L.insts.size(); i++) {
-		L.inst_quad_root[i] = want(L.insts[i].root_ref);
-		L.insts[i].pad[0] = (uint32_t)L.inst_quad_root[i]; // InstRec.meta.z on the device
-	}
-	const float nan = std::numeric_limits<float>::quiet_NaN();
-	for (size_t head = 0; head < order.size(); head++) {
-		const PairNodeH X = L.pairs[order[head]];
-		QuadNodeH q;
-		for (auto &c : q.c) { c.lo[0] = c.lo[1] = c.lo[2] = c.hi[0] = c.hi[1] = c.hi[2] = nan; c.ref = kQuadEmptyRef; c.cull = kCullMargin; }
-		// slots in depth-first order: X's two children, then -- while a slot is free -- the expandable inner slot with the
-		// largest box is replaced, in place, by its own two children (so a node may reach three levels down; the rule above is
-		// transitive: hit(G) => hit(C) => hit(C's parent))
-		QuadChildH e[4];
-		int n = 0;
-		auto put = [&](int at, const float *lo, const float *hi, int32_t ref, float cull) {
-			memcpy(e[at].lo, lo, 12); memcpy(e[at].hi, hi, 12);
-			e[at].ref = ref; e[at].cull = cull;
-		};
-		put(n++, X.lo0, X.hi0, X.ref0, cull_of(X.pad0));
-		put(n++, X.lo1, X.hi1, X.ref1, cull_of(X.pad1));
-		while (n < 4) {
-			int best = -1;
-			float best_area = -1.0f;
-			for (int k = 0; k < n; k++) {
-				if (e[k].ref < 0 || !expandable(e[k].lo, e[k].hi, L.pairs[e[k].ref])) continue;
-				const float dx = e[k].hi[0] - e[k].lo[0], dy = e[k].hi[1] - e[k].lo[1], dz = e[k].hi[2] - e[k].lo[2];
-				const float area = dx * dy + dy * dz + dz * dx;
-				if (best < 0 || area > best_area) { best = k; best_area = area; }
-			}
-			if (best < 0) break;
-			const PairNodeH &G = L.pairs[e[best].ref];
-			for (int k = n; k > best + 1; k--) e[k] = e[k - 1]; // make room behind `best`
-			n++;
-			put(best, G.lo0, G.hi0, G.ref0, cull_of(G.pad0));
-			put(best + 1, G.lo1, G.hi1, G.ref1, cull_of(G.pad1));
-		}
-		for (int k = 0; k < n; k++) q.c[k] = e[k];
-		for (int k = 0; k < n; k++) q.c[k].ref = want(q.c[k].ref); // (after the node's own slots are final: breadth-first numbering)
-		L.quad_children += (uint32_t)n;
-		L.quads.push_back(q);
-	}
-	if (L.quads.empty()) { // never an empty device array
-		QuadNodeH q;
-		for (auto &c : q.c) { c.lo[0] = c.lo[1] = c.lo[2] = c.hi[0] = c.hi[1] = c.hi[2] = nan; c.ref = kQuadEmptyRef; c.cull = kCullMargin; }
-		L.quads.push_back(q);
-	}
-	// stack entries a ray can hold: while it is inside child i of a node, the node's other used slots may all be pending
-	std::vector<int> need_q(L.quads.size(), -1);
-	std::vector<std::pair<int32_t, int>> st;
-	auto need_ref = [&](int32_t ref, bool &ready) -> int { // of a child reference; ready = false when a quad below is not computed yet
-		if (ref >= 0) { if (need_q[ref] < 0) { ready = false; st.push_back({ref, 0}); return 0; } return need_q[ref]; }
-		const uint32_t code = (uint32_t)~ref;
-		if (code & 15u) return 0;
-		const LeafInfoH &li = L.leaves[code >> 4];
-		if (li.rdata != 0) return 0; // a triangle leaf of more than 15 triangles
-		const int32_t r = L.inst_quad_root[(size_t)(-(int64_t)li.ldata)];
-		if (r >= 0 && need_q[r] < 0) { ready = false; st.push_back({r, 0}); return 0; }
-		return 1 + (r >= 0 ? need_q[r] : 0); // the exit marker + the mesh tree
-	};
-	auto need_tree = [&](int32_t root) -> int {
-		if (root < 0) { bool ready = true; return need_ref(root, ready); }
-		st.clear();
-		st.push_back({root, 0});
-		while (!st.empty()) {
-			const int32_t qi = st.back().first;
-			if (need_q[qi] >= 0) { st.pop_back(); continue; }
-			const QuadNodeH &q = L.quads[qi];
-			bool ready = true;
-			int n = 0, deepest = 0;
-			for (int k = 0; k < 4; k++) {
-				if (q.c[k].ref == kQuadEmptyRef) continue;
-				n++;
-				const int d = need_ref(q.c[k].ref, ready);
-				if (d > deepest) deepest = d;
-			}
-			if (!ready) continue; // children were pushed: come back after them
-			need_q[qi] = (n > 0 ? n - 1 : 0) + deepest;
-			st.pop_back();
-		}
-		return need_q[root];
-	};
-	for (size_t i = 0; i < L.insts.size(); i++) (void)need_tree(L.inst_quad_root[i]);
-	int need = 0;
-	if (L.quad_root_ref >= 0) need = need_tree(L.quad_root_ref);
-	else { bool ready = true; need = need_ref(L.quad_root_ref, ready); }
-	L.quad_stack = need + 1 <= kQuadStackMax ? need + 1 : 0;
-}
 
 // Shading class of every material node = which BxDF leaves and texture operators the tree rooted at it can reach.  k_shade
 // groups the rays of a workgroup by the class of the triangle's material root before shading them (rays of one class run
@@ -795,7 +652,6 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out, in
 		d.rank = tri_rank[t] == 0xFFFFFFFFu ? t : tri_rank[t];
 		d.orig = out.tri_bits < 31 ? (t | (uint32_t)node_class[sc.material_index[t]] << out.tri_bits) : t;
 	}
-	build_quads(out);
 	return "";
 }
 

@@ -89,6 +89,22 @@ class TraceStats(C.Structure):
         return d
 
 
+IPC_MAX_DEPTH = 4
+
+
+class IpcExport(C.Structure):
+    """PolarisIpcExport (include/polaris_hip.h): what a tracer publishes once so that another PROCESS can map its trace
+    accumulator ring.  Plain bytes: bytes(export) travels over any channel, IpcExport.from_buffer_copy(b) restores it."""
+    _fields_ = [
+        ("abi_version", C.c_uint32), ("depth", C.c_uint32), ("frame_w", C.c_uint32), ("frame_h", C.c_uint32),
+        ("device", C.c_int32), ("pid", C.c_uint32), ("has_event", C.c_uint32), ("reserved", C.c_uint32),
+        ("mem", (C.c_uint8 * 64) * IPC_MAX_DEPTH), ("event", C.c_uint8 * 64),
+    ]
+
+
+assert C.sizeof(IpcExport) == 32 + 64 * IPC_MAX_DEPTH + 64
+
+
 def _ptr(a):
     return None if a is None or a.size == 0 else a.ctypes.data_as(C.c_void_p)
 
@@ -119,6 +135,8 @@ C_ABI_SYMBOLS = [
     "polaris_hip_kernel_ms", "polaris_hip_reset_frame", "polaris_hip_probe", "polaris_hip_probe_intersect",
     "polaris_hip_selftest_rcp", "polaris_hip_reset_epoch", "polaris_hip_wait_reset",
     "polaris_hip_kernel_symbol", "polaris_hip_shade_counts",
+    "polaris_hip_ipc_export", "polaris_hip_ipc_open", "polaris_hip_ipc_close", "polaris_hip_merge_ipc",
+    "polaris_hip_trace_slot", "polaris_hip_merge_slot",
 ]
 
 _lib = None
@@ -202,6 +220,12 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.polaris_hip_kernel_symbol.argtypes = [vp, C.c_char_p, C.c_char_p]
     lib.polaris_hip_shade_counts.argtypes = [vp, C.POINTER(C.c_uint64), C.c_size_t]
     lib.polaris_hip_kernel_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    lib.polaris_hip_ipc_export.argtypes = [vp, u32, C.POINTER(IpcExport)]
+    lib.polaris_hip_ipc_open.argtypes = [vp, C.POINTER(IpcExport), C.POINTER(vp)]
+    lib.polaris_hip_ipc_close.argtypes = [vp, vp]
+    lib.polaris_hip_merge_ipc.argtypes = [vp, vp, u32, C.POINTER(BlockRequest)]
+    lib.polaris_hip_trace_slot.argtypes = [vp, C.POINTER(u32)]
+    lib.polaris_hip_merge_slot.argtypes = [vp, vp, u32, C.POINTER(BlockRequest)]
     for name in C_ABI_SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ("polaris_hip_device_count", "polaris_hip_abi_version"):

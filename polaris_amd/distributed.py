@@ -2,11 +2,19 @@
 
 The reference renders a frame on N devices inside one process: `Schedule` -> one worker per tracer
 `Trace`s its row block -> `primary.MergeOutput(tracer)` (renderer/default.go:106-196,
-tracer/opencl/resources.go:108-124).  Under the driver's launch contract every GPU has its own
-process, so the single exchange step of the path -- the blocks' accumulator strips travelling to
-the primary -- is a set of `torch.distributed` point-to-point transfers (backend nccl = RCCL on the GPU
-box, gloo in the CPU tests): every rank sends exactly its rows, the primary receives them at their place
-in the frame.  There is no other data-path transfer; the scheduler feedback below is 16 bytes per rank.
+tracer/opencl/resources.go:108-124); all devices share ONE OpenCL context, so the primary's
+aggregateAccumulator kernel reads a secondary's traceAccumulator directly (renderer/default.go:225-229,
+tracer/opencl/tracer.go:279-286).  Under the driver's launch contract every GPU has its own process.
+
+`PeerExchange` (the default) is that same read across processes: every rank publishes HIP-IPC handles of
+its trace accumulator ring ONCE (polaris_hip_ipc_export), the primary maps them (polaris_hip_ipc_open), and
+per frame its merge stream runs k_aggregate straight over the peer-mapped rows (polaris_hip_merge_ipc: an
+xGMI peer read; no copy, no staging strip, no RCCL).  torch.distributed carries CONTROL only: the
+handles at set-up and 32 bytes per rank and frame (frame number, ring slot, rows, time) over gloo.
+
+`StripExchange` + `SchedulerFeedback` are the fallback when an IPC mapping cannot be opened: the strips
+travel as `torch.distributed` point-to-point transfers (backend nccl = RCCL, gloo in the CPU tests): every
+rank sends exactly its rows, the primary receives them at their place in the frame.
 
 `StripExchange` keeps the transfers OFF the critical path: `post()` starts those of frame i
 asynchronously and returns at once, so every rank goes straight on to trace frame i + 1; `wait()`
@@ -45,11 +53,11 @@ class StripExchange:
     (gloo cannot move device tensors): test mode for ranks sharing one GPU.
     """
 
-    def __init__(self, dist, rank: int, world: int, frame_w: int, frame_h: int, device, dst: int = 0, via_host: bool = False, depth: int = 2):
+    def __init__(self, dist, rank: int, world: int, frame_w: int, frame_h: int, device, dst: int = 0, via_host: bool = False, depth: int = 2, group=None):
         import torch
 
         self.dist, self.rank, self.world, self.W, self.H, self.dst = dist, rank, world, frame_w, frame_h, dst
-        self.via_host = via_host
+        self.via_host, self.group = via_host, group  # group: the process group the strips travel on (None = the default one)
         n = frame_h * frame_w
         # dst: whole frames.  Elsewhere: one strip -- sized for the whole frame too, because the scheduler, not this class,
         # decides how many rows a rank gets (16 bytes per pixel: 4 MB at 512 x 512)
@@ -86,10 +94,10 @@ class StripExchange:
             yy = 0
             for r in range(self.world):
                 if r != self.dst:
-                    ops.append(self.dist.P2POp(self.dist.irecv, wire[yy * W:(yy + rows[r]) * W], r))
+                    ops.append(self.dist.P2POp(self.dist.irecv, wire[yy * W:(yy + rows[r]) * W], r, group=self.group))
                 yy += rows[r]
         else:
-            ops.append(self.dist.P2POp(self.dist.isend, wire[: rows[self.rank] * W], self.dst))
+            ops.append(self.dist.P2POp(self.dist.isend, wire[: rows[self.rank] * W], self.dst, group=self.group))
         works = self.dist.batch_isend_irecv(ops)  # (nccl: one grouped launch; gloo: the individual operations)
         return (i, works, rows)
 
@@ -124,12 +132,12 @@ class SchedulerFeedback:
     the same rows without a synchronous step.  Frame f + 2 is scheduled from frame f's times; the first two frames use the
     naive split (the scheduler's own first frame, scheduler.go:52-56)."""
 
-    def __init__(self, dist, rank: int, world: int, frame_h: int, device, kind: str = "perfect"):
+    def __init__(self, dist, rank: int, world: int, frame_h: int, device, kind: str = "perfect", group=None):
         import torch
 
         from . import host_api
 
-        self.dist, self.rank, self.world, self.H, self.kind = dist, rank, world, frame_h, kind
+        self.dist, self.rank, self.world, self.H, self.kind, self.group = dist, rank, world, frame_h, kind, group
         self.rows = naive_rows(world, frame_h)
         self._sched = None
         if kind == "perfect" and world > 1:
@@ -147,10 +155,10 @@ class SchedulerFeedback:
         mine = t.tensor([int(rows[self.rank]), int(trace_ms * 1e6)], dtype=t.int64, device=self._dev)
         if mine.is_cuda:  # nccl: one output tensor, so that reading the result back is ONE device-to-host copy
             out = t.zeros((self.world, 2), dtype=t.int64, device=self._dev)
-            work = self.dist.all_gather_into_tensor(out, mine, async_op=True)
+            work = self.dist.all_gather_into_tensor(out, mine, group=self.group, async_op=True)
         else:             # gloo (tests)
             out = [t.zeros(2, dtype=t.int64) for _ in range(self.world)]
-            work = self.dist.all_gather(out, mine, async_op=True)
+            work = self.dist.all_gather(out, mine, group=self.group, async_op=True)
         self._pending.append((work, out, mine))
 
     def next_rows(self):
@@ -168,3 +176,144 @@ class SchedulerFeedback:
         for work, out, _ in self._pending:
             work.wait()
         self._pending = []
+
+
+class PeerExchange:
+    """Row blocks merged into the primary by PEER READS of every rank's trace accumulator, one frame behind the tracing.
+
+    `port` is the tracer side (bench.py: HipPort over the C ABI; the CPU test: a shared-memory stand-in):
+        export(depth) -> bytes         this rank's ring, as a blob another process can open     polaris_hip_ipc_export
+        open(blob) -> peer             (primary) map a peer's ring                               polaris_hip_ipc_open
+        close(peer)                                                                              polaris_hip_ipc_close
+        slot() -> int                  ring slot the last Trace wrote                            polaris_hip_trace_slot
+        begin_frame()                  (primary) the Reset stage of the frame being assembled    polaris_hip_reset_frame
+        merge_peer(peer, slot, y, h)   (primary) frame rows [y, y+h) += peer ring[slot] rows     polaris_hip_merge_ipc
+        merge_self(slot, y, h)         (primary) its own block, from its own ring               polaris_hip_merge_slot
+        end_frame()                    (primary) wait for the merges + tone-map                  polaris_hip_sync_framebuffer
+
+    Per frame f every rank runs   rows = next_rows();  Trace(block of rows);  finish(ticket f-1);  ticket f = post(rows, ms).
+    `post` starts an asynchronous all_gather of (f, slot, rows[rank], ns) -- the ONLY per-frame message, 32 bytes per rank
+    over gloo; `finish` completes it and, on the primary, merges frame f-1 from the slots the ranks named.  The same numbers
+    feed the reference's block scheduler (tracer/scheduler.go) identically on every rank: frame f+1 is scheduled from frame
+    f-1's times, exactly the lag of SchedulerFeedback.
+
+    Why a ring of depth 3 is enough (and 2 is not).  A rank's Trace f writes slot f % depth.  The primary reads the slots of
+    frame g inside finish(g), and posts g+1 only AFTER that (finish before post) -- so "all_gather(g+1) has completed" tells
+    every rank that the primary is done with frame g's slots (end_frame is synchronous: the merge kernels have run).  A
+    rank completes all_gather(g+1) in ITS finish(g+1), during step g+2, i.e. before its Trace g+3 -- the first Trace that
+    comes round to slot g % 3 again.  With depth 2, Trace g+2 would reuse the slot one step before that is known.
+    """
+
+    MIN_DEPTH = 3
+
+    def __init__(self, dist, rank: int, world: int, frame_w: int, frame_h: int, port, scheduler: str = "naive", depth: int = 3, group=None, primary: int = 0):
+        import torch
+
+        from . import host_api
+
+        assert depth >= self.MIN_DEPTH, "the ring must hold the frame being traced, the frame being merged and one in between"
+        self.dist, self.group, self.rank, self.world, self.W, self.H = dist, group, rank, world, frame_w, frame_h
+        self.port, self.depth, self.primary, self.kind = port, depth, primary, scheduler
+        self._torch = torch
+        self.rows = naive_rows(world, frame_h)
+        self._sched = None
+        if scheduler == "perfect" and world > 1:
+            self._sched = host_api.Scheduler(host_api.PERFECT, [1] * world)
+            self._sched.schedule(frame_h)  # its first frame: the naive split (scheduler.go:52-56)
+        self._frame = 0
+        self._finished = -1   # newest frame whose all_gather this rank has completed
+        self._peers = {}
+        self.opened = False
+
+    def setup(self) -> bool:
+        """Exchange the rings' IPC blobs (once); the primary maps every peer.  Returns True on every rank iff every mapping
+        opened -- otherwise nothing stays open and the caller falls back to StripExchange (in this process, no re-launch)."""
+        blob = self.port.export(self.depth)
+        blobs = [None] * self.world
+        self.dist.all_gather_object(blobs, blob, group=self.group)
+        ok, why = True, ""
+        if self.rank == self.primary:
+            try:
+                for r in range(self.world):
+                    if r != self.primary:
+                        self._peers[r] = self.port.open(blobs[r])
+            except Exception as e:  # hipIpcOpenMemHandle refused (no peer access, containers without a shared /dev/kfd view ...)
+                ok, why = False, str(e)
+                for p in self._peers.values():
+                    self.port.close(p)
+                self._peers = {}
+        verdict = [ok, why]
+        self.dist.broadcast_object_list(verdict, src=self.primary, group=self.group)
+        self.opened, self.why_not = bool(verdict[0]), verdict[1]
+        return self.opened
+
+    def set_scheduler(self, kind: str):
+        """Start over with another block scheduler (between two timed regions; nothing may be pending).  The mappings stay."""
+        from . import host_api
+
+        self.kind = kind
+        self.rows = naive_rows(self.world, self.H)
+        self._sched = None
+        if kind == "perfect" and self.world > 1:
+            self._sched = host_api.Scheduler(host_api.PERFECT, [1] * self.world)
+            self._sched.schedule(self.H)
+
+    def next_rows(self):
+        return self.rows
+
+    def post(self, rows, own_ms: float):
+        """After Trace f and finish(f-1): announce (f, slot, rows[rank], time).  Returns the ticket for finish()."""
+        t = self._torch
+        f = self._frame
+        assert self._finished >= f - 1, "finish(f-1) comes before post(f): the primary's post tells the ranks their slots of f-1 are free"
+        self._frame += 1
+        mine = t.tensor([f, int(self.port.slot()), int(rows[self.rank]), max(1, int(own_ms * 1e6))], dtype=t.int64)
+        out = [t.zeros(4, dtype=t.int64) for _ in range(self.world)]
+        work = self.dist.all_gather(out, mine, group=self.group, async_op=True) if self.world > 1 else None
+        if work is None:
+            out[0].copy_(mine)
+        return (f, work, out, list(rows))
+
+    def finish(self, ticket):
+        """Complete frame f's message; the primary merges the frame: every block read where it lies."""
+        f, work, out, rows = ticket
+        if work is not None:
+            work.wait()
+        got = [o.tolist() for o in out]
+        assert all(g[0] == f for g in got), f"ranks disagree about the frame number: {got}"
+        assert [g[2] for g in got] == rows, f"ranks disagree about the rows of frame {f}: {got} vs {rows}"
+        self._finished = f
+        if self._sched is not None:
+            self.rows = self._sched.schedule(self.H, block_h=[g[2] for g in got], render_ns=[g[3] for g in got])
+        if self.rank != self.primary:
+            return
+        self.port.begin_frame()
+        y = 0
+        for r in range(self.world):
+            if r == self.primary:
+                self.port.merge_self(got[r][1], y, rows[r])
+            else:
+                self.port.merge_peer(self._peers[r], got[r][1], y, rows[r])
+            y += rows[r]
+        self.port.end_frame()
+
+    def close(self):
+        for p in self._peers.values():
+            self.port.close(p)
+        self._peers = {}
+
+
+class HipPort:
+    """PeerExchange's tracer side over the C ABI (polaris_amd.tracer.HipTracer)."""
+
+    def __init__(self, tracer, make_req):
+        self.tr, self.make_req = tracer, make_req
+
+    def export(self, depth): return self.tr.ipc_export(depth)
+    def open(self, blob): return self.tr.ipc_open(blob)
+    def close(self, peer): self.tr.ipc_close(peer)
+    def slot(self): return self.tr.trace_slot()
+    def begin_frame(self): self.tr.reset_frame()
+    def merge_peer(self, peer, slot, y, h): self.tr.merge_ipc(peer, slot, self.make_req(y, h))
+    def merge_self(self, slot, y, h): self.tr.merge_slot(self.tr, slot, self.make_req(y, h))
+    def end_frame(self): self.tr.SyncFramebuffer(self.make_req(0, self.tr._H))

@@ -43,7 +43,14 @@ public:
 	Error ReadAccumulator(int which, float *out, size_t n);
 	// ordering merges from other threads behind this tracer's Reset stage (include/polaris_hip.h, polaris_hip_reset_epoch)
 	uint64_t ResetEpoch() const { uint64_t e = 0; if (h_) (void)polaris_hip_reset_epoch(h_, &e); return e; }
-	void WaitReset(uint64_t epoch) const { if (h_) (void)polaris_hip_wait_reset(h_, epoch); }
+	// (non-nil after POLARIS_E_TIMEOUT: the awaited Reset never came -- the caller must not merge onto an uncleared accumulator)
+	Error WaitReset(uint64_t epoch) const {
+		if (!h_) return Error{POLARIS_E_BAD_ARGUMENT, "hip tracer: WaitReset on a closed tracer"};
+		const int rc = polaris_hip_wait_reset(h_, epoch);
+		if (rc == POLARIS_OK) return Error::Nil();
+		const char *m = polaris_hip_last_error(h_);
+		return Error{rc, std::string("hip tracer: ") + (m ? m : "wait_reset failed")};
+	}
 	void ResetFrame() { if (h_) (void)polaris_hip_reset_frame(h_); } // the Reset stage on its own (also advances the epoch)
 	const PolarisTraceStats &LastTraceStats() const { return last_; }
 	polaris_hip_tracer *Handle() const { return h_; }

@@ -71,7 +71,8 @@ void DefaultRenderer::jobWorker(size_t trIndex) {
 				if (hp) {
 					const uint64_t epoch = primaryEpoch_;
 					lk.unlock();
-					hp->WaitReset(epoch);
+					const Error werr = hp->WaitReset(epoch); // a reset that never came: the block must not land on an uncleared frame
+					if (!err && werr) err = werr;
 				} else {
 					frameCv_.wait(lk, [&] { return primaryTraced_ == frame_; });
 				}

@@ -200,7 +200,7 @@ class HipTracer:
         self._check(self._lib.polaris_hip_kernel_symbol(self._h, name.encode(), buf), self._h)
         return buf.value.decode()
 
-    SHADE_TIMERS = ("shade_first", "shade_sort", "shade_plain", "shade_wave", "shade_group")
+    SHADE_TIMERS = ("shade_first", "shade_sort", "shade_plain", "shade_wave")
 
     def shade_counts(self, bounces: int) -> list[dict]:
         """Per bounce of the last Trace: shaded hits / misses / emitter hits and the shade timer the step ran under."""
@@ -218,6 +218,36 @@ class HipTracer:
 
     def merge_device(self, device_ptr: int, req: T.BlockRequest) -> None:
         self._check(self._lib.polaris_hip_merge_device(self._h, C.c_void_p(device_ptr), C.byref(req)), self._h)
+
+    # ---- cross-process merge: peer reads over HIP IPC (include/polaris_hip.h) ------------------------
+    def ipc_export(self, depth: int = 3) -> bytes:
+        """The trace accumulator becomes a ring of `depth` buffers; returns the PolarisIpcExport blob a peer PROCESS opens."""
+        x = T.IpcExport()
+        self._check(self._lib.polaris_hip_ipc_export(self._h, depth, C.byref(x)), self._h)
+        return bytes(x)
+
+    def ipc_open(self, blob: bytes) -> int:
+        """Map another process's ring (its ipc_export blob) on this tracer's device; returns the peer handle."""
+        x = T.IpcExport.from_buffer_copy(blob)
+        p = C.c_void_p()
+        self._check(self._lib.polaris_hip_ipc_open(self._h, C.byref(x), C.byref(p)), self._h)
+        return p.value
+
+    def ipc_close(self, peer: int) -> None:
+        self._check(self._lib.polaris_hip_ipc_close(self._h, C.c_void_p(peer)), self._h)
+
+    def merge_ipc(self, peer: int, slot: int, req: T.BlockRequest) -> None:
+        """MergeOutput from a peer process: rows of `req` of the peer's ring slot, read through the IPC mapping."""
+        self._check(self._lib.polaris_hip_merge_ipc(self._h, C.c_void_p(peer), slot, C.byref(req)), self._h)
+
+    def merge_slot(self, other: "HipTracer", slot: int, req: T.BlockRequest) -> None:
+        """MergeOutput from ring slot `slot` of a tracer of this process (the primary's own block, merged one frame late)."""
+        self._check(self._lib.polaris_hip_merge_slot(self._h, other._h, slot, C.byref(req)), self._h)
+
+    def trace_slot(self) -> int:
+        s = C.c_uint32()
+        self._check(self._lib.polaris_hip_trace_slot(self._h, C.byref(s)), self._h)
+        return int(s.value)
 
     @property
     def device_name(self) -> str:

@@ -7,7 +7,10 @@ import glob
 import json
 import sys
 
-f = glob.glob(sys.argv[1] + "/*/*counter_collection.csv")[0]
+found = glob.glob(sys.argv[1] + "/*/*counter_collection.csv")
+if not found:
+    sys.exit(f"pmc_sum.py: no *counter_collection.csv under {sys.argv[1]} -- the rocprofv3 pass produced nothing (did it fail?)")
+f = found[0]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 launches = collections.defaultdict(set)
 for r in csv.DictReader(open(f)):

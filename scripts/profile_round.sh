@@ -18,6 +18,6 @@ for ov in 1 4; do
 done
 bash scripts/traffic.sh > gpurun_out/${tag}_traffic.txt 2>&1
 cp gpurun_out/traffic.json gpurun_out/${tag}_traffic.json
-bash scripts/pmc.sh ${tag} > /dev/null 2>&1
+bash scripts/pmc.sh ${tag} > gpurun_out/${tag}_pmc.log 2>&1 || echo "profile_round.sh: the SQ counter pass failed, see gpurun_out/${tag}_pmc.log"
 head -12 gpurun_out/${tag}_kernel_stats_overlap1.csv
 cat gpurun_out/${tag}_bench.json | cut -c1-1500

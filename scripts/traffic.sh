@@ -6,6 +6,7 @@
 # gfx950, counts 64 B per 128-B request of a wide coalesced stream: the read side is doubled).
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+cd $R || exit 1
 ARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timers $@"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -- python3 bench.py $ARGS > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -- python3 bench.py $ARGS > /dev/null 2>&1

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol(built):
     for name in declared:
         assert hasattr(lib, name), f"libpolaris_hip.so does not export {name}"
     assert sorted(T.C_ABI_SYMBOLS) == declared, "ctypes_api.C_ABI_SYMBOLS is out of sync with polaris_hip.h"
-    assert lib.polaris_hip_abi_version() == 2
+    assert lib.polaris_hip_abi_version() == 3
 
 
 def test_struct_sizes_match_header(built):
@@ -29,6 +29,7 @@ def test_struct_sizes_match_header(built):
     assert C.sizeof(T.TraceStats) == 7 * 8 + 2 * 32 * 8 + 8
     assert T.BVH_NODE.itemsize == 32 and T.MESH_INSTANCE.itemsize == 80
     assert T.MATERIAL_NODE.itemsize == 64 and T.EMISSIVE.itemsize == 80 and T.TEXTURE_META.itemsize == 16
+    assert C.sizeof(T.IpcExport) == 352             # 8 x 4 + 4 x 64 (hipIpcMemHandle_t) + 64 (hipIpcEventHandle_t)
 
 
 def test_no_device_is_an_error_not_a_crash(built):
@@ -47,6 +48,8 @@ def test_no_device_is_an_error_not_a_crash(built):
     # null handles are rejected, not dereferenced
     assert lib.polaris_hip_resize(None, 4, 4) == 2
     assert lib.polaris_hip_trace(None, None, None, 0, None) == 2
+    assert lib.polaris_hip_ipc_export(None, 3, None) == 2 and lib.polaris_hip_merge_ipc(None, None, 0, None) == 2
+    assert lib.polaris_hip_ipc_open(None, None, None) == 2 and lib.polaris_hip_ipc_close(None, None) == 2
     lib.polaris_hip_destroy(None)
 
 

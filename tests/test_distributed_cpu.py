@@ -1,4 +1,7 @@
-"""The N>1 path of bench.py on CPU: 2 ranks over gloo partition the frame by row block, each renders
+"""(Second half of the file: PeerExchange, the default exchange -- peer reads of every rank's ring -- with shared-memory
+segments standing in for the HIP IPC mappings.)
+
+The N>1 path of bench.py on CPU: 2 ranks over gloo partition the frame by row block, each renders
 its block (the CPU oracle stands in for the GPU tracer -- it is the checker, used here as test
 infrastructure only), and the strips travel to rank 0 through polaris_amd.distributed.StripExchange
 -- the SAME classes, used the same way (next_rows -> trace -> publish -> post -> wait one frame later),
@@ -116,3 +119,151 @@ def test_naive_rows_is_the_reference_schedule():
     assert naive_rows(2, 10, [2, 1]) == [7, 3]
     assert naive_rows(2, 10, [1, 1000]) == [1, 9]
     assert naive_rows(8, 512) == [64] * 8 and naive_rows(8, 1080) == [135] * 8 and naive_rows(2, 97) == [49, 48]
+
+
+# ---- PeerExchange: the default exchange of bench.py (peer reads through IPC mappings) ---------------------------------------
+class ShmPort:
+    """PeerExchange's tracer side without a GPU: the ring is `depth` shared-memory segments (the role of the IPC-mapped trace
+    accumulators), a "Trace" writes the block's rows into the next slot after POISONING the whole slot (what the clear at the
+    start of polaris_hip_trace does to a slot the primary might still be reading), the primary reads peers' rows through its
+    attachments.  A slot read too early or too late shows as NaNs or as another frame's rows."""
+
+    def __init__(self, rank, W, H):
+        self.rank, self.W, self.H = rank, W, H
+        self.segs, self.views, self.pos, self.depth = [], [], 0, 1
+        self.frames, self.frame = [], None
+        self.attached = []
+
+    def export(self, depth):
+        from multiprocessing import shared_memory
+
+        self.depth = depth
+        for i in range(depth):
+            seg = shared_memory.SharedMemory(create=True, size=self.H * self.W * 16)
+            self.segs.append(seg)
+            self.views.append(np.ndarray((self.H, self.W, 4), np.float32, buffer=seg.buf))
+            self.views[-1][:] = 0
+        return ",".join(seg.name for seg in self.segs).encode()
+
+    def open(self, blob):
+        from multiprocessing import shared_memory
+
+        segs = [shared_memory.SharedMemory(name=n) for n in blob.decode().split(",")]
+        self.attached.append(segs)
+        return [np.ndarray((self.H, self.W, 4), np.float32, buffer=seg.buf) for seg in segs]
+
+    def close(self, peer):
+        pass
+
+    def trace(self, acc, by, bh):
+        self.pos = (self.pos + 1) % self.depth
+        self.views[self.pos][:] = np.nan
+        self.views[self.pos][by:by + bh] = acc[by:by + bh]
+
+    def slot(self):
+        return self.pos
+
+    def begin_frame(self):
+        self.frame = np.zeros((self.H, self.W, 4), np.float32)
+
+    def merge_peer(self, peer, slot, y, h):
+        self.frame[y:y + h] += peer[slot][y:y + h]
+
+    def merge_self(self, slot, y, h):
+        self.frame[y:y + h] += self.views[slot][y:y + h]
+
+    def end_frame(self):
+        self.frames.append(self.frame.copy())
+
+    def release(self, unlink):
+        self.views = []
+        for segs in self.attached:
+            for seg in segs:
+                seg.close()
+        for seg in self.segs:
+            seg.close()
+            if unlink:
+                seg.unlink()
+
+
+def _peer_worker(rank, world, port, out_path, scheduler, slow_rank):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import time
+
+    import torch.distributed as dist
+
+    from oracle import pybind as ob
+    from polaris_amd import scenes
+    from polaris_amd.distributed import PeerExchange, block_of
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc = scenes.SCENES["cornell-diffuse"](W / H)
+    shm = ShmPort(rank, W, H)
+    px = PeerExchange(dist, rank, world, W, H, shm, scheduler=scheduler)
+    assert px.setup()
+    orc = ob.Oracle("oracle")
+    pending, all_rows = [], []
+    for f in range(FRAMES + 2):
+        rows = px.next_rows()
+        all_rows.append(list(rows))
+        by, bh = block_of(rank, rows)
+        acc, _, _ = orc.trace(sc, ob.make_request(W, H, spp=SPP, bounces=B, block_y=by, block_h=bh), scenes.make_seeds(SPP, B, base=100 + f))
+        shm.trace(acc, by, bh)
+        if rank == slow_rank:
+            time.sleep(0.15)   # the other rank runs ahead as far as the protocol lets it
+        while pending:
+            px.finish(pending.pop(0))
+        pending.append(px.post(rows, (3.0 if rank == 1 else 1.0) * bh))
+    while pending:
+        px.finish(pending.pop(0))
+    if rank == 0:
+        np.save(out_path, np.stack(shm.frames))
+        np.save(out_path + ".rows.npy", np.array(all_rows))
+    dist.barrier()
+    px.close()
+    shm.release(unlink=False)
+    dist.barrier()
+    shm.release(unlink=True)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scheduler,slow_rank", [("naive", 0), ("naive", 1), ("perfect", 0)])
+def test_two_rank_peer_read_exchange(built, tmp_path, scheduler, slow_rank):
+    """Two processes, the primary reads the other's rows out of a shared ring one frame behind the tracing -- with one rank held
+    back so that the other runs as far ahead as the protocol allows (a ring slot reused before the primary has read it would
+    put NaNs or another frame's rows into the assembled frame).  Every frame == the per-block oracle, bit for bit."""
+    import torch.multiprocessing as mp
+
+    from oracle import pybind as ob
+    from polaris_amd import scenes
+    from polaris_amd.distributed import block_of
+
+    out = str(tmp_path / "frames.npy")
+    mp.spawn(_peer_worker, args=(2, _free_port(), out, scheduler, slow_rank), nprocs=2, join=True)
+    frames = np.load(out)
+    all_rows = np.load(out + ".rows.npy").tolist()
+    n = FRAMES + 2
+    assert frames.shape == (n, H, W, 4) and np.isfinite(frames).all()
+    assert all_rows[0] == [16, 15] and all_rows[1] == [16, 15]   # frame f + 1 is scheduled from frame f - 1
+    if scheduler == "naive":
+        assert all(r == [16, 15] for r in all_rows)
+    else:
+        assert all(sum(r) == H and min(r) >= 1 for r in all_rows) and all_rows[2][1] < 12 and all_rows[-1][1] <= 9, all_rows
+    sc = scenes.SCENES["cornell-diffuse"](W / H)
+    orc = ob.Oracle("oracle")
+    for f in range(n):
+        seeds = scenes.make_seeds(SPP, B, base=100 + f)
+        expect = np.zeros((H, W, 3), np.float32)
+        for r in range(2):
+            by, bh = block_of(r, all_rows[f])
+            a, _, _ = orc.trace(sc, ob.make_request(W, H, spp=SPP, bounces=B, block_y=by, block_h=bh), seeds)
+            expect[by:by + bh] = a[by:by + bh, :, :3]
+        assert np.array_equal(frames[f][..., :3].view(np.uint32), expect.view(np.uint32)), f
+
+
+def test_peer_exchange_refuses_a_ring_that_is_too_short():
+    from polaris_amd.distributed import PeerExchange
+
+    with pytest.raises(AssertionError, match="ring"):
+        PeerExchange(None, 0, 2, 8, 8, None, depth=2)

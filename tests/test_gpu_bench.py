@@ -1,8 +1,9 @@
 """bench.py end to end on the GPU box: the single-GPU line carries the contract's fields, and the
-N>1 flow (row blocks, gather to the primary, merge, tonemap) completes under torch.distributed --
-two ranks sharing the one GPU over gloo, which exercises the same code path the driver runs over
-RCCL on 8 GPUs.  Both run as subprocesses under a timeout so a collective mismatch cannot hang the
-suite."""
+N>1 flow (row blocks, the primary's peer-read merge through HIP IPC mappings, tonemap) completes under
+torch.distributed -- two PROCESSES sharing the one GPU, which exercises the code path the driver runs
+on 8 GPUs (the mapping is then a peer mapping over xGMI instead of a second mapping of local memory).
+The strip-transfer fallback is covered too (over gloo).  Everything runs as subprocesses under a timeout
+so a collective mismatch cannot hang the suite."""
 import json
 import os
 import socket
@@ -79,19 +80,36 @@ def test_bench_two_ranks_bare_launch_and_frame(built, tmp_path):
     frame the primary assembled from the gathered strips equals the per-block oracle bit for bit."""
     acc = str(tmp_path / "frame.npy")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--backend", "gloo", "--same-device", "--no-cpu-baseline",
-           "--scheduler", "naive", "--opt", "exact_accumulate=1", "--save-accumulator", acc]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--same-device", "--no-cpu-baseline",
+           "--opt", "exact_accumulate=1", "--save-accumulator", acc]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and d["scaling"] == "strong" and d["value"] > 0
-    assert "row blocks [49, 48]" in d["config"]["workload"]
+    assert d["config"]["exchange"].startswith("hip-ipc"), d["config"]["exchange"]      # the default: peer reads, no fallback
+    assert d["config"]["scheduler"] == "naive" and "row blocks [49, 48]" in d["config"]["workload"]   # what `polaris render` passes
+    ps = d["config"]["perfect_scheduler"]                                                 # the second timed region of the same run
+    assert ps["scheduler"] == "perfect" and ps["value"] > 0 and sum(ps["rows_last_frame"]) == 97
+    _two_rank_frame_matches_the_oracle(d, acc)
+
+
+def test_bench_two_ranks_strip_fallback(built, tmp_path):
+    """`--exchange strips`: the path bench.py falls back to when an IPC mapping cannot be opened -- point-to-point transfers of
+    the strips (here over gloo, staged through the host; RCCL needs two GPUs), merged with polaris_hip_merge_device."""
+    acc = str(tmp_path / "frame.npy")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--exchange", "strips", "--backend", "gloo", "--same-device", "--no-cpu-baseline",
+           "--no-second-scheduler", "--opt", "exact_accumulate=1", "--save-accumulator", acc]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["exchange"].startswith("gloo point-to-point")
     _two_rank_frame_matches_the_oracle(d, acc)
 
 
 def test_bench_two_ranks_perfect_scheduler(built, tmp_path):
-    """The default for N > 1: the reference's perfect scheduler (tracer/scheduler.go:50-80) fed by all-gathered (rows, time)
-    pairs -- every rank must arrive at the same rows every frame, or the strips would not fit together.  The last frame, with
+    """`--scheduler perfect`: the reference's perfect scheduler (tracer/scheduler.go:50-80) fed by all-gathered (rows, time)
+    pairs -- every rank must arrive at the same rows every frame, or the blocks would not fit together.  The last frame, with
     whatever rows the scheduler had settled on, must be the per-block oracle result bit for bit."""
     import numpy as np
 
@@ -101,13 +119,14 @@ def test_bench_two_ranks_perfect_scheduler(built, tmp_path):
     acc = str(tmp_path / "frame.npy")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     small = ["--width", "128", "--height", "97", "--spp", "8", "--steps", "4", "--warmup", "3"]
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *small, "--backend", "gloo", "--same-device", "--no-cpu-baseline", "--no-kernel-timers",
-           "--opt", "exact_accumulate=1", "--save-accumulator", acc]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *small, "--same-device", "--no-cpu-baseline", "--no-kernel-timers",
+           "--scheduler", "perfect", "--no-second-scheduler", "--opt", "exact_accumulate=1", "--save-accumulator", acc]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     rows = d["config"]["rows_last_frame"]
     assert d["config"]["scheduler"] == "perfect" and "perfect scheduler" in d["config"]["workload"] and sum(rows) == 97 and min(rows) >= 1
+    assert d["config"]["exchange"].startswith("hip-ipc"), d["config"]["exchange"]
     W, H, spp, B = 128, 97, 8, 5
     sc = scenes.SCENES["cornell"](W / H)
     seeds = scenes.make_seeds(spp, B)
@@ -122,9 +141,10 @@ def test_bench_two_ranks_perfect_scheduler(built, tmp_path):
 
 
 def test_bench_two_ranks_with_a_different_frame_every_step(built, tmp_path):
-    """The strip exchange runs one frame behind the tracing (polaris_amd/distributed.py): with the same seeds every frame a
-    strip merged into the wrong frame would go unnoticed.  --test-seeds gives every frame its own seed list; the frame rank 0
-    assembled LAST must be the per-block oracle result of the last frame's seeds."""
+    """The exchange runs one frame behind the tracing (polaris_amd/distributed.py) and every rank's trace accumulator is a ring
+    of three: with the same seeds every frame a block read from the wrong ring slot, or merged into the wrong frame, would go
+    unnoticed.  --test-seeds gives every frame its own seed list; the frame rank 0 assembled LAST (through the IPC mappings)
+    must be the per-block oracle result of the last frame's seeds."""
     import numpy as np
 
     from oracle import pybind as ob
@@ -133,12 +153,14 @@ def test_bench_two_ranks_with_a_different_frame_every_step(built, tmp_path):
 
     acc = str(tmp_path / "frame.npy")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    steps, warmup = 3, 2
+    steps, warmup = 5, 2
     small = ["--width", "128", "--height", "97", "--spp", "8", "--steps", str(steps), "--warmup", str(warmup)]
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *small, "--backend", "gloo", "--same-device", "--no-cpu-baseline",
-           "--no-kernel-timers", "--scheduler", "naive", "--opt", "exact_accumulate=1", "--save-accumulator", acc, "--test-seeds"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *small, "--same-device", "--no-cpu-baseline",
+           "--no-kernel-timers", "--no-second-scheduler", "--opt", "exact_accumulate=1", "--save-accumulator", acc, "--test-seeds"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["exchange"].startswith("hip-ipc"), d["config"]["exchange"]
     W, H, spp, B = 128, 97, 8, 5
     frame = np.load(acc)
     sc = scenes.SCENES["cornell"](W / H)
@@ -202,11 +224,11 @@ def test_bench_refuses_more_gpus_than_visible(built):
 
 def test_bench_two_ranks_under_the_drivers_launcher(built):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--backend", "gloo", "--same-device",
-           "--no-cpu-baseline", "--scheduler", "naive"]
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--same-device",
+           "--no-cpu-baseline"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
-    assert "row blocks [49, 48]" in d["config"]["workload"]
+    assert "row blocks [49, 48]" in d["config"]["workload"] and d["config"]["exchange"].startswith("hip-ipc")

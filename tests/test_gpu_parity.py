@@ -72,16 +72,11 @@ def test_hip_vs_oracle_exact_and_batched(built, oracle, name):
                 ({"samples_per_batch": 4}, False), ({"samples_per_batch": 1, "overlap": 3}, False),
                 ({"samples_per_batch": 2, "overlap": 1, "traversal": 0}, False),
                 # where k_trace reads its node records: global memory / top of the tree in LDS / (tiny scenes) whole tree in LDS
-                ({"exact_accumulate": 1, "node_mode": 0, "wide": 0}, True), ({"exact_accumulate": 1, "node_mode": 1, "wide": 0}, True),
-                ({"exact_accumulate": 1, "node_mode": 2}, True), ({"node_mode": 1, "wide": 0, "samples_per_batch": 3}, False),
-                # four lanes per ray over the four-wide tree (k_trace4), with the leaves the upload makes by default, the caller's, and 4-triangle ones
-                ({"exact_accumulate": 1, "wide": 1}, True), ({"exact_accumulate": 1, "wide": 1, "max_leaf_tris": 0}, True),
-                ({"exact_accumulate": 1, "wide": 1, "max_leaf_tris": 4, "packet_primary": 0}, True), ({"wide": 1, "samples_per_batch": 3}, False),
+                ({"exact_accumulate": 1, "node_mode": 0}, True), ({"exact_accumulate": 1, "node_mode": 1}, True),
+                ({"exact_accumulate": 1, "node_mode": 2}, True), ({"node_mode": 1, "samples_per_batch": 3}, False),
                 ({"exact_accumulate": 1, "shade_wave": 0}, True), ({"exact_accumulate": 1, "shade_wave_from": 0}, True),
                 ({"shade_wave": 0, "stage_lds": 0, "samples_per_batch": 3}, False), ({"shade_wave_from": 1, "samples_per_batch": 2}, False),
                 # shading order: never sorted by class / sorted from bounce 2 / sorted with the tables in global memory
-                # bounce rays class by class across 16 chunks (k_shade_group) instead of per chunk (k_shade sorted / unsorted, k_shade_wave)
-                ({"exact_accumulate": 1, "shade_group": 1}, True), ({"shade_group": 1, "samples_per_batch": 3}, False), ({"shade_group": 1, "stage_lds": 0, "overlap": 1}, False),
                 ({"exact_accumulate": 1, "shade_sort": 32}, True), ({"exact_accumulate": 1, "shade_sort": 2}, True),
                 ({"exact_accumulate": 1, "stage_lds": 0}, True), ({"shade_sort": 32, "shade_wave": 0, "samples_per_batch": 3}, False))
     for opts, exact in variants:
@@ -312,31 +307,81 @@ def test_merge_does_not_wait_for_a_trace_on_the_destination(built, oracle):
     assert frame[:128, :, :3].sum() > 0
 
 
-@pytest.mark.parametrize("name,W,H,spp", [("cornell", 512, 512, 32), ("instanced", 1024, 1024, 4), ("material-ball", 960, 540, 8)])
-def test_optional_kernels_at_bench_sizes_equal_the_default_path(built, name, W, H, spp):
-    """The kernels that are off by default -- four lanes per ray over the four-wide tree (wide=1), bounce rays shaded class by
-    class across 16 chunks (shade_group=1) -- on frames of the bench configurations' width (tens of millions of rays, every
-    persistent-grid / ticket / refill path under load): counters and the batched accumulator must equal the default path's
-    BIT FOR BIT (per-path sums are resolved in sample order whatever kernel produced them)."""
+def test_merges_are_ordered_against_the_next_trace_without_a_sync(built, oracle):
+    """MergeOutput is asynchronous (Exec1DNoWait, resources.go:119) on the destination's merge stream; the source's NEXT Trace
+    clears and rewrites the rows the merge reads.  The library orders the two on the device (self-merge: the main stream joins
+    the merge stream; another handle: the event its merge stream records behind the read), so a host may go
+    Trace -> MergeOutput -> Trace -> MergeOutput ... with ONE SyncFramebuffer at the end -- the progressive loop -- on a frame
+    big enough that the merge of one pass is still queued when the next Trace starts."""
     from oracle import pybind as ob
     from polaris_amd import scenes
 
-    sc = scenes.SCENES[name](W / H)
-    B = 5
-    seeds = scenes.make_seeds(spp, B, base=4242)
-    results = []
-    for opts in ({}, {"wide": 1}, {"shade_group": 1}, {"wide": 1, "shade_group": 1, "overlap": 1}):
-        tr = make_hip_tracer(sc, W, H, **opts)
+    sc = scenes.SCENES["sphere"]()
+    W, H, B, spp, passes = 512, 384, 2, 1, 4
+    lists = [scenes.make_seeds(spp, B, base=900 + i) for i in range(passes)]
+    total = np.zeros((H, W, 3), np.float32)
+    for sd in lists:
+        o, _, _ = oracle.trace(sc, ob.make_request(W, H, spp=spp, bounces=B), sd)
+        total = total + o[..., :3]
+    for two_handles in (False, True):
+        prim = make_hip_tracer(sc, W, H, exact_accumulate=1)
+        src = make_hip_tracer(sc, W, H, exact_accumulate=1) if two_handles else prim
         try:
-            tr.Trace(ob.make_request(W, H, spp=spp, bounces=B), seeds)
-            results.append((opts, tr.read_accumulator(0), counters(tr.last_trace_stats, B), tr.last_trace_stats.emitter_hits))
+            prim.reset_frame()
+            for i, sd in enumerate(lists):
+                src.Trace(ob.make_request(W, H, spp=spp, bounces=B, accumulated=1), sd)   # (accumulated > 0: no Reset stage)
+                prim.MergeOutput(src, ob.make_request(W, H, spp=spp, bounces=B, accumulated=1))
+            prim.SyncFramebuffer(ob.make_request(W, H, spp=spp, bounces=B, accumulated=passes - spp))
+            frame = prim.read_accumulator(1)
         finally:
-            tr.Close()
-    base = results[0]
-    assert base[1][..., :3].sum() > 0 and base[2][2] == W * H * spp
-    for opts, acc, cnt, emit in results[1:]:
-        assert cnt == base[2] and emit == base[3], opts
-        assert np.array_equal(bits(acc[..., :3]), bits(base[1][..., :3])), opts
+            if two_handles:
+                src.Close()
+            prim.Close()
+        assert np.array_equal(bits(frame[..., :3]), bits(total)), two_handles
+
+
+def test_trace_accumulator_ring_and_merge_from_a_slot(built, oracle):
+    """polaris_hip_ipc_export turns the trace accumulator into a ring: Trace i writes slot (i mod depth), older frames stay
+    readable (what a peer process relies on while this tracer is already tracing the next frame), polaris_hip_merge_slot adds
+    a given slot; opening one's own export is refused (HIP cannot), a resize drops the ring."""
+    from oracle import pybind as ob
+    from polaris_amd import ctypes_api as T
+    from polaris_amd import scenes
+    from polaris_amd.tracer import TracerError
+
+    sc = scenes.SCENES["cornell"]()
+    W, H, B, spp = 64, 48, 4, 2
+    tr = make_hip_tracer(sc, W, H, exact_accumulate=1)
+    try:
+        blob = tr.ipc_export(3)
+        x = T.IpcExport.from_buffer_copy(blob)
+        assert (x.depth, x.frame_w, x.frame_h, x.abi_version) == (3, W, H, 3) and x.pid == __import__("os").getpid()
+        with pytest.raises(TracerError, match="this process"):
+            tr.ipc_open(blob)
+        want, slots = [], []
+        for i in range(4):
+            sd = scenes.make_seeds(spp, B, base=40 + i)
+            tr.Trace(ob.make_request(W, H, spp=spp, bounces=B), sd)
+            slots.append(tr.trace_slot())
+            want.append(oracle.trace(sc, ob.make_request(W, H, spp=spp, bounces=B), sd)[0][..., :3])
+            assert np.array_equal(bits(tr.read_accumulator(0)[..., :3]), bits(want[-1]))   # the "trace accumulator" is the newest slot
+        assert slots == [1, 2, 0, 1]
+        # frames 2 and 3 (slots 0 and 1) and frame 1 (slot 2) are all still there
+        for frame_i, slot in ((1, 2), (2, 0), (3, 1)):
+            tr.reset_frame()
+            tr.merge_slot(tr, slot, ob.make_request(W, H, spp=spp, bounces=B, block_y=5, block_h=30))
+            tr.SyncFramebuffer(ob.make_request(W, H, spp=spp, bounces=B))
+            got = tr.read_accumulator(1)[..., :3]
+            assert np.array_equal(bits(got[5:35]), bits(want[frame_i][5:35])) and not got[:5].any() and not got[35:].any()
+        with pytest.raises(TracerError, match="slot"):
+            tr.merge_slot(tr, 3, ob.make_request(W, H, spp=spp, bounces=B))
+        from polaris_amd.tracer import ChangeType, UpdateMode
+        tr.UpdateState(UpdateMode.Synchronous, ChangeType.FrameDimensions, (W, H))   # resize: back to the single buffer
+        tr.Trace(ob.make_request(W, H, spp=spp, bounces=B), scenes.make_seeds(spp, B, base=40))
+        assert tr.trace_slot() == 0
+        assert np.array_equal(bits(tr.read_accumulator(0)[..., :3]), bits(want[0]))
+    finally:
+        tr.Close()
 
 
 def test_progressive_accumulation(built, oracle):
@@ -554,8 +599,7 @@ def test_frames_of_the_other_configs_against_the_oracle(built, oracle, name, W, 
 
 @pytest.mark.parametrize("name", ["material-ball", "instanced"])
 def test_big_scene_kernel_variants_agree_with_the_oracle(built, oracle, name):
-    """Scenes that select the other kernel variants -- four lanes per ray over the four-wide tree (the default where the
-    tree does not fit LDS) and, with wide=0, the one-lane-per-ray kernel with its 24-entry stack and no LDS tree top;
+    """Scenes that select the other kernel variants -- the one-lane-per-ray kernel with its 24-entry stack and no LDS tree top,
     leaves of up to 4 triangles, (for > 256 K triangles) per-ray camera traversal -- traced in exact mode with each
     upload / traversal option flipped: all bit-identical to the CPU oracle."""
     from oracle import pybind as ob
@@ -567,8 +611,8 @@ def test_big_scene_kernel_variants_agree_with_the_oracle(built, oracle, name):
     seeds = scenes.make_seeds(spp, B, base=21)
     want, wst, _ = oracle.trace(sc, req, seeds)
     assert wst.shaded_hits > 0
-    for opts in ({}, {"max_leaf_tris": 0}, {"max_leaf_tris": 1}, {"packet_primary": 0}, {"traversal": 0}, {"stage_lds": 0}, {"node_mode": 0}, {"node_mode": 2},
-                 {"wide": 0}, {"wide": 0, "max_leaf_tris": 0}, {"wide": 0, "packet_primary": 0}, {"wide": 0, "node_mode": 1}, {"wide": 1, "max_leaf_tris": 2}):
+    for opts in ({}, {"max_leaf_tris": 0}, {"max_leaf_tris": 1}, {"max_leaf_tris": 2}, {"packet_primary": 0}, {"traversal": 0}, {"stage_lds": 0}, {"node_mode": 0},
+                 {"node_mode": 1}, {"node_mode": 2}):
         tr = make_hip_tracer(sc, W, H, exact_accumulate=1, **opts)
         try:
             tr.Trace(req, seeds)

@@ -186,7 +186,7 @@ def _random_rays(sc, n, rng):
 @pytest.mark.parametrize("name", ["cornell", "cubes", "transformed", "material-ball-small", "instanced-small", "terrain-small", "many-materials"])
 def test_arbitrary_rays_through_every_traversal_kernel(built, oracle, name):
     """rayIntersectionQuery / rayIntersectionTest on 100 000 arbitrary rays: persistent refill kernel in each node mode
-    the scene admits, one-ray-per-lane kernel, wave-packet kernel, quad-ray kernel over the four-wide tree -- hit flag,
+    the scene admits, one-ray-per-lane kernel, wave-packet kernel -- hit flag,
     triangle and (w,u,v,t) bit-equal to the oracle."""
     from polaris_amd import scenes
 
@@ -196,8 +196,7 @@ def test_arbitrary_rays_through_every_traversal_kernel(built, oracle, name):
     w_hit, w_wuvt, w_it = oracle.intersect(sc, rays, any_hit=False)
     w_occ, _, _ = oracle.intersect(sc, rays, any_hit=True)
     assert 0.2 < w_hit.mean() < 1.0 and 0.0 < w_occ.mean()
-    variants = [dict(traversal=1, node_mode=m, wide=0) for m in (0, 1, 2)] + [dict(traversal=0), dict(packet_primary=1, packet_shadow=32)]
-    variants += [dict(wide=1), dict(wide=1, max_leaf_tris=0), dict(wide=1, max_leaf_tris=4)]  # k_trace4: four lanes per ray, four-wide nodes
+    variants = [dict(traversal=1, node_mode=m) for m in (0, 1, 2)] + [dict(traversal=0), dict(packet_primary=1, packet_shadow=32)]
     for opts in variants:
         tr = make_hip_tracer(sc, 8, 8, **opts)
         try:

@@ -33,19 +33,19 @@ def harness():
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"),
                                "-I" + os.path.join(ROOT, "polaris_amd", "csrc"), SRC, "-o", LIB])
     lib = C.CDLL(LIB)
-    for fn in (lib.layout_check_traverse, lib.layout_check_traverse_quad):
+    for fn in (lib.layout_check_traverse,):
         fn.argtypes = [C.POINTER(T.SceneView), C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
     return lib
 
 
-def traverse(lib, sc, rays, max_leaf, any_hit=False, quad=False):
-    """Walk the uploaded layout on the CPU: the pair tree with k_trace's rules, or (quad=True) the four-wide tree with k_trace4's."""
+def traverse(lib, sc, rays, max_leaf, any_hit=False):
+    """Walk the uploaded layout on the CPU with k_trace's rules."""
     rays = np.ascontiguousarray(rays, dtype=np.float32)
     hit = np.zeros((rays.shape[0], 6), np.int32)
     cnt = np.zeros(7, np.uint64)
     err = C.create_string_buffer(256)
     view = T.scene_view(sc)
-    fn = lib.layout_check_traverse_quad if quad else lib.layout_check_traverse
+    fn = lib.layout_check_traverse
     rc = fn(C.byref(view), max_leaf, rays.ctypes.data, rays.shape[0], int(any_hit), hit.ctypes.data, cnt.ctypes.data, err, 256)
     assert rc == 0, err.value.decode()
     return hit, cnt
@@ -198,46 +198,6 @@ def face_rays(sc, rng, n):
 QUAD_SCENES = dict(RANDOM_RAY_SCENES)
 QUAD_SCENES.update({"cornell": lambda tmp: scenes.cornell_box(), "terrain-small": lambda tmp: scenes.SCENES["terrain-small"](),
                     "instanced-small": lambda tmp: scenes.SCENES["instanced-small"](), "sphere": lambda tmp: scenes.sphere_scene()})
-
-
-@pytest.mark.parametrize("name", list(QUAD_SCENES))
-def test_four_wide_tree_reaches_exactly_the_reference_leaves(harness, oracle, name, tmp_path):
-    """scene_layout.h build_quads collapses the pair tree two levels at a time (a child's box is no longer tested where its
-    children's boxes lie inside it): the four-wide walk must return the hit records of rayIntersectionQuery / the flags of
-    rayIntersectionTest for every ray -- random ones, axis-parallel ones, and rays ON box faces running parallel to them,
-    where 0 * inf turns up in the slab test (the case the collapse rule excludes)."""
-    sc = QUAD_SCENES[name](tmp_path)
-    box_lo = np.minimum(sc.vertices[:, :3].min(axis=0), -1.0) - 0.5
-    box_hi = np.maximum(sc.vertices[:, :3].max(axis=0), 1.0) + 0.5
-    rng = np.random.default_rng(11)
-    n = 40000
-    rays = np.zeros((n, 8), np.float32)
-    rays[:, 0:3] = rng.uniform(box_lo, box_hi, size=(n, 3))
-    d = rng.normal(size=(n, 3))
-    rays[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True)
-    rays[:, 3] = np.float32(3.402823466e+38)
-    rays[: n // 8, 4 + (np.arange(n // 8) % 3)] = 0.0
-    rays = np.concatenate([rays, face_rays(sc, rng, 20000)])
-    shadow = rays.copy()
-    shadow[:, 3] = rng.uniform(0.05, 4.0, size=len(rays))
-    h, wuvt, it = oracle.intersect(sc, rays)
-    ha, _, _ = oracle.intersect(sc, shadow, any_hit=True)
-    hm = h != 0
-    assert 0 < hm.sum() < len(rays)
-    for max_leaf in (0, 2, 4):
-        got, cnt = traverse(harness, sc, rays, max_leaf, quad=True)
-        assert np.array_equal(got[:, 5] != 0, hm), f"{name}: hit flags differ (max_leaf_tris={max_leaf})"
-        assert np.array_equal(got[hm][:, [1, 0]], it[hm])
-        assert np.array_equal(got[hm][:, 2], wuvt[hm][:, 3].view(np.int32))
-        assert np.array_equal(got[hm][:, 3:5], wuvt[hm][:, 1:3].view(np.int32))
-        got_any, _ = traverse(harness, sc, shadow, max_leaf, any_hit=True, quad=True)
-        assert np.array_equal(got_any[:, 5] != 0, ha != 0)
-        assert 0 < cnt[5] <= 64 and cnt[6] < cnt[5]     # the stack bound computed at upload holds (and is not hit exactly: one spare entry)
-        pair_hits, pair_cnt = traverse(harness, sc, rays, max_leaf)
-        assert np.array_equal(pair_hits, got)
-        assert cnt[0] <= pair_cnt[0]                     # never more dependent steps than the pair tree
-        print(f"{name} max_leaf={max_leaf}: {int(cnt[3])} quads x {cnt[4] / max(int(cnt[3]), 1):.2f} children, steps {int(cnt[0])} vs {int(pair_cnt[0])} pair steps "
-              f"({cnt[0] / max(int(pair_cnt[0]), 1):.2f}), triangle tests {int(cnt[1])} vs {int(pair_cnt[1])}, stack {int(cnt[5])} vs {int(pair_cnt[5])}")
 
 
 def test_subdivision_cuts_triangle_tests_on_big_leaves(harness, oracle):

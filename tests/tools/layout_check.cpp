@@ -149,123 +149,4 @@ int layout_check_traverse(const PolarisSceneView *sc, int max_leaf_tris, const f
 	}
 	return 0;
 }
-
-// The same walk over the FOUR-WIDE tree (SceneLayout::quads, scene_layout.h build_quads) with the rules of k_trace4
-// (kernels_quad.h): all used child slots tested, hit children visited nearest first (slot order among equals; stored order
-// for any-hit), the others pushed; leaves, instances and the tie rule as above.
-// counters: [0] quad steps, [1] triangle tests, [2] leaf visits, [3] quad records, [4] used child slots, [5] stack need (0 = the
-//           collapsed tree is not available for this scene), [6] deepest stack seen.
-int layout_check_traverse_quad(const PolarisSceneView *sc, int max_leaf_tris, const float *rays, uint32_t n, int any_hit,
-                               int32_t *hit, uint64_t *counters, char *err, size_t err_len) {
-	SceneLayout L;
-	std::string e = build_layout(*sc, L, max_leaf_tris);
-	if (e == "@retry-without-subdivision") { L = SceneLayout(); e = build_layout(*sc, L, 0); }
-	if (e.empty() && L.quad_stack == 0) e = "the collapsed tree needs more than kQuadStackMax stack entries";
-	if (!e.empty()) {
-		if (err && err_len) { strncpy(err, e.c_str(), err_len - 1); err[err_len - 1] = 0; }
-		return 1;
-	}
-	uint64_t steps = 0, tests = 0, visits = 0, deepest = 0;
-	std::vector<int> stk(kQuadStackMax + 8);
-	for (uint32_t r = 0; r < n; r++) {
-		const float *R = rays + 8 * (size_t)r;
-		const V3 O = {R[0], R[1], R[2]}, D = {R[4], R[5], R[6]};
-		const float maxDist = R[3];
-		V3 o = O, d = D, inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)};
-		int sp = 0, cur = L.quad_root_ref, inst = 0, btri = -1, binst = 0;
-		uint32_t irank = 0, birank = 0, btrank = 0;
-		float bt = maxDist, bu = 0, bv = 0;
-		bool found = false;
-		for (;;) {
-			if (cur >= 0) {
-				const QuadNodeH &Q = L.quads[cur];
-				steps++;
-				float t[4];
-				int order[4], nh = 0;
-				for (int k = 0; k < 4; k++) {
-					t[k] = slab(Q.c[k].lo, Q.c[k].hi, o, inv, maxDist); // (a NaN box: every comparison false -> the NaN comes back, and NaN < kFltMax is false)
-					bool h = t[k] < kFltMax;
-					if (h && !any_hit && t[k] > bt * Q.c[k].cull) h = false;
-					if (h) order[nh++] = k;
-				}
-				if (!any_hit) // nearest first, slot order among equals
-					for (int a = 1; a < nh; a++)
-						for (int b = a; b > 0 && t[order[b]] < t[order[b - 1]]; b--) { const int x = order[b]; order[b] = order[b - 1]; order[b - 1] = x; }
-				if (nh > 0) {
-					for (int a = nh - 1; a >= 1; a--) stk[sp++] = Q.c[order[a]].ref;
-					if ((uint64_t)sp > deepest) deepest = (uint64_t)sp;
-					if (sp > L.quad_stack) { if (err && err_len) strncpy(err, "stack need exceeded", err_len - 1); return 2; }
-					cur = Q.c[order[0]].ref;
-					continue;
-				}
-			} else {
-				const uint32_t code = (uint32_t)~cur;
-				const LeafInfoH li = (code & 15u) ? LeafInfoH{-(int32_t)(code >> 4), (int32_t)(code & 15u)} : L.leaves[code >> 4];
-				if (li.rdata == 0) {
-					inst = -li.ldata;
-					const InstH &I = L.insts[inst];
-					irank = I.rank;
-					stk[sp++] = kExit;
-					if ((uint64_t)sp > deepest) deepest = (uint64_t)sp;
-					if (sp > L.quad_stack) { if (err && err_len) strncpy(err, "stack need exceeded", err_len - 1); return 2; }
-					V3 no = {I.r0[0] * o.x + I.r0[1] * o.y + I.r0[2] * o.z + I.r0[3], I.r1[0] * o.x + I.r1[1] * o.y + I.r1[2] * o.z + I.r1[3],
-					         I.r2[0] * o.x + I.r2[1] * o.y + I.r2[2] * o.z + I.r2[3]};
-					V3 nd = {I.r0[0] * d.x + I.r0[1] * d.y + I.r0[2] * d.z, I.r1[0] * d.x + I.r1[1] * d.y + I.r1[2] * d.z,
-					         I.r2[0] * d.x + I.r2[1] * d.y + I.r2[2] * d.z};
-					o = no; d = nd;
-					inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)};
-					cur = L.inst_quad_root[inst];
-					continue;
-				}
-				visits++;
-				const int first = -li.ldata;
-				for (int t = first; t < first + li.rdata && !found; t++) {
-					const TriH &T = L.tris[t];
-					tests++;
-					V3 e1 = {T.e1[0], T.e1[1], T.e1[2]}, e2 = {T.e2[0], T.e2[1], T.e2[2]};
-					V3 pv = cross(d, e2);
-					float det = dot(e1, pv);
-					if (pm_fabs(det) < kEps) continue;
-					float idet = pm_rcp(det);
-					V3 tv = {o.x - T.v0[0], o.y - T.v0[1], o.z - T.v0[2]};
-					float u = dot(tv, pv) * idet;
-					if (u < 0.0f || u > 1.0f) continue;
-					V3 qv = cross(tv, e1);
-					float v = dot(d, qv) * idet;
-					if (v < 0.0f || u + v > 1.0f) continue;
-					float tt = dot(e2, qv) * idet;
-					if (any_hit) {
-						if (tt > kEps && tt < maxDist) found = true;
-					} else if (tt > kEps) {
-						const bool closer = tt < bt;
-						const bool tie = tt == bt && btri >= 0 && (irank < birank || (irank == birank && T.rank < btrank));
-						if (closer || tie) { bt = tt; bu = u; bv = v; btri = (int)(T.orig & ((1u << L.tri_bits) - 1u)); binst = inst; birank = irank; btrank = T.rank; }
-					}
-				}
-				if (found) break;
-			}
-			bool done = false;
-			for (;;) {
-				if (sp == 0) { done = true; break; }
-				cur = stk[--sp];
-				if (cur != kExit) break;
-				o = O; d = D;
-				inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)};
-			}
-			if (done) break;
-		}
-		int32_t *H = hit + 6 * (size_t)r;
-		if (any_hit) { H[0] = H[1] = H[2] = H[3] = H[4] = 0; H[5] = found; }
-		else {
-			H[0] = btri; H[1] = binst;
-			memcpy(&H[2], &bt, 4); memcpy(&H[3], &bu, 4); memcpy(&H[4], &bv, 4);
-			H[5] = btri >= 0;
-		}
-	}
-	if (counters) {
-		counters[0] = steps; counters[1] = tests; counters[2] = visits;
-		counters[3] = L.quads.size(); counters[4] = L.quad_children; counters[5] = (uint64_t)L.quad_stack; counters[6] = deepest;
-	}
-	return 0;
-}
 }
