@@ -247,7 +247,8 @@ int polaris_hip_selftest_rcp(polaris_hip_tracer *h, float lo, float hi, uint64_t
 /* With option time_kernels=1: accumulated device milliseconds and launch count of the named
  * timer since the last call for that name.  Timers: "generate", "intersect_packet" (camera rays through
  * the wave-packet kernel), "intersect" (closest hit), "shade_first" / "shade_sort" /
- * "shade_plain" / "shade_wave" (one per shade kernel symbol), "scan", "occlusion", "resolve", "aggregate", "tonemap". */
+ * "shade_plain" / "shade_wave" (one per shade kernel symbol), "scan", "occlusion", "fold" (the batch's NEE records into the
+ * per-path radiance), "resolve", "aggregate", "tonemap". */
 int polaris_hip_kernel_ms(polaris_hip_tracer *h, const char *kernel, double *ms, uint64_t *launches);
 
 /* The kernel symbol (as rocprofv3 prints it, e.g. "pol::k_trace<false, 16, 2>") the named timer last

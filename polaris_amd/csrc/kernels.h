@@ -6,7 +6,8 @@
 // (one 16 B access per lane = the coalescing sweet spot of the guide):
 //     ray_o  = origin.xyz | max distance          ray_d = direction.xyz | path word
 //     thr    = path throughput.xyz | -            hit   = u | v | t | triangle (-1 = miss)
-//     occ_o / occ_d / occ_e = shadow ray origin|maxDist, dir|accumulator index, NEE radiance
+//     occ_o / occ_d / occ_e = shadow ray origin|maxDist, dir|accumulator cell, NEE radiance|accumulator cell
+//     vis    = one byte per shadow ray: 1 = unoccluded (batched mode: what the any-hit kernels write; k_fold_nee reads it)
 //     lsum   = per-path radiance of this batch (resolved into the trace accumulator in
 //              sample order at the end of the batch)
 // path word = path index (24 bit, the reference keeps it as a float in dir.w,
@@ -72,6 +73,7 @@ struct BvhDev {
 struct Streams {
 	float4 *ray_o, *ray_d, *thr, *hit;
 	float4 *occ_o, *occ_d, *occ_e;
+	uint8_t *vis; // batched mode: visibility flag of the shadow ray in the same slot of occ_* (written for EVERY shadow ray: dense, whole sectors)
 	float4 *lsum;
 	uint32_t *cnt_ray, *cnt_occ, *pfx;
 	uint32_t *wg_stat; // per workgroup, written by shade: hits | misses << 10 | emitter hits << 20 (summed by k_scan)
@@ -253,8 +255,31 @@ __global__ __launch_bounds__(WG) void k_intersect(Streams st, BvhDev B) {
 	if (st.hit_inst) st.hit_inst[slot] = h.inst;
 }
 
+// What an unoccluded shadow ray does (accumulateEmissiveSamples, pt_integrator.cl:278-296), in one of two ways:
+//   acc != null  (exact mode: one sample per batch, the trace accumulator itself) -- the NEE radiance is added to the ray's
+//                accumulator cell right here, in the reference's order; one path per cell and launch: plain read-modify-write;
+//   acc == null  (batched mode) -- DEFERRED: every shadow ray writes ONE BYTE, vis[slot] = unoccluded (a dense array: the
+//                stores of a chunk's rays fill whole sectors -- a 4-byte flag inside the 16-byte record, tried first, cost 19
+//                bytes of write traffic per flag); the NEE records of every bounce are kept (one occ_e / vis array per
+//                bounce) and k_fold_nee adds the unoccluded ones to the per-path radiance once per batch, bounce after
+//                bounce -- the same sums in the same order.  Until round 4 every unoccluded ray did a read-modify-write of its
+//                16-byte cell of lsum, scattered over the chunk's 4 KB: whole lines moved per bounce (1.55 x the kernel's
+//                algorithmic bytes), and the any-hit kernel loaded the NEE radiance and the cell beside every ray.
+__device__ __forceinline__ void nee_result(const Streams &st, float4 *acc, size_t slot, uint32_t cell, bool unoccluded) {
+	if (acc) {
+		if (unoccluded) {
+			const float4 e = st.occ_e[slot];
+			float4 a = acc[cell];
+			a.x += e.x; a.y += e.y; a.z += e.z;
+			acc[cell] = a;
+		}
+	} else {
+		st.vis[slot] = unoccluded ? (uint8_t)1 : (uint8_t)0;
+	}
+}
+
 // rayIntersectionTest + accumulateEmissiveSamples (intersect.cl:26-180, pt_integrator.cl:278-296)
-// fused: an unoccluded shadow ray adds its NEE radiance straight to its accumulator cell.
+// fused: an unoccluded shadow ray adds its NEE radiance straight to its accumulator cell (or records its visibility: nee_result).
 __global__ __launch_bounds__(WG) void k_occlusion(Streams st, BvhDev B, float4 *acc, unsigned long long *stats) {
 	__shared__ int stk[kTraversalStack][WG];
 	if (threadIdx.x >= st.cnt_occ[blockIdx.x]) return;
@@ -262,13 +287,7 @@ __global__ __launch_bounds__(WG) void k_occlusion(Streams st, BvhDev B, float4 *
 	const float4 o4 = st.occ_o[slot], d4 = st.occ_d[slot];
 	HitRec h;
 	const bool occluded = traverse<true>(B, xyz(o4), xyz(d4), o4.w, stk, h);
-	if (!occluded) {
-		const float4 e = st.occ_e[slot];
-		float4 *cell = acc + (uint32_t)fbits(d4.w);
-		float4 a = *cell; // one path per cell and launch: plain read-modify-write
-		a.x += e.x; a.y += e.y; a.z += e.z;
-		*cell = a;
-	}
+	nee_result(st, acc, slot, (uint32_t)fbits(d4.w), !occluded);
 	const unsigned long long m = __ballot(!occluded);
 	if (m != 0 && (threadIdx.x & 63) == (__ffsll((long long)m) - 1)) atomicAdd(&stats[ST_UNOCCLUDED], (unsigned long long)__popcll(m));
 }
@@ -445,8 +464,10 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 			// (round 3 A/B: reading the cell only when a ray ends unoccluded moves no fewer bytes -- 2.44 vs 2.40 GB of FETCH_SIZE
 			// per frame: on this scene 90 % of the shadow rays do reach the light, and the 16-byte cells move as whole lines
 			// either way -- and costs 3 % of the kernel's time)
-			const float4 e4 = st.occ_e[slot], a4 = acc[cell];
-			nee = xyz(e4); acc_old = xyz(a4);
+			if (acc) { // (exact mode only; batched mode writes the ray's visibility byte at the end instead: nee_result)
+				const float4 e4 = st.occ_e[slot], a4 = acc[cell];
+				nee = xyz(e4); acc_old = xyz(a4);
+			}
 		}
 		sp = sp0;
 		cur = B.root_ref;
@@ -536,8 +557,12 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 		// ---- phase 2: everything that is not an inner node ------------------------------------------------
 		if (cur == kDone) { // the ray is finished
 			if (ANY_HIT) { // unoccluded: accumulateEmissiveSamples, pt_integrator.cl:278-296 (both operands were fetched at set-up)
-				float *c = reinterpret_cast<float *>(acc + cell);
-				c[0] = acc_old.x + nee.x; c[1] = acc_old.y + nee.y; c[2] = acc_old.z + nee.z;
+				if (acc) {
+					float *c = reinterpret_cast<float *>(acc + cell);
+					c[0] = acc_old.x + nee.x; c[1] = acc_old.y + nee.y; c[2] = acc_old.z + nee.z;
+				} else {
+					st.vis[slot] = 1; // deferred: k_fold_nee adds the ray's NEE record
+				}
 				unocc++;
 			} else {
 				st.hit[slot] = make_float4(best_u, best_v, best_t, ibits(best_tri));
@@ -590,7 +615,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 						if (closer || tie) { best_t = tt; best_u = u; best_v = v; best_tri = fbits(T.e1.w); best_irank = irank; best_trank = trank; }
 					}
 				}
-				if (occluded) cur = kIdle; // shadow ray blocked: nothing to add
+				if (occluded) { cur = kIdle; if (!acc) st.vis[slot] = 0; } // shadow ray blocked: nothing to add
 				else pop();
 			}
 		}
@@ -603,38 +628,42 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 				const int popped = read_ref(sp); // what follows the leaf: read beside the triangles, not after them
 				bool occluded = false;
 				uint32_t i = 0; // (bottom-tested: some lane holds a leaf, and a leaf has at least one triangle)
-				do {
-					if (i < ntri && !occluded) {
-						const TriRec T = B.tris[first + i];
-						const f3 e1 = xyz(T.e1), e2 = xyz(T.e2);
-						const f3 pv = cross(d, e2);
-						const float det = dot(e1, pv);
-						bool ok = !(pm_fabs(det) < kEps);
-						const float idet = rcp_det(det);
-						const f3 tv = o - xyz(T.v0);
-						const float u = dot(tv, pv) * idet;
-						ok = ok && !(u < 0.0f || u > 1.0f);
-						const f3 qv = cross(tv, e1);
-						const float v = dot(d, qv) * idet;
-						ok = ok && !(v < 0.0f || u + v > 1.0f);
-						const float tt = dot(e2, qv) * idet;
-						ok = ok && tt > kEps;
-						if (ANY_HIT) {
-							occluded = ok && tt < maxDist;
-						} else {
-							const uint32_t trank = (uint32_t)fbits(T.v0.w);
-							const bool closer = tt < best_t;
-							const bool tie = tt == best_t && best_tri >= 0 && (irank < best_irank || (irank == best_irank && trank < best_trank));
-							const bool take = ok && (closer || tie);
-							best_t = take ? tt : best_t; best_u = take ? u : best_u; best_v = take ? v : best_v;
-							best_tri = take ? fbits(T.e1.w) : best_tri;
-							best_irank = take ? irank : best_irank; best_trank = take ? trank : best_trank;
-						}
+				// one triangle through Moeller-Trumbore (intersect.cl:255-292) without early exits; updates the lane's hit record
+				auto test_tri = [&](const TriRec &T) {
+					const f3 e1 = xyz(T.e1), e2 = xyz(T.e2);
+					const f3 pv = cross(d, e2);
+					const float det = dot(e1, pv);
+					bool ok = !(pm_fabs(det) < kEps);
+					const float idet = rcp_det(det);
+					const f3 tv = o - xyz(T.v0);
+					const float u = dot(tv, pv) * idet;
+					ok = ok && !(u < 0.0f || u > 1.0f);
+					const f3 qv = cross(tv, e1);
+					const float v = dot(d, qv) * idet;
+					ok = ok && !(v < 0.0f || u + v > 1.0f);
+					const float tt = dot(e2, qv) * idet;
+					ok = ok && tt > kEps;
+					if (ANY_HIT) {
+						occluded = occluded || (ok && tt < maxDist);
+					} else {
+						const uint32_t trank = (uint32_t)fbits(T.v0.w);
+						const bool closer = tt < best_t;
+						const bool tie = tt == best_t && best_tri >= 0 && (irank < best_irank || (irank == best_irank && trank < best_trank));
+						const bool take = ok && (closer || tie);
+						best_t = take ? tt : best_t; best_u = take ? u : best_u; best_v = take ? v : best_v;
+						best_tri = take ? fbits(T.e1.w) : best_tri;
+						best_irank = take ? irank : best_irank; best_trank = take ? trank : best_trank;
 					}
+				};
+				// (round 4 A/B: two triangles per round -- six loads in flight, half the rounds -- where the tree is read from global
+				// memory, and 64-byte triangle records that never straddle a line: both within +-2 % on the terrain, C4 and C5,
+				// profiles/r04_tri_variants_ab.txt)
+				do {
+					if (i < ntri && !occluded) test_tri(B.tris[first + i]);
 					i++;
 				} while (__ballot(i < ntri && !occluded) != 0ull);
 				if (tl) {
-					if (ANY_HIT && occluded) cur = kIdle; // blocked: nothing to add
+					if (ANY_HIT && occluded) { cur = kIdle; if (!acc) st.vis[slot] = 0; } // blocked: nothing to add
 					else {
 						const bool empty = sp == sp0;
 						const uint32_t spm = sp - kRow;
@@ -803,13 +832,7 @@ __global__ __launch_bounds__(WG) void k_trace_packet(Streams st, BvhDev B, float
 	}
 	if (ANY_HIT) {
 		const bool clear = valid && !occluded;
-		if (clear) {
-			const float4 e = st.occ_e[slot];
-			float4 *cell = acc + (uint32_t)fbits(d4.w);
-			float4 a = *cell;
-			a.x += e.x; a.y += e.y; a.z += e.z;
-			*cell = a;
-		}
+		if (valid) nee_result(st, acc, slot, (uint32_t)fbits(d4.w), clear);
 		const unsigned long long m = __ballot(clear);
 		if (lane == 0 && m) atomicAdd(&stats[ST_UNOCCLUDED], (unsigned long long)__popcll(m));
 	} else if (valid) {
@@ -838,6 +861,20 @@ struct ShadeOut {
 	uint32_t hit, miss, emit;       // event flags for the counters
 };
 
+// A path's TERMINAL contribution -- background radiance of a missed ray (pt_integrator.cl:214-275) or the radiance of a directly
+// hit emitter (:101-107): a path gets at most one, at its end.  Exact mode adds it to the trace accumulator in the reference's
+// order.  Batched mode: the per-path cell of lsum holds nothing else until k_fold_nee (the NEE terms are deferred), so it is a
+// plain 16-byte store, not a read-modify-write.
+__device__ __forceinline__ void terminal_add(const ShadeArgs &A, uint32_t cell, f3 add) {
+	if (A.exact) {
+		float4 a = A.acc[cell];
+		a.x += add.x; a.y += add.y; a.z += add.z;
+		A.acc[cell] = a;
+	} else {
+		A.acc[cell] = make_float4(add.x, add.y, add.z, 0.0f);
+	}
+}
+
 // One ray through shadeHits / shade*RayMisses.  `gid_ref` is the ray's position in the reference's
 // compacted buffer (PRNG state, pt_integrator.cl:81), `sample` the sample the workgroup belongs to.
 // The shadow ray (origin|maxDist, dir|accumulator cell, NEE radiance) is handed to `occ_sink` the moment it exists -- the
@@ -861,9 +898,7 @@ __device__ __forceinline__ void shade_ray(const SceneT<LDS> &S, const ShadeArgs 
 			f2 uv = latlong_uv(xyz(d4));
 			f3 kd = mat_color(uv, bg->k, bg->tex, S);
 			f3 add = A.bounce == 0 ? kd : thr * kd;
-			float4 a = A.acc[cell];
-			a.x += add.x; a.y += add.y; a.z += add.z;
-			A.acc[cell] = a;
+			terminal_add(A, cell, add);
 			R.miss = 1;
 		}
 		return;
@@ -891,9 +926,7 @@ __device__ __forceinline__ void shade_ray(const SceneT<LDS> &S, const ShadeArgs 
 	if (m.type == POLARIS_BXDF_EMISSIVE) { // pt_integrator.cl:101-107 (indexed by pixel: SURVEY 5.8)
 		if (in_dot_n > 0.0f) {
 			f3 add = thr * m.nd->scale * m.kcol;
-			float4 a = A.acc[cell];
-			a.x += add.x; a.y += add.y; a.z += add.z;
-			A.acc[cell] = a;
+			terminal_add(A, cell, add);
 			R.emit = 1;
 		}
 		return;
@@ -937,7 +970,7 @@ __device__ __forceinline__ void shade_ray(const SceneT<LDS> &S, const ShadeArgs 
 			e_rad = e_rad * (e_weight * bxdf_e_val * thr * n_dot_e / (e_pdf * sel_pdf)); // :160
 			if (maxcomp(e_rad) > 0.0f) {
 				occ_sink(make_float4(occ_origin.x, occ_origin.y, occ_origin.z, e_dist - kLightEps), // :203
-				         make_float4(e_dir.x, e_dir.y, e_dir.z, ibits((int)cell)), make_float4(e_rad.x, e_rad.y, e_rad.z, 0.0f));
+				         make_float4(e_dir.x, e_dir.y, e_dir.z, ibits((int)cell)), make_float4(e_rad.x, e_rad.y, e_rad.z, ibits((int)cell)));
 			}
 		}
 	}
@@ -1392,6 +1425,48 @@ __global__ __launch_bounds__(1024) void k_scan(Streams st, uint32_t wgs_per_samp
 		for (int w = 0; w < 16; w++) t += red[tid][w];
 		if (t) atomicAdd(&stats[(tid == 0 ? ST_HITS_BOUNCE : (tid == 1 ? ST_MISSES_BOUNCE : ST_EMITTERS_BOUNCE)) + bounce], (unsigned long long)t);
 	}
+}
+
+// accumulateEmissiveSamples (pt_integrator.cl:278-296) for a whole batch at once: one workgroup per chunk adds the NEE records its
+// unoccluded shadow rays left (nee_result: vis), bounce after bounce, to the chunk's 256 per-path cells and writes them back
+// as one coalesced 4 KB store.  A path has at most one shadow ray per bounce, so the adds of one bounce never collide, and the
+// barrier between bounces keeps a path's terms in the reference's order: ((nee_0 + nee_1) + ...) + terminal contribution -- the
+// sums the per-bounce read-modify-writes used to produce, bit for bit.
+struct FoldArgs { const float4 *nee[POLARIS_MAX_BOUNCES]; const uint8_t *vis[POLARIS_MAX_BOUNCES]; const uint32_t *cnt[POLARIS_MAX_BOUNCES]; uint32_t bounces; };
+__global__ __launch_bounds__(WG) void k_fold_nee(FoldArgs F, float4 *lsum) {
+	__shared__ float acc[3][WG];
+	const uint32_t tid = threadIdx.x;
+	const uint32_t base = blockIdx.x * WG;
+	acc[0][tid] = 0.0f; acc[1][tid] = 0.0f; acc[2][tid] = 0.0f;
+	const float4 term = lsum[base + tid]; // the path's terminal contribution (or 0): requested before the records
+	__syncthreads();
+	uint32_t any = 0;
+	// four bounces at a time: their counts, then their records, are requested together (two memory round trips per group, not
+	// two per bounce: the kernel is a chain of dependent loads, 1 GB per batch), the adds stay in bounce order
+	for (uint32_t b0 = 0; b0 < F.bounces; b0 += 4) {
+		uint32_t n[4];
+#pragma unroll
+		for (uint32_t k = 0; k < 4; k++) n[k] = b0 + k < F.bounces ? F.cnt[b0 + k][blockIdx.x] : 0u;
+		float4 r[4];
+		uint32_t v[4];
+#pragma unroll
+		for (uint32_t k = 0; k < 4; k++) {
+			v[k] = 0;
+			r[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			if (tid < n[k]) { v[k] = F.vis[b0 + k][base + tid]; r[k] = F.nee[b0 + k][base + tid]; }
+		}
+#pragma unroll
+		for (uint32_t k = 0; k < 4; k++) {
+			if (v[k]) {
+				const uint32_t local = (uint32_t)fbits(r[k].w) - base; // the ray's path: a cell of this chunk (rays never leave their chunk)
+				acc[0][local] += r[k].x; acc[1][local] += r[k].y; acc[2][local] += r[k].z;
+			}
+			any |= n[k];
+			__syncthreads();
+		}
+	}
+	if (any == 0) return; // (uniform) no shadow ray in any bounce: the cells already hold what they should
+	lsum[base + tid] = make_float4(acc[0][tid] + term.x, acc[1][tid] + term.y, acc[2][tid] + term.z, 0.0f);
 }
 
 // Batch epilogue: trace accumulator += per-path radiance, samples added in ascending order.

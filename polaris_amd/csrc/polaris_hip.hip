@@ -107,6 +107,12 @@ struct polaris_hip_tracer {
 		hipStream_t q = nullptr;
 		size_t slots = 0; // capacity in slots
 		Streams st{};
+		// batched mode: one NEE record array (occ_e) and one shadow-ray count array (cnt_occ) PER BOUNCE, kept until k_fold_nee has
+		// added the batch's unoccluded records to the per-path radiance (kernels.h, nee_unoccluded); [0] are st.occ_e / st.cnt_occ
+		float4 *nee[POLARIS_MAX_BOUNCES] = {};
+		uint8_t *vis[POLARIS_MAX_BOUNCES] = {};
+		uint32_t *cnt_occ_b[POLARIS_MAX_BOUNCES] = {};
+		uint32_t nee_bounces = 0; // how many of them are allocated
 		std::vector<DevBuf> bufs;
 		hipEvent_t done = nullptr; // recorded after the pipe's last resolve
 	};
@@ -304,14 +310,20 @@ hipError_t sync_all(polaris_hip_tracer *h) { // every pipeline of the handle idl
 	return first;
 }
 
-int ensure_streams(polaris_hip_tracer *h, int p, size_t slots, bool want_inst) {
+int ensure_streams(polaris_hip_tracer *h, int p, size_t slots, bool want_inst, uint32_t nee_bounces = 1) {
 	polaris_hip_tracer::Pipe &P = h->pipe[p];
-	if (slots <= P.slots && (!want_inst || P.st.hit_inst)) return POLARIS_OK;
+	nee_bounces = std::max(1u, std::min<uint32_t>(nee_bounces, POLARIS_MAX_BOUNCES));
+	if (slots <= P.slots && (!want_inst || P.st.hit_inst) && nee_bounces <= P.nee_bounces) return POLARIS_OK;
 	slots = std::max(slots, P.slots);
+	nee_bounces = std::max(nee_bounces, P.nee_bounces);
 	HIP_TRY(h, hipStreamSynchronize(P.q));
 	free_pool(P.bufs);
 	P.st = Streams{};
 	P.slots = 0;
+	P.nee_bounces = 0;
+	for (auto &q : P.nee) q = nullptr;
+	for (auto &q : P.vis) q = nullptr;
+	for (auto &q : P.cnt_occ_b) q = nullptr;
 	const size_t wgs = slots / WG;
 	int rc = 0;
 	rc |= dev_alloc(h, P.bufs, &P.st.ray_o, slots);
@@ -329,8 +341,18 @@ int ensure_streams(polaris_hip_tracer *h, int p, size_t slots, bool want_inst) {
 	rc |= dev_alloc(h, P.bufs, &P.st.emask[0], wgs * 8);
 	rc |= dev_alloc(h, P.bufs, &P.st.emask[1], wgs * 8);
 	if (want_inst) rc |= dev_alloc(h, P.bufs, &P.st.hit_inst, slots);
-	if (rc) { free_pool(P.bufs); P.st = Streams{}; return rc; }
+	P.nee[0] = P.st.occ_e;
+	P.cnt_occ_b[0] = P.st.cnt_occ;
+	rc |= dev_alloc(h, P.bufs, &P.vis[0], slots);
+	P.st.vis = P.vis[0];
+	for (uint32_t b = 1; b < nee_bounces; b++) {
+		rc |= dev_alloc(h, P.bufs, &P.nee[b], slots);
+		rc |= dev_alloc(h, P.bufs, &P.vis[b], slots);
+		rc |= dev_alloc(h, P.bufs, &P.cnt_occ_b[b], wgs);
+	}
+	if (rc) { free_pool(P.bufs); P.st = Streams{}; for (auto &q : P.nee) q = nullptr; for (auto &q : P.vis) q = nullptr; for (auto &q : P.cnt_occ_b) q = nullptr; return rc; }
 	P.slots = slots;
+	P.nee_bounces = nee_bounces;
 	return POLARIS_OK;
 }
 
@@ -438,6 +460,8 @@ hipError_t launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest 
 	const uint32_t persistent = grid_of(h->trace_resident_per_cu), persistent_occl = grid_of(h->occl_resident_per_cu);
 	for (uint32_t b = 0; b < B; b++) {
 		Streams S = P.st; // (in place: k_shade / k_shade_wave read a chunk's rays before they write into it)
+		if (!exact) { S.occ_e = P.nee[b]; S.vis = P.vis[b]; S.cnt_occ = P.cnt_occ_b[b]; } // this bounce's NEE records, visibility bytes and shadow-ray counts stay until k_fold_nee
+		float4 *const occl_acc = exact ? A.acc : nullptr;                // batched: unoccluded rays only mark their record (deferred)
 		{
 			Timed t(h, (b == 0 && h->packet_primary) ? "intersect_packet" : "intersect", q);
 			if (h->opt_time_kernels) {
@@ -497,12 +521,20 @@ hipError_t launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest 
 			Timed t(h, "occlusion", q);
 			if (h->opt_time_kernels) h->timer_symbol["occlusion"] = (int)b < h->opt_packet_shadow ? std::string("pol::k_trace_packet<true, false>") : (h->opt_traversal ? trace_symbol<true>(h) : std::string("pol::k_occlusion"));
 			if ((int)b < h->opt_packet_shadow)
-				hipLaunchKernelGGL(k_trace_packet<true>, dim3(wgs), dim3(WG), 0, q, S, h->bvh, A.acc, h->d_stats, h->cam.eye);
+				hipLaunchKernelGGL(k_trace_packet<true>, dim3(wgs), dim3(WG), 0, q, S, h->bvh, occl_acc, h->d_stats, h->cam.eye);
 			else if (h->opt_traversal)
-				note(launch_trace<true>(h, P, S, persistent_occl, wgs, A.acc));
+				note(launch_trace<true>(h, P, S, persistent_occl, wgs, occl_acc));
 			else
-				hipLaunchKernelGGL(k_occlusion, dim3(wgs), dim3(WG), 0, q, S, h->bvh, A.acc, h->d_stats);
+				hipLaunchKernelGGL(k_occlusion, dim3(wgs), dim3(WG), 0, q, S, h->bvh, occl_acc, h->d_stats);
 		}
+	}
+	if (!exact && B > 0) { // accumulateEmissiveSamples of the whole batch: the marked NEE records of every bounce into the per-path radiance
+		FoldArgs F{};
+		for (uint32_t b = 0; b < B; b++) { F.nee[b] = P.nee[b]; F.vis[b] = P.vis[b]; F.cnt[b] = P.cnt_occ_b[b]; }
+		F.bounces = B;
+		Timed t(h, "fold", q);
+		if (h->opt_time_kernels) h->timer_symbol["fold"] = "pol::k_fold_nee";
+		hipLaunchKernelGGL(k_fold_nee, dim3(wgs), dim3(WG), 0, q, F, P.st.lsum);
 	}
 	if (!exact) {
 		// batches resolve into the trace accumulator in sample order: wait for the previous batch's resolve
@@ -841,7 +873,7 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 		else K = std::min<uint32_t>(std::max<uint32_t>(1u, (uint32_t)((32u << 20) / Npad)), std::max(1u, (spp + 1) / 2));
 		K = std::max<uint32_t>(1u, std::min(K, std::max(spp, 1u)));
 	}
-	// The batch buffers are 128 bytes per path slot and up to `overlap`
+	// The batch buffers are 128 bytes per path slot + 16 per bounce (the NEE records are kept per bounce until the batch folds them) and up to `overlap`
 	// batches are in flight: 4.3 GB per pipeline at 33.5 M slots, nothing on a 288 GB MI355X but not on a smaller or shared device.  K chosen automatically is first clamped by the
 	// free device memory and, if an allocation still fails, halved and retried (a caller-chosen samples_per_batch is kept as it
 	// is: its failure is reported).
@@ -849,11 +881,12 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 		size_t free_b = 0, total_b = 0;
 		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
 			size_t have = 0; // what the pipelines already hold counts as available
-			for (auto &P : h->pipe) have += P.slots * (size_t)192;
+			const size_t slot_bytes = 144 + 17 * (size_t)std::max(1u, B); // stream buffers per path slot: 128 B + one NEE record array per bounce (+ the per-chunk words)
+			for (auto &P : h->pipe) have += P.slots * (144 + 17 * (size_t)std::max(1u, P.nee_bounces));
 			const size_t pipes = (size_t)std::max(1, std::min(h->opt_overlap, (int)polaris_hip_tracer::kMaxPipes));
 			const size_t budget = (free_b + have) / 10 * 9;
 			// (batches in flight = min(overlap, #batches): it grows towards `overlap` as K shrinks, so it is recomputed per step)
-			auto need = [&](uint32_t k) { return (size_t)k * Npad * 192 * std::min<size_t>(pipes, (spp + k - 1) / k); };
+			auto need = [&](uint32_t k) { return (size_t)k * Npad * slot_bytes * std::min<size_t>(pipes, (spp + k - 1) / k); };
 			while (K > 1 && need(K) > budget) K = (K + 1) / 2;
 		}
 	}
@@ -863,12 +896,12 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 		n_batches = spp ? (spp + K - 1) / K : 0;
 		n_pipes = exact ? 1 : (int)std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)h->opt_overlap, n_batches));
 		int rc = POLARIS_OK;
-		for (int p = 0; p < n_pipes && rc == POLARIS_OK; p++) rc = ensure_streams(h, p, (size_t)K * Npad, false);
+		for (int p = 0; p < n_pipes && rc == POLARIS_OK; p++) rc = ensure_streams(h, p, (size_t)K * Npad, false, exact ? 1u : B);
 		if (rc == POLARIS_OK) break;
 		if (exact || h->opt_samples_per_batch > 0 || K == 1) return rc;
 		(void)hipGetLastError(); // out of memory: release every pipeline's buffers, halve the batch, try again
 		for (auto &P : h->pipe)
-			if (P.q && P.slots) { (void)hipStreamSynchronize(P.q); free_pool(P.bufs); P.st = Streams{}; P.slots = 0; }
+			if (P.q && P.slots) { (void)hipStreamSynchronize(P.q); free_pool(P.bufs); P.st = Streams{}; P.slots = 0; P.nee_bounces = 0; for (auto &x : P.nee) x = nullptr; for (auto &x : P.vis) x = nullptr; for (auto &x : P.cnt_occ_b) x = nullptr; }
 		K = (K + 1) / 2;
 	}
 	if (need_seeds > h->seeds_cap) {

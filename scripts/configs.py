@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """scripts/configs.py -- the BASELINE.json configurations on ONE MI355X (run inside gpurun), one bench.py run each:
 Mrays/s and ms/frame into profiles/<round>_configs.json.  The frame sizes are BASELINE.json's; where the full sample
-count would take minutes (C4: 512 spp, C5: 1024 spp) a stated fraction of it is traced -- throughput per frame does
-not depend on the sample count once a batch is full (samples are traced K at a time).
+count is large (C4: 512 spp, C5: 1024 spp = 2^32 primary samples) fewer timed frames are taken; every configuration runs at
+its FULL frame size and sample count.
 
     python scripts/configs.py r02            # -> profiles/r02_configs.json
 """
@@ -19,7 +19,9 @@ CONFIGS = [
     ("C3", "layered Cornell box 1024x1024x256spp (configs[2])", ["--width", "1024", "--height", "1024", "--spp", "256"]),
     ("C4", "material-ball (58,682 tris; stand-in for the Mitsuba scene) 1920x1080x512spp (configs[3])",
      ["--scene", "material-ball", "--width", "1920", "--height", "1080", "--spp", "512", "--steps", "2"]),
-    ("C5", "instanced (1,060-tri mesh x 1,024 instances = 1.09 M tris) 2048x2048, 16 of 1024 spp (configs[4])",
+    ("C5", "instanced (1,060-tri mesh x 1,024 instances = 1.09 M tris) 2048x2048x1024spp: 2^32 primary samples per frame (configs[4])",
+     ["--scene", "instanced", "--width", "2048", "--height", "2048", "--spp", "1024", "--steps", "2"]),
+    ("C5-16spp", "the same scene and frame at 16 of its 1024 spp (the line of rounds 1-3)",
      ["--scene", "instanced", "--width", "2048", "--height", "2048", "--spp", "16"]),
     ("terrain", "terrain (1.0 M unique triangles: real HBM gathers) 1024x1024x32spp", ["--scene", "terrain", "--width", "1024", "--height", "1024", "--spp", "32"]),
 ]

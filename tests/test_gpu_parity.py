@@ -541,6 +541,44 @@ def test_full_frame_sizes_of_the_other_configs(built, name, W, H, spp):
     assert lit[H // 2] and lit[: H // 4].any() and lit[-(H // 4):].any() and lit.mean() > 0.5
 
 
+@pytest.mark.parametrize("name,W,H,spp", [("material-ball", 1920, 1080, 512),   # C4 at its full sample count: 1.06 G primary samples
+                                          ("instanced", 2048, 2048, 1024)])    # C5: EXACTLY 2^32 primary samples
+def test_full_sample_counts_of_c4_and_c5(built, name, W, H, spp):
+    """BASELINE.json configs[3] and [4] at their FULL sample counts, one Trace each.  C5's 2048 x 2048 x 1024 spp is exactly 2^32
+    primary rays: the boundary SURVEY.md 8 flags -- the reference's ray counters are u32 and the path index travels as a float
+    (util/ray.cl:9-11); here every counter is 64-bit, a batch holds at most 2^25 path slots and a block at most 2^24 pixels, so
+    nothing wraps: primary_rays == W * H * spp exactly, every per-bounce counter identical between two runs and between 1 and
+    4 batches in flight, the accumulators bit-identical (same batch shapes => same order of every float sum), finite and
+    non-negative."""
+    from oracle import pybind as ob
+    from polaris_amd import scenes
+
+    sc = scenes.SCENES[name](W / H)
+    B = 5
+    seeds = scenes.make_seeds(spp, B)
+    outs, cnts, ms = [], [], []
+    for opts in ({}, {}, {"overlap": 1}):
+        tr = make_hip_tracer(sc, W, H, **opts)
+        try:
+            tr.Trace(ob.make_request(W, H, spp=spp, bounces=B, rr=3), seeds)
+            st = tr.last_trace_stats
+            outs.append(tr.read_accumulator(0))
+            cnts.append(counters(st, B))
+            ms.append(st.device_ms)
+            assert st.primary_rays == W * H * spp and st.rays_per_bounce[0] == W * H * spp
+            assert st.primary_rays + st.indirect_rays + st.occlusion_rays == st.total_rays() > 2 * W * H * spp
+            assert sum(st.rays_per_bounce[1:B]) == st.indirect_rays and sum(st.occl_per_bounce[:B]) == st.occlusion_rays
+            assert 0 < st.shaded_hits and st.shaded_hits + st.shaded_misses <= st.primary_rays + st.indirect_rays   # (misses count only where a background exists)
+        finally:
+            tr.Close()
+    if name == "instanced":
+        assert cnts[0][2] == 2 ** 32
+    assert cnts[0] == cnts[1] == cnts[2]
+    assert np.array_equal(bits(outs[0]), bits(outs[1])) and np.array_equal(bits(outs[0]), bits(outs[2]))
+    assert np.isfinite(outs[0]).all() and (outs[0][..., :3] >= 0).all() and outs[0][..., :3].mean() > 0
+    print(f"{name} {W}x{H}x{spp}spp: {cnts[0][2] + cnts[0][3] + cnts[0][4]} rays, device ms per Trace {[round(v, 1) for v in ms]}")
+
+
 @pytest.mark.parametrize("name", ["cornell", "sphere"])
 def test_headline_frame_against_the_oracle(built, oracle, name):
     """BASELINE.json's headline workload (and configs[1], the diffuse sphere) at FULL size -- layered Cornell box, 512x512, 128 spp, 5

@@ -9,6 +9,9 @@
 //          quad64   four lanes = one chain, 64-B records (1 load per lane: the quad reads one contiguous line segment)
 //          quad128  four lanes = one chain, 128-B records (2 loads per lane: a four-wide node, one box per lane)
 //          pair128  two lanes = one chain, 128-B records (4 loads per lane)
+//          lane32   one lane = one chain, 32-B records  (2 loads: a pair node with both boxes quantised to 16 bits per coordinate)
+//          lane48   one lane = one chain, 48-B records  (3 loads)
+//          lane16   one lane = one chain, 16-B records  (1 load: the floor of a per-lane gather)
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -17,15 +20,16 @@
 #include <random>
 #include <vector>
 
-enum Shape { kLane64 = 0, kLane128, kQuad64, kQuad128, kPair128, kShapes };
-static const char *kShapeName[kShapes] = {"lane64", "lane128", "quad64", "quad128", "pair128"};
+enum Shape { kLane64 = 0, kLane128, kQuad64, kQuad128, kPair128, kLane32, kLane48, kLane16, kShapes };
+static const char *kShapeName[kShapes] = {"lane64", "lane128", "quad64", "quad128", "pair128", "lane32", "lane48", "lane16"};
+static const int kShapeRecBytes[kShapes] = {64, 128, 64, 128, 128, 32, 48, 16};
 
 // record r starts with the index of the next record of the chain that passes through it (a random permutation cycle), the rest
 // is payload that is summed so the loads cannot be dropped
 template <int SHAPE>
 __global__ __launch_bounds__(256) void walk(const float4 *table, uint32_t num_records, int steps, uint32_t live_mask, float *out) {
-	constexpr int REC4 = (SHAPE == kLane64 || SHAPE == kQuad64) ? 4 : 8;           // float4s per record
-	constexpr int TEAM = (SHAPE == kLane64 || SHAPE == kLane128) ? 1 : (SHAPE == kPair128 ? 2 : 4); // lanes per chain
+	constexpr int REC4 = SHAPE == kLane32 ? 2 : SHAPE == kLane48 ? 3 : SHAPE == kLane16 ? 1 : (SHAPE == kLane64 || SHAPE == kQuad64) ? 4 : 8; // float4s per record
+	constexpr int TEAM = (SHAPE == kQuad64 || SHAPE == kQuad128) ? 4 : (SHAPE == kPair128 ? 2 : 1); // lanes per chain
 	constexpr int PER = REC4 / TEAM;                                               // float4 loads per lane and step
 	const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t lane = threadIdx.x & 63;
@@ -57,10 +61,10 @@ int main(int argc, char **argv) {
 	hipMalloc(&out, sizeof(float) * (size_t)cus * 8 * 256 * 4);
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0); hipEventCreate(&e1);
-	const size_t table_bytes[] = {1u << 20, 24u << 20};
+	const size_t table_bytes[] = {1u << 20, 3u << 20, 24u << 20, 96u << 20};
 	std::mt19937 rng(7);
 	for (size_t tb : table_bytes) {
-		for (int rec_bytes : {64, 128}) {
+		for (int rec_bytes : {16, 32, 48, 64, 128}) {
 			const uint32_t n = (uint32_t)(tb / rec_bytes);
 			// one random cycle through all records (Sattolo): every chain step lands on a fresh, uniformly distributed record
 			std::vector<uint32_t> perm(n);
@@ -72,16 +76,16 @@ int main(int argc, char **argv) {
 			hipMalloc(&table, (size_t)n * rec_bytes);
 			hipMemcpy(table, host.data(), (size_t)n * rec_bytes, hipMemcpyHostToDevice);
 			for (int shape = 0; shape < kShapes; shape++) {
-				const bool is128 = shape == kLane128 || shape == kQuad128 || shape == kPair128;
-				if (is128 != (rec_bytes == 128)) continue;
-				const int team = (shape == kLane64 || shape == kLane128) ? 1 : (shape == kPair128 ? 2 : 4);
+				if (kShapeRecBytes[shape] != rec_bytes) continue;
+				const int team = (shape == kQuad64 || shape == kQuad128) ? 4 : (shape == kPair128 ? 2 : 1);
 				for (uint32_t live : {0xFFFFFFFFu, 0x55555555u, 0x11111111u}) {
 					for (int wps : {2, 4, 8}) {
 						const int blocks = cus * wps;
 						float ms = 0;
 						for (int rep = 0; rep < 2; rep++) {
 							hipEventRecord(e0);
-							void (*fn)(const float4 *, uint32_t, int, uint32_t, float *) = shape == kLane64 ? walk<kLane64> : shape == kLane128 ? walk<kLane128> : shape == kQuad64 ? walk<kQuad64> : shape == kQuad128 ? walk<kQuad128> : walk<kPair128>;
+							void (*fn)(const float4 *, uint32_t, int, uint32_t, float *) = shape == kLane64 ? walk<kLane64> : shape == kLane128 ? walk<kLane128> : shape == kQuad64 ? walk<kQuad64> : shape == kQuad128 ? walk<kQuad128> :
+								shape == kPair128 ? walk<kPair128> : shape == kLane32 ? walk<kLane32> : shape == kLane48 ? walk<kLane48> : walk<kLane16>;
 							hipLaunchKernelGGL(fn, dim3(blocks), dim3(256), 0, 0, table, n, steps, live, out);
 							hipEventRecord(e1);
 							hipEventSynchronize(e1);
