@@ -151,14 +151,15 @@ __device__ __forceinline__ float slab_entry(float4 lo, float4 hi, f3 o, f3 inv, 
 
 struct HitRec { float t, u, v; int tri; int inst; uint32_t irank, trank; };
 
-// A leaf reference is ~code.  code & 15 = triangle count (1..15) and code >> 4 = first triangle slot:
-// the common case costs no fetch.  code & 15 == 0: look the leaf up by node id (code >> 4) --
-// instance leaves (count 0) and leaves of more than 15 triangles.  Returns (-first | -instance, count).
+// A leaf reference is ~code (scene_layout.h).  code & 15 = triangle count (1..15) and code >> 4 = first triangle slot: the
+// common case costs no fetch.  code & 15 == 0: a top-level leaf, code >> 4 = the mesh instance -- unless kBigLeafFlag is set:
+// a leaf of more than 15 triangles, looked up by node id.  Returns (-first | -instance, count).
 __device__ __forceinline__ int2 leaf_of(const BvhDev &B, int ref) {
 	const uint32_t code = (uint32_t)~ref;
 	const uint32_t cnt = code & 15u;
 	if (cnt) return make_int2(-(int)(code >> 4), (int)cnt);
-	return B.leaves[code >> 4];
+	if (!(code & kBigLeafFlag)) return make_int2(-(int)(code >> 4), 0);
+	return B.leaves[(code & (kBigLeafFlag - 1u)) >> 4];
 }
 
 template <bool ANY_HIT>
@@ -402,6 +403,11 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 	constexpr int BLOCK = TINY ? kTinyBlock : WG; // threads per workgroup (a CHUNK of rays is always WG = 256 slots)
 	typedef typename std::conditional<TINY, int16_t, int>::type StackEntry;
 	constexpr int EXIT = TINY ? kTinyExitMarker : kExitMarker; // the instance exit marker as this variant's stack holds it
+	// A ray that leaves an instance with more to do gets its world-space ray back (intersect.cl:330-335).  Where the register
+	// budget allows (every variant but the tiny mode, which sits at 64 VGPRs for 8 waves) it is kept in six registers; the tiny
+	// mode re-reads it from the ray streams.  In a scene of many instances a ray enters and leaves several: two dependent
+	// gathers per exit (and, until round 4, one more per entry for the instance id) were a third of the lines such a ray touched.
+	constexpr bool KEEP_WORLD = !TINY;
 	// The per-lane node stack: a column of an LDS array.  A lane keeps its stack pointer as the BYTE OFFSET of its top entry
 	// (sp0 = empty, + kRow per entry), so a pop reads at `sp` and a push writes at `sp + kRow` with no address arithmetic;
 	// row 0 is a dummy, so that "the entry below an empty stack" can be read (and ignored) without a clamp.
@@ -440,6 +446,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 	float best_t = 0.0f, best_u = 0.0f, best_v = 0.0f;
 	int best_tri = -1;
 	uint32_t best_irank = 0, best_trank = 0;
+	f3 wo = {0, 0, 0}, wd = {0, 0, 0}; // KEEP_WORLD: the world-space ray
 	f3 nee = {0, 0, 0}, acc_old = {0, 0, 0}; // any hit: the NEE radiance of the shadow ray and its accumulator cell, both fetched at set-up
 
 	// next pending node of the lane's ray: the popped reference, or kDone when nothing is pending -- an instance's exit
@@ -456,6 +463,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 	auto start_ray = [&](uint32_t ray_slot, float4 o4, float4 d4) {
 		slot = ray_slot;
 		o = xyz(o4); d = xyz(d4);
+		if (KEEP_WORLD) { wo = o; wd = d; }
 		maxDist = o4.w;
 		cell = fbits(d4.w);
 		if (ANY_HIT) {
@@ -570,15 +578,18 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 			cur = kIdle;
 		}
 		if (cur == EXIT) { // leaving the instance: back to the world-space ray (intersect.cl:330-335)
-			const float4 o4 = src_o[slot], d4 = src_d[slot];
-			o = xyz(o4); d = xyz(d4);
+			if (KEEP_WORLD) { o = wo; d = wd; }
+			else {
+				const float4 o4 = src_o[slot], d4 = src_d[slot];
+				o = xyz(o4); d = xyz(d4);
+			}
 			inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)};
 			pop();
 		}
-		if (cur < 0 && cur >= kFirstLeafRef && (((uint32_t)~cur) & 15u) == 0u) { // leaf described by LeafInfo
-			const int2 li = B.leaves[((uint32_t)~cur) >> 4];
-			if (li.y == 0) { // top-level leaf: enter the mesh instance (intersect.cl:239-252)
-				const InstRec I = B.insts[-li.x];
+		if (cur < 0 && cur >= kFirstLeafRef && (((uint32_t)~cur) & 15u) == 0u) { // a top-level leaf, or a leaf of more than 15 triangles
+			const uint32_t code = (uint32_t)~cur;
+			if (!(code & kBigLeafFlag)) { // top-level leaf: enter the mesh instance (intersect.cl:239-252); its id is in the reference
+				const InstRec I = B.insts[code >> 4];
 				irank = (uint32_t)I.meta.y;
 				push_ref(sp, EXIT);
 				sp += kRow;
@@ -591,6 +602,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 				inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)};
 				cur = I.meta.x;
 			} else { // more than 15 triangles: re-filed as a run of inline leaves is not possible (count > 15): walk it here
+				const int2 li = B.leaves[(code & (kBigLeafFlag - 1u)) >> 4];
 				bool occluded = false;
 				for (int t = -li.x; t < -li.x + li.y && !occluded; t++) {
 					const TriRec T = B.tris[t];

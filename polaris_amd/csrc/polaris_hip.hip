@@ -764,10 +764,10 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 	if (rc) { free_pool(h->scene_bufs); return rc; }
 	HIP_TRY(h, hipStreamSynchronize(h->stream)); // host vectors in L die at return
 	h->bvh = BvhDev{pairs, (uint32_t)L.pairs.size(), leaves, tris, insts, L.root_ref, 0, InstRec{}};
-	if (L.root_ref < 0 && (((uint32_t)~L.root_ref) & 15u) == 0u) { // the top-level tree is a single leaf ...
-		const LeafInfoH &li = L.leaves[((uint32_t)~L.root_ref) >> 4];
-		if (li.rdata == 0 && (size_t)(-(int64_t)li.ldata) < L.insts.size()) { // ... and that leaf is an instance: its record goes with the kernel arguments
-			const InstH &I = L.insts[(size_t)(-(int64_t)li.ldata)];
+	if (L.root_ref < 0 && (((uint32_t)~L.root_ref) & 15u) == 0u && !(((uint32_t)~L.root_ref) & kBigLeafFlag)) { // the top-level tree is a single leaf ...
+		const size_t root_inst = ((uint32_t)~L.root_ref) >> 4; // (... which, in the top-level tree, is an instance: its id is in the reference)
+		if (root_inst < L.insts.size()) { // its record goes with the kernel arguments
+			const InstH &I = L.insts[root_inst];
 			h->bvh.root_is_instance = 1;
 			h->bvh.root_inst.r0 = make_float4(I.r0[0], I.r0[1], I.r0[2], I.r0[3]);
 			h->bvh.root_inst.r1 = make_float4(I.r1[0], I.r1[1], I.r1[2], I.r1[3]);
@@ -785,7 +785,8 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 	// -5 % frame time on the 1 024-instance scene, -26 % on the 1 M-triangle terrain
 	if (h->opt_packet_primary < 0) h->packet_primary = sc->num_triangles <= 262144u && sc->num_mesh_instances == 1;
 	// node records: whole tree in LDS for tiny scenes, its top for small ones, global memory otherwise (kernels.h NodeMode)
-	const bool tiny_ok = L.pairs.size() <= (size_t)kTinyPairs && L.tris.size() <= kTinyMaxIndex && L.leaves.size() <= kTinyMaxIndex && L.max_stack <= 16;
+	// (16-bit stack entries: triangle slots and instance ids must fit 11 bits, and no leaf reference may carry kBigLeafFlag)
+	const bool tiny_ok = L.pairs.size() <= (size_t)kTinyPairs && L.tris.size() <= kTinyMaxIndex && L.insts.size() <= kTinyMaxIndex && L.big_leaves == 0 && L.max_stack <= 16;
 	h->node_mode = tiny_ok ? kNodesLdsAll : (L.pairs.size() <= (size_t)(POLARIS_LDS_TOP_MAX_PAIRS) ? kNodesLdsTop : kNodesGlobal);
 	if (h->opt_node_mode >= 0 && (h->opt_node_mode != kNodesLdsAll || tiny_ok)) h->node_mode = h->opt_node_mode;
 	h->trace_resident_per_cu = trace_occupancy<false>(h);

@@ -12,7 +12,9 @@
 //     kernels/intersect.cl:296-298) plus a tagged reference per child:
 //         ref >= 0  -> inner node index          ref < 0 -> ~code of a leaf:
 //         code = first triangle slot << 4 | triangle count (1..15): no fetch needed to start testing;
-//         code = node index << 4 | 0: LeafInfo[node] has the details (instance leaves, leaves of > 15 triangles)
+//         code = mesh instance << 4 | 0: a top-level leaf -- the instance id is in the reference itself (until round 4 it was
+//                looked up: one dependent fetch per instance a ray enters);
+//         code = 1 << 30 | node index << 4 | 0: a leaf of more than 15 triangles, LeafInfo[node] has first / count
 //     and a cull factor per child (1.001, or +inf when the box does not bound its subtree).
 //   * LeafInfo[node] = (ldata, rdata) of a leaf: 8 B fetch when a leaf is popped.
 //   * Tri[slot] = {v0 | rank, e01 = v1 - v0 | scene triangle index, e02 = v2 - v0}: the two edge subtractions of
@@ -49,9 +51,12 @@ constexpr float kMaxCoordinate = 1099511627776.0f; // 2^40: largest vertex coord
 constexpr float kMaxMatrixEntry = 1073741824.0f;   // 2^30: largest entry of an instance matrix
 constexpr int kTraversalStack = 32; // entries per ray, == BVH_MAX_STACK_SIZE (intersect.cl:4)
 
+constexpr uint32_t kBigLeafFlag = 1u << 30; // leaf code: count nibble 0 and this bit = "look the triangle range up in LeafInfo[node]"
+
 struct SceneLayout {
 	std::vector<PairNodeH> pairs;   // inner nodes only, in breadth-first order (the first kLdsTopNodes are staged in LDS)
-	std::vector<LeafInfoH> leaves;  // indexed by node id (only leaves meaningful)
+	std::vector<LeafInfoH> leaves;  // indexed by node id (only leaves meaningful; the kernels read it for leaves of > 15 triangles only)
+	uint32_t big_leaves = 0;        // reachable leaves of more than 15 triangles (the tiny-scene traversal mode excludes them)
 	std::vector<TriH> tris;
 	std::vector<InstH> insts;
 	int32_t root_ref = 0;
@@ -135,7 +140,8 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out, in
 	if (!sc.mesh_instances || NI == 0) return "scene has no mesh instances";
 	if (NT == 0 || !sc.vertices || !sc.normals || !sc.uvs || !sc.material_index) return "scene has no triangles";
 	if (NT > (1u << 30)) return "too many triangles";
-	if (NN >= (1u << 27)) return "too many BVH nodes";
+	if (NN >= (1u << 26)) return "too many BVH nodes";
+	if (NI >= (1u << 26)) return "too many mesh instances";
 	if (sc.num_material_nodes == 0 || !sc.material_nodes) return "scene has no material nodes";
 	if (sc.num_emissives && !sc.emissives) return "emissive list pointer is null";
 	if (sc.num_textures && (!sc.texture_meta || !sc.texture_data)) return "texture pointers are null";
@@ -215,8 +221,9 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out, in
 		const PolarisBvhNode &n = nodes[idx];
 		if (!is_leaf(n)) return idx;
 		const uint32_t first = (uint32_t)(-(int64_t)n.ldata);
-		if (n.rdata >= 1 && n.rdata <= 15 && first < (1u << 27) - 1u) return ~(int32_t)((first << 4) | (uint32_t)n.rdata);
-		return ~(int32_t)((uint32_t)idx << 4);
+		if (n.rdata == 0) return ~(int32_t)(first << 4);                     // top-level leaf: first = the mesh instance (< 2^26: checked below)
+		if (n.rdata >= 1 && n.rdata <= 15 && first < (1u << 26) - 1u) return ~(int32_t)((first << 4) | (uint32_t)n.rdata);
+		return ~(int32_t)(kBigLeafFlag | ((uint32_t)idx << 4));             // (node ids < 2^26: checked below)
 	};
 
 	// iterative left-first DFS from `root`; level = 0 top tree, 1 bottom tree.  `need` tracks the
@@ -252,6 +259,7 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out, in
 					if (n.rdata < 0) { err = "negative triangle count"; return false; }
 					const uint64_t first = (uint64_t)(-(int64_t)n.ldata);
 					if (first + (uint64_t)n.rdata > n_slots) { err = "leaf triangle range out of bounds"; return false; }
+					if (pass == 2 && n.rdata > 15) out.big_leaves++;
 					if (pass == 1) {
 						if (leaf_root[it.node] < 0) leaf_root[it.node] = root;
 						for (uint64_t t = first; t < first + (uint64_t)n.rdata; t++)
@@ -417,7 +425,7 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out, in
 				work.push_back({l + 1, mid, rg.hi});
 			}
 		}
-		if (nodes.size() >= (1ull << 27)) return "too many BVH nodes";
+		if (nodes.size() >= (1ull << 26)) return "too many BVH nodes";
 	}
 	if (!subdivided) { // nothing to do: keep the caller's tree and triangle order
 		nodes.assign(sc.bvh_nodes, sc.bvh_nodes + NN);

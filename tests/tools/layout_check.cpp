@@ -83,7 +83,8 @@ int layout_check_traverse(const PolarisSceneView *sc, int max_leaf_tris, const f
 				if (h0 || h1) { cur = h0 ? c0 : c1; continue; }
 			} else {
 				const uint32_t code = (uint32_t)~cur; // kernels.h leaf_of()
-				const LeafInfoH li = (code & 15u) ? LeafInfoH{-(int32_t)(code >> 4), (int32_t)(code & 15u)} : L.leaves[code >> 4];
+				const LeafInfoH li = (code & 15u) ? LeafInfoH{-(int32_t)(code >> 4), (int32_t)(code & 15u)}
+				                   : (!(code & kBigLeafFlag) ? LeafInfoH{-(int32_t)(code >> 4), 0} : L.leaves[(code & (kBigLeafFlag - 1u)) >> 4]);
 				if (li.rdata == 0) {
 					inst = -li.ldata;
 					const InstH &I = L.insts[inst];
