@@ -205,6 +205,9 @@ def main() -> None:
     ap.add_argument("--bounces", type=int, default=5)
     ap.add_argument("--rr", type=int, default=3)
     ap.add_argument("--samples-per-batch", type=int, default=0)
+    ap.add_argument("--bvh", default="scene", choices=("scene", "device"), help="`device`: the scene's two-level BVH is rebuilt on the GPU before the upload "
+                    "(polaris_hip_build_bvh: an LBVH; an alternative producer, not the headline's tree)")
+    ap.add_argument("--bvh-max-leaf", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--save-png", default="")
@@ -282,6 +285,13 @@ def main() -> None:
 
     W, H, spp, B = args.width, args.height, args.spp, args.bounces
     sc = scenes.SCENES[args.scene](W / H)
+    bvh_info = None
+    if args.bvh == "device":
+        from polaris_amd import bvh_build
+
+        t_b = time.perf_counter()
+        sc, bvh_info = bvh_build.rebuild_on_device(sc, max_leaf_tris=args.bvh_max_leaf, device=local_rank)
+        bvh_info["wall_ms_with_permutation"] = (time.perf_counter() - t_b) * 1e3
     seeds = scenes.make_seeds(spp, B)
     rows = naive_rows(world, H)                      # tracer/scheduler.go:83-106, equal speeds
     block_y, block_h = block_of(rank, rows)
@@ -473,7 +483,7 @@ def main() -> None:
                                    f"strips to the primary + tonemap",
                        "ranks": world, "scheduler": "naive" if world == 1 else args.scheduler,
                        "rows_first_timed_frame": rows_log[0] if rows_log else None, "rows_last_frame": rows_log[-1] if rows_log else None,
-                       "exchange": exchange, "perfect_scheduler" if (second or {}).get("scheduler") == "perfect" else "second_scheduler": second,
+                       "bvh": "as compiled with the scene" if bvh_info is None else {"built_on_device": bvh_info}, "exchange": exchange, "perfect_scheduler" if (second or {}).get("scheduler") == "perfect" else "second_scheduler": second,
                        "frame": [W, H], "spp": spp, "bounces": B, "rays_per_frame": rays // args.steps,
                        "paths_per_s": W * H * spp * args.steps / elapsed},
         }

@@ -244,6 +244,35 @@ int polaris_hip_probe_intersect(polaris_hip_tracer *h, const float *rays, uint32
 int polaris_hip_selftest_rcp(polaris_hip_tracer *h, float lo, float hi, uint64_t *mismatches_inside, uint64_t *mismatches_outside,
                              uint32_t *sample);
 
+/*
+ * BVH construction on the device -- an ALTERNATIVE producer of the scene's two-level BVH (the stretch; the
+ * reference's own builder, asset/compiler/bvh/bvh_builder.go:100-308, scores ~1024 / (depth + 1) candidate planes per axis with
+ * one goroutine each and is restated for the CPU in polaris_amd/host/scene_compiler.cpp).  A linear BVH: Morton order of the
+ * centroids, one radix sort, all inner nodes at once (Karras 2012), boxes fitted bottom-up, subtrees of up to max_leaf_tris
+ * triangles collapsed into the reference's kind of leaf.  One tree per mesh over its triangles, one over the instances' world
+ * boxes with one instance per leaf (compiler.go:88-103).  Output in the reference's encoding (PolarisBvhNode; node 0 = the scene's
+ * root), ready for PolarisSceneView once the caller has put the triangle arrays in the new order:
+ *   tri_order[new position] = old triangle index (a permutation within every mesh's range; emissive tri_index values follow it);
+ *   mesh_root[m] = the node a PolarisMeshInstance.bvh_root of mesh m must name.
+ * nodes_capacity >= 2 * (num_instances + num_triangles).  The tree differs from the reference compiler's (another algorithm) --
+ * parity is defined on the uploaded arrays, and any tree whose boxes bound their contents is traversed correctly.
+ * device_ms (may be NULL) = the build on the device, vertices resident, without the read-back.  No tracer handle is involved.
+ */
+typedef struct PolarisBvhBuildInput {
+	const float *vertices;          /* float4 per vertex, 3 per triangle, as PolarisSceneView.vertices */
+	uint32_t num_triangles;
+	const uint32_t *mesh_first_tri; /* [num_meshes]: mesh m owns triangles [first, first + count); the ranges tile [0, num_triangles) in order */
+	const uint32_t *mesh_num_tris;
+	uint32_t num_meshes;
+	const float *instance_boxes;    /* [num_instances][6]: world-space min.xyz, max.xyz of every mesh instance (the scene reader's boxes) */
+	const uint32_t *instance_mesh;  /* [num_instances] */
+	uint32_t num_instances;
+	uint32_t max_leaf_tris;         /* 1..15 */
+} PolarisBvhBuildInput;
+int polaris_hip_build_bvh(int device, const PolarisBvhBuildInput *in, PolarisBvhNode *nodes, uint32_t nodes_capacity, uint32_t *num_nodes,
+                          uint32_t *tri_order, uint32_t *mesh_root, double *device_ms);
+const char *polaris_hip_build_bvh_error(void); /* text of the calling thread's last polaris_hip_build_bvh failure */
+
 /* With option time_kernels=1: accumulated device milliseconds and launch count of the named
  * timer since the last call for that name.  Timers: "generate", "intersect_packet" (camera rays through
  * the wave-packet kernel), "intersect" (closest hit), "shade_first" / "shade_sort" /

@@ -105,6 +105,16 @@ class IpcExport(C.Structure):
 assert C.sizeof(IpcExport) == 32 + 64 * IPC_MAX_DEPTH + 64
 
 
+class BvhBuildInput(C.Structure):
+    """PolarisBvhBuildInput (include/polaris_hip.h): what polaris_hip_build_bvh builds the two-level BVH from."""
+    _fields_ = [
+        ("vertices", C.c_void_p), ("num_triangles", C.c_uint32),
+        ("mesh_first_tri", C.c_void_p), ("mesh_num_tris", C.c_void_p), ("num_meshes", C.c_uint32),
+        ("instance_boxes", C.c_void_p), ("instance_mesh", C.c_void_p), ("num_instances", C.c_uint32),
+        ("max_leaf_tris", C.c_uint32),
+    ]
+
+
 def _ptr(a):
     return None if a is None or a.size == 0 else a.ctypes.data_as(C.c_void_p)
 
@@ -136,7 +146,7 @@ C_ABI_SYMBOLS = [
     "polaris_hip_selftest_rcp", "polaris_hip_reset_epoch", "polaris_hip_wait_reset",
     "polaris_hip_kernel_symbol", "polaris_hip_shade_counts",
     "polaris_hip_ipc_export", "polaris_hip_ipc_open", "polaris_hip_ipc_close", "polaris_hip_merge_ipc",
-    "polaris_hip_trace_slot", "polaris_hip_merge_slot",
+    "polaris_hip_trace_slot", "polaris_hip_merge_slot", "polaris_hip_build_bvh", "polaris_hip_build_bvh_error",
 ]
 
 _lib = None
@@ -226,6 +236,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.polaris_hip_merge_ipc.argtypes = [vp, vp, u32, C.POINTER(BlockRequest)]
     lib.polaris_hip_trace_slot.argtypes = [vp, C.POINTER(u32)]
     lib.polaris_hip_merge_slot.argtypes = [vp, vp, u32, C.POINTER(BlockRequest)]
+    lib.polaris_hip_build_bvh.argtypes = [i32, C.POINTER(BvhBuildInput), vp, u32, C.POINTER(u32), vp, vp, C.POINTER(C.c_double)]
+    lib.polaris_hip_build_bvh_error.restype = C.c_char_p
     for name in C_ABI_SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ("polaris_hip_device_count", "polaris_hip_abi_version"):
