@@ -248,8 +248,10 @@ int polaris_hip_selftest_rcp(polaris_hip_tracer *h, float lo, float hi, uint64_t
  * BVH construction on the device -- an ALTERNATIVE producer of the scene's two-level BVH (the stretch; the
  * reference's own builder, asset/compiler/bvh/bvh_builder.go:100-308, scores ~1024 / (depth + 1) candidate planes per axis with
  * one goroutine each and is restated for the CPU in polaris_amd/host/scene_compiler.cpp).  A linear BVH: Morton order of the
- * centroids, one radix sort, all inner nodes at once (Karras 2012), boxes fitted bottom-up, subtrees of up to max_leaf_tris
- * triangles collapsed into the reference's kind of leaf.  One tree per mesh over its triangles, one over the instances' world
+ * centroids (one radix sort), all inner nodes at once (Karras 2012), boxes fitted bottom-up, subtrees of up to max_leaf_tris
+ * triangles collapsed into the reference's kind of leaf.  A linear BVH is deeper and looser than a surface-area-heuristic tree:
+ * frames take 20-45 % longer on it, and a mesh that packs many triangles into one cell of the 30-bit grid can
+ * exceed the 32-entry traversal stack (upload_scene then refuses the scene: use a CPU producer).  One tree per mesh over its triangles, one over the instances' world
  * boxes with one instance per leaf (compiler.go:88-103).  Output in the reference's encoding (PolarisBvhNode; node 0 = the scene's
  * root), ready for PolarisSceneView once the caller has put the triangle arrays in the new order:
  *   tri_order[new position] = old triangle index (a permutation within every mesh's range; emissive tri_index values follow it);

@@ -256,3 +256,45 @@ func (tr *Tracer) ReadFrameBuffer(pix []uint8) error {
 	}
 	return tr.check(C.polaris_hip_read_framebuffer(tr.handle, (*C.uint8_t)(unsafe.Pointer(&pix[0])), C.size_t(len(pix))))
 }
+
+// ---- one tracer per PROCESS (INTEGRATION.md section 3b): the merge as a peer read through HIP IPC --------------------------
+
+// IpcExport turns the trace accumulator into a ring of `depth` buffers (every Trace writes the next; TraceSlot says which) and
+// returns the 352-byte blob another process opens with IpcOpen.  Plain bytes: send them over any channel.
+func (tr *Tracer) IpcExport(depth uint32) ([]byte, error) {
+	var x C.PolarisIpcExport
+	if err := tr.check(C.polaris_hip_ipc_export(tr.handle, C.uint32_t(depth), &x)); err != nil {
+		return nil, err
+	}
+	return C.GoBytes(unsafe.Pointer(&x), C.int(unsafe.Sizeof(x))), nil
+}
+
+// Peer is another process's trace accumulator ring, mapped on this tracer's device.
+type Peer struct{ p *C.polaris_hip_peer }
+
+func (tr *Tracer) IpcOpen(blob []byte) (*Peer, error) {
+	if len(blob) != int(unsafe.Sizeof(C.PolarisIpcExport{})) {
+		return nil, fmt.Errorf("hip: an IPC export is %d bytes, got %d", unsafe.Sizeof(C.PolarisIpcExport{}), len(blob))
+	}
+	var p *C.polaris_hip_peer
+	if err := tr.check(C.polaris_hip_ipc_open(tr.handle, (*C.PolarisIpcExport)(unsafe.Pointer(&blob[0])), &p)); err != nil {
+		return nil, err
+	}
+	return &Peer{p}, nil
+}
+
+func (tr *Tracer) IpcClose(peer *Peer) error { return tr.check(C.polaris_hip_ipc_close(tr.handle, peer.p)) }
+
+// MergeIpc is MergeOutput from a tracer of another process: the rows of blockReq of the peer's ring slot, read where they lie.
+func (tr *Tracer) MergeIpc(peer *Peer, slot uint32, blockReq *tracer.BlockRequest) (time.Duration, error) {
+	start := time.Now()
+	creq := toC(blockReq)
+	return time.Since(start), tr.check(C.polaris_hip_merge_ipc(tr.handle, peer.p, C.uint32_t(slot), &creq))
+}
+
+// TraceSlot is the ring slot the last Trace wrote (0 without a ring).
+func (tr *Tracer) TraceSlot() uint32 {
+	var s C.uint32_t
+	C.polaris_hip_trace_slot(tr.handle, &s)
+	return uint32(s)
+}

@@ -4,8 +4,11 @@
 // one goroutine each, every one an O(n) pass over the node's items: fine for a few thousand triangles, minutes for a million.
 // polaris_amd/host/scene_compiler.cpp restates it for the CPU.  This file is an ALTERNATIVE producer for the same arrays
 // (PolarisBvhNode in the reference's encoding, optimized_scene.go:14-64) shaped for the GPU: a linear BVH (Morton order of the
-// centroids, one radix sort, the hierarchy of Karras 2012 built for all inner nodes at once, boxes fitted bottom-up), with
-// subtrees of up to max_leaf_tris items collapsed into the reference's kind of leaf (first item, count).  One tree per mesh
+// centroids on a grid whose cells stay near-cubic, one radix sort, the hierarchy of Karras 2012 built for all inner nodes at
+// once, boxes fitted bottom-up), with subtrees of up to max_leaf_tris items collapsed into the reference's kind of leaf (first
+// item, count).  (Round 4 also built PLOC -- bottom-up clustering of mutual nearest neighbours, Meister & Bittner 2018 -- on the
+// same infrastructure: better on the Cornell box (14.5 vs 16.7 ms per frame), level elsewhere, and too DEEP for the 32-entry
+// traversal stack on the 58 K-triangle ball; removed again, profiles/r04_bvh_build_lbvh_vs_ploc.json.)  One tree per mesh
 // over its triangles, one over the instances' world boxes (one instance per leaf, compiler.go:88-103).
 //
 // It cannot reproduce the reference's tree (a different algorithm, and the reference breaks equal-score ties by goroutine
@@ -64,30 +67,48 @@ __global__ __launch_bounds__(BT) void k_box_bounds(const Box *boxes, uint32_t n,
 	}
 }
 
-__device__ __forceinline__ uint32_t spread10(uint32_t v) { // 10 bits -> every third bit
-	v = (v * 0x00010001u) & 0xFF0000FFu;
-	v = (v * 0x00000101u) & 0x0F00F00Fu;
-	v = (v * 0x00000011u) & 0xC30C30C3u;
-	v = (v * 0x00000005u) & 0x49249249u;
-	return v;
-}
-
-// key = 30-bit Morton code of the centroid on the tree's grid << 32 | item index: unique keys, so the hierarchy below needs
-// no tie rule, and items that share a cell split by index (balanced)
+// key = 30-bit code of the centroid << 32 | item index (unique: the sort is total).  The code is a Morton code whose bits go to
+// the axes in the order of the CELL'S SIZE -- every bit halves the axis along which the current cell is longest -- so that cells
+// stay near-cubic at every level whatever the shape of the mesh: a heightfield spends its first bits on the two axes it
+// extends along, not every third bit on the one it barely has (which would cut it into slabs by height).
 __global__ __launch_bounds__(BT) void k_morton(const Box *boxes, uint32_t n, const uint32_t *bounds, uint64_t *keys) {
 	const uint32_t i = blockIdx.x * BT + threadIdx.x;
 	if (i >= n) return;
-	uint32_t q[3];
+	float cell[3];
+	uint32_t q[3], used[3] = {0, 0, 0};
 	for (int k = 0; k < 3; k++) {
-		const float lo = o2f(bounds[k]), hi = o2f(bounds[3 + k]);
+		const float lo = o2f(bounds[k]), ext = o2f(bounds[3 + k]) - lo;
 		const float c = 0.5f * boxes[i].lo[k] + 0.5f * boxes[i].hi[k];
-		const float ext = hi - lo;
-		float t = ext > 0.0f ? (c - lo) / ext : 0.0f;
-		t = fminf(fmaxf(t * 1024.0f, 0.0f), 1023.0f);
-		q[k] = (uint32_t)t;
+		const float t = ext > 0.0f ? (c - lo) / ext : 0.0f;
+		q[k] = (uint32_t)fminf(fmaxf(t * 65536.0f, 0.0f), 65535.0f);
+		cell[k] = ext > 0.0f ? ext : 0.0f;
 	}
-	const uint32_t code = spread10(q[0]) << 2 | spread10(q[1]) << 1 | spread10(q[2]);
+	uint32_t code = 0;
+	for (int b = 0; b < 30; b++) {
+		int a = 0;
+		if (cell[1] > cell[a]) a = 1;
+		if (cell[2] > cell[a]) a = 2;
+		uint32_t bit = 0;
+		if (cell[a] > 0.0f) {
+			bit = (q[a] >> (15u - used[a])) & 1u;
+			used[a]++;
+			cell[a] = used[a] < 16u ? 0.5f * cell[a] : 0.0f;
+		}
+		code = code << 1 | bit;
+	}
 	keys[i] = (uint64_t)code << 32 | i;
+}
+
+// The keys the HIERARCHY is built on: the sorted item's code, then its POSITION in the sorted order (not its original index: items
+// that share a code then split by position, i.e. into runs of neighbours on the curve, and the depth below a full cell is
+// log2 of its population).  `bits` < 30 would cut the code short and leave more to the positions -- a shallower tree; measured
+// (cells of ~8 items): the bottom levels, split by position alone, cost more than the depth saves (terrain 28.7 -> 34.9 ms per
+// frame) -- so the full code is used.
+__global__ __launch_bounds__(BT) void k_hier_keys(const uint64_t *keys, uint32_t n, uint32_t bits, uint64_t *hkeys) {
+	const uint32_t p = blockIdx.x * BT + threadIdx.x;
+	if (p >= n) return;
+	const uint64_t code = bits ? (keys[p] >> 32) >> (30u - bits) : 0ull;
+	hkeys[p] = code << 32 | p;
 }
 
 // Karras 2012, "Maximizing parallelism in the construction of BVHs, octrees, and k-d trees": inner node i of n - 1, all at once.
@@ -193,8 +214,13 @@ __global__ __launch_bounds__(BT) void k_emit(uint32_t n, uint32_t max_leaf, cons
 		bool leaf = (kids[k] & kLeafBit) != 0;
 		uint32_t lo, hi;
 		Box b;
-		if (leaf) { lo = hi = kids[k] & ~kLeafBit; b = boxes[(uint32_t)(keys[lo] & 0xFFFFFFFFu)]; }
-		else {
+		uint32_t inst = 0;
+		if (leaf) {
+			const uint32_t p = kids[k] & ~kLeafBit;
+			inst = (uint32_t)(keys[p] & 0xFFFFFFFFu);
+			b = boxes[inst];
+			lo = hi = p;
+		} else {
 			const uint2 q = range[kids[k]];
 			lo = q.x; hi = q.y;
 			b = inner_box[kids[k]];
@@ -203,7 +229,7 @@ __global__ __launch_bounds__(BT) void k_emit(uint32_t n, uint32_t max_leaf, cons
 		if (!leaf) { child[k] = (int32_t)(node_base + place[kids[k]]); continue; }
 		PolarisBvhNode nd;
 		for (int a = 0; a < 3; a++) { nd.min[a] = b.lo[a]; nd.max[a] = b.hi[a]; }
-		if (instances) { nd.ldata = -(int32_t)(uint32_t)(keys[lo] & 0xFFFFFFFFu); nd.rdata = 0; } // top-level leaf: ONE instance (max_leaf = 1)
+		if (instances) { nd.ldata = -(int32_t)inst; nd.rdata = 0; } // top-level leaf: ONE instance (max_leaf = 1: never a collapsed subtree)
 		else { nd.ldata = -(int32_t)(item_base + lo); nd.rdata = (int32_t)(hi - lo + 1); }        // triangles [first, first + count) of the NEW order
 		out[node_base + next] = nd;
 		child[k] = (int32_t)(node_base + next);
@@ -232,7 +258,7 @@ __global__ void k_single_leaf(const uint64_t *keys, const Box *boxes, uint32_t n
 
 __global__ __launch_bounds__(BT) void k_order(const uint64_t *keys, uint32_t n, uint32_t item_base, uint32_t *order) {
 	const uint32_t p = blockIdx.x * BT + threadIdx.x;
-	if (p < n) order[item_base + p] = item_base + (uint32_t)(keys[p] & 0xFFFFFFFFu);
+	if (p < n) order[item_base + p] = item_base + (uint32_t)(keys[p] & 0xFFFFFFFFu); // (the tree keeps the Morton order: sorted item p is item p)
 }
 
 struct Scratch { // device buffers sized for the largest tree of the call
@@ -269,15 +295,17 @@ int build_tree(Scratch &S, hipStream_t q, uint32_t n, uint32_t max_leaf, uint32_
 	hipLaunchKernelGGL(k_morton, dim3(grid(n)), dim3(BT), 0, q, S.boxes, n, S.bounds, S.keys_alt);
 	size_t tb = S.temp_bytes;
 	BUILD_TRY(hipcub::DeviceRadixSort::SortKeys(S.temp, tb, S.keys_alt, S.keys, (int)n, 0, 62, q));
+	const bool single = n <= max_leaf || n < 2;
 	if (d_order) hipLaunchKernelGGL(k_order, dim3(grid(n)), dim3(BT), 0, q, S.keys, n, item_base, d_order);
-	if (n <= max_leaf || n < 2) {
+	if (single) {
 		hipLaunchKernelGGL(k_single_leaf, dim3(1), dim3(64), 0, q, S.keys, S.boxes, n, node_base, item_base, instances, d_out);
 		*emitted = 1;
 		BUILD_TRY(hipGetLastError());
 		return POLARIS_OK;
 	}
 	BUILD_TRY(hipMemsetAsync(S.arrived, 0, (size_t)(n - 1) * sizeof(uint32_t), q));
-	hipLaunchKernelGGL(k_hierarchy, dim3(grid(n - 1)), dim3(BT), 0, q, S.keys, n, S.left, S.right, S.parent_inner, S.parent_leaf, S.range);
+	hipLaunchKernelGGL(k_hier_keys, dim3(grid(n)), dim3(BT), 0, q, S.keys, n, 30u, S.keys_alt); // (the sort's input buffer is free again)
+	hipLaunchKernelGGL(k_hierarchy, dim3(grid(n - 1)), dim3(BT), 0, q, S.keys_alt, n, S.left, S.right, S.parent_inner, S.parent_leaf, S.range);
 	hipLaunchKernelGGL(k_fit, dim3(grid(n)), dim3(BT), 0, q, S.keys, S.boxes, n, S.left, S.right, S.parent_inner, S.parent_leaf, S.inner_box, S.arrived);
 	hipLaunchKernelGGL(k_need, dim3(grid(n - 1)), dim3(BT), 0, q, n, max_leaf, S.left, S.right, S.range, S.parent_inner, S.need);
 	tb = S.temp_bytes;

@@ -95,6 +95,16 @@ def test_device_built_bvh_is_valid_and_traces_like_the_oracle(built, oracle, nam
         assert (diff > 1e-6).mean() < 0.02, (name, float((diff > 1e-6).mean()))
 
 
+def test_the_build_is_deterministic(built):
+    """Two builds give the same arrays, byte for byte (the sort keys are unique, node places come from a prefix sum)."""
+    from polaris_amd import bvh_build, scenes
+
+    old = scenes.SCENES["material-ball-small"]()
+    a, _ = bvh_build.rebuild_on_device(old, max_leaf_tris=2)
+    b, _ = bvh_build.rebuild_on_device(old, max_leaf_tris=2)
+    assert a.bvh_nodes.tobytes() == b.bvh_nodes.tobytes() and np.array_equal(a.material_index, b.material_index) and np.array_equal(a.vertices, b.vertices)
+
+
 def test_build_refuses_malformed_input(built):
     import ctypes as C
 
