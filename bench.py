@@ -217,6 +217,8 @@ def main() -> None:
                     "trace accumulator through HIP IPC mappings (polaris_hip_merge_ipc; falls back to `strips` if a mapping cannot be opened), "
                     "`strips`: point-to-point transfers of the strips on --backend")
     ap.add_argument("--backend", default="nccl", help="--exchange strips: torch.distributed backend of the strip transfers (nccl = RCCL; gloo only to test that flow on one GPU)")
+    ap.add_argument("--test-ipc-failure", action="store_true", help="testing aid: rank 0 refuses to map the peers' rings, as if hipIpcOpenMemHandle had failed -- "
+                    "the run must fall back to the strip transfers inside the same processes")
     ap.add_argument("--no-second-scheduler", action="store_true", help="N > 1: skip the second timed region (the perfect scheduler when --scheduler naive)")
     ap.add_argument("--same-device", action="store_true", help="testing aid: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--emulate-rank", default="", help="R/N: on ONE GPU, trace only the row block rank R of N would own "
@@ -331,7 +333,12 @@ def main() -> None:
         from polaris_amd.distributed import HipPort, PeerExchange
 
         if args.exchange == "ipc":
-            px = PeerExchange(dist, rank, world, W, H, HipPort(tr, make_req), scheduler=args.scheduler)
+            port = HipPort(tr, make_req)
+            if args.test_ipc_failure:
+                def refuse(blob):
+                    raise RuntimeError("hipIpcOpenMemHandle: refused (--test-ipc-failure)")
+                port.open = refuse
+            px = PeerExchange(dist, rank, world, W, H, port, scheduler=args.scheduler)
             if px.setup():
                 exchange = (f"hip-ipc: rank 0's merge stream reads every rank's rows through an IPC mapping of its trace accumulator ring "
                             f"(depth {px.depth}), one frame behind the tracing; control = 32 B per rank and frame over gloo; no RCCL")

@@ -107,6 +107,56 @@ def test_bench_two_ranks_strip_fallback(built, tmp_path):
     _two_rank_frame_matches_the_oracle(d, acc)
 
 
+def test_bench_falls_back_inside_the_same_processes_when_a_mapping_cannot_be_opened(built, tmp_path):
+    """The default exchange with rank 0 refusing to map the peers' rings (what a failing hipIpcOpenMemHandle looks like to
+    PeerExchange.setup): every rank must switch to the strip transfers without a re-launch -- here over gloo, since RCCL needs two
+    GPUs -- say so in config.exchange, and still assemble the right frame."""
+    acc = str(tmp_path / "frame.npy")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--test-ipc-failure", "--backend", "gloo", "--same-device", "--no-cpu-baseline",
+           "--no-second-scheduler", "--opt", "exact_accumulate=1", "--save-accumulator", acc]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "falling back to strip transfers" in out.stderr
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["exchange"].startswith("fallback after a failed IPC mapping") and "gloo point-to-point" in d["config"]["exchange"]
+    _two_rank_frame_matches_the_oracle(d, acc)
+
+
+def test_an_ipc_export_that_cannot_be_mapped_is_refused_cleanly(built):
+    """polaris_hip_ipc_open on handles the runtime will not open (here: this process's own export with another pid written into
+    it -- HIP cannot open its own IPC handle) returns POLARIS_E_UNSUPPORTED with the runtime's message and leaves nothing
+    half-mapped: the tracer keeps working, a merge from an own ring slot still adds up."""
+    import numpy as np
+
+    from conftest import make_hip_tracer
+    from oracle import pybind as ob
+    from polaris_amd import ctypes_api as T
+    from polaris_amd import scenes
+    from polaris_amd.tracer import TracerError
+
+    sc = scenes.SCENES["cubes"]()
+    W, H, spp, B = 32, 24, 1, 2
+    tr = make_hip_tracer(sc, W, H, exact_accumulate=1)
+    try:
+        x = T.IpcExport.from_buffer_copy(tr.ipc_export(3))
+        x.pid += 1
+        with pytest.raises(TracerError) as e:
+            tr.ipc_open(bytes(x))
+        assert e.value.code == 6 and "hipIpcOpenMemHandle" in str(e.value)      # POLARIS_E_UNSUPPORTED
+        x.frame_w += 1
+        with pytest.raises(TracerError, match="does not match"):
+            tr.ipc_open(bytes(x))
+        seeds = scenes.make_seeds(spp, B)
+        tr.Trace(ob.make_request(W, H, spp=spp, bounces=B), seeds)
+        tr.reset_frame()
+        tr.merge_slot(tr, tr.trace_slot(), ob.make_request(W, H, spp=spp, bounces=B))
+        tr.SyncFramebuffer(ob.make_request(W, H, spp=spp, bounces=B))
+        assert np.array_equal(tr.read_accumulator(1), tr.read_accumulator(0)) and tr.read_accumulator(0)[..., :3].sum() > 0
+    finally:
+        tr.Close()
+
+
 def test_bench_two_ranks_perfect_scheduler(built, tmp_path):
     """`--scheduler perfect`: the reference's perfect scheduler (tracer/scheduler.go:50-80) fed by all-gathered (rows, time)
     pairs -- every rank must arrive at the same rows every frame, or the blocks would not fit together.  The last frame, with
