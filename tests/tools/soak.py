@@ -51,11 +51,27 @@ def run(iters=200):
         by = int(rng.integers(0, H))
         bh = int(rng.integers(1, H - by + 1))
         req = ob.make_request(W, H, spp=spp, bounces=B, rr=int(rng.integers(1, B + 2)), block_y=by, block_h=bh)
+        ring = int(rng.integers(0, 3)) == 0          # every third iteration: the trace accumulator as a ring (what a peer process maps)
+        if ring:
+            depth = int(rng.integers(1, 5))
+            blob = tr.ipc_export(depth)
+            assert len(blob) == 352
         tr.Trace(req, scenes.make_seeds(spp, B, base=it))
-        tr.MergeOutput(tr, req)
+        if ring and int(rng.integers(0, 2)):         # a second Trace moves on to the next slot; the first frame's slot stays readable
+            first = tr.trace_slot()
+            tr.Trace(req, scenes.make_seeds(spp, B, base=it + 1))
+            assert tr.trace_slot() == (first + 1) % depth
+        if ring:
+            tr.reset_frame()
+            tr.merge_slot(tr, tr.trace_slot(), req)
+        else:
+            tr.MergeOutput(tr, req)
         tr.SyncFramebuffer(req)
         acc = tr.read_accumulator(0)
         assert np.isfinite(acc).all(), (it, n)
+        if ring:
+            frame = tr.read_accumulator(1)
+            assert np.array_equal(frame[by:by + bh, :, :3], acc[by:by + bh, :, :3]), (it, n)   # the merged rows are the newest slot's
         if it == 20:
             start = free_mb()
         if start is not None:
