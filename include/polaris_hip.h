@@ -83,7 +83,7 @@ int polaris_hip_set_camera(polaris_hip_tracer *h, const float eye[3], const floa
  *                        the reference's order (forces one sample per batch; bit-exact with
  *                        the CPU oracle), 0 = per-path radiance + ordered resolve (default)
  *   "packet_primary"     1 = wave-packet traversal for primary rays, 0 = per-ray, -1 = by scene
- *                        (default: packets for single-instance scenes of up to 256 K triangles)
+ *                        (default: packets for single-instance scenes of up to 32 K triangles)
  *   "time_kernels"       1 = bracket every kernel with HIP events (polaris_hip_kernel_ms)
  *   "overlap"            batches in flight on separate streams (1-8, default 4)
  *   "max_leaf_tris"      applies to the NEXT upload_scene: triangle leaves with more triangles

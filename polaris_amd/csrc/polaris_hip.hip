@@ -779,11 +779,13 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 	                    sc->scene_diffuse_mat_index, sc->num_material_nodes, sc->num_textures, light_geo, sc->num_emissives ? pm_rcp((float)(int)sc->num_emissives) : 0.0f, L.tri_bits};
 	h->max_stack = L.max_stack;
 	h->tex_bytes = sc->texture_data_bytes;
-	// camera rays: the wave-packet kernel where a packet stays together -- one instance, a tree of moderate size.  Since the
-	// per-ray kernel's instruction diet the two are level on those scenes (headline 1.2 vs 1.0 ms of 11.3, sphere
-	// +-0, 58 K-triangle ball +-0); in a scene of many instances the packet's lanes part ways inside the instances: per-ray
-	// -5 % frame time on the 1 024-instance scene, -26 % on the 1 M-triangle terrain
-	if (h->opt_packet_primary < 0) h->packet_primary = sc->num_triangles <= 262144u && sc->num_mesh_instances == 1;
+	// camera rays: the wave-packet kernel where a packet stays together AND the tree is small -- one instance, up to 32 K
+	// triangles.  Since the per-ray kernel's instruction diet the two are level on the tiny scenes (headline 11.37 /
+	// 11.31 / 11.39 ms with packets against 11.42 / 11.32 / 11.38 without, round 4: the packet kernel stays there, it keeps the
+	// origin stream unwritten); on the 58 K-triangle ball the packet's dependent scalar node fetches cost more than the per-ray
+	// kernel's gathers (camera rays 5.5 vs 4.1 ms per 32 spp, frame -1.8 %); in a scene of many instances the packet's lanes part
+	// ways inside the instances (-5 % frame time per-ray on the 1 024-instance scene, -26 % on the 1 M-triangle terrain)
+	if (h->opt_packet_primary < 0) h->packet_primary = sc->num_triangles <= 32768u && sc->num_mesh_instances == 1;
 	// node records: whole tree in LDS for tiny scenes, its top for small ones, global memory otherwise (kernels.h NodeMode)
 	// (16-bit stack entries: triangle slots and instance ids must fit 11 bits, and no leaf reference may carry kBigLeafFlag)
 	const bool tiny_ok = L.pairs.size() <= (size_t)kTinyPairs && L.tris.size() <= kTinyMaxIndex && L.insts.size() <= kTinyMaxIndex && L.big_leaves == 0 && L.max_stack <= 16;
