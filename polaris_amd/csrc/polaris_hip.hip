@@ -26,7 +26,6 @@
 #include <unistd.h>
 
 #include "kernels.h"
-#include "kernels_wide.h"
 #include "polaris_hip.h"
 
 using namespace pol;
@@ -96,14 +95,6 @@ struct polaris_hip_tracer {
 	int opt_node_mode = -1;       // -1 = by scene size
 	uint32_t tex_bytes = 0; // size of the uploaded texture blob (without its padding)
 	int trace_resident_per_cu = 6, occl_resident_per_cu = 6; // workgroups of the selected k_trace<closest | any hit> variant a CU holds at once (occupancy API, at upload)
-	// The four-wide tree (scene_layout.h build_wide, kernels_wide.h k_trace_wide): built for the scenes whose tree is read from
-	// global memory, where a ray pays per node record it touches.  wide_on = this scene's bounce and shadow rays go through it.
-	WideDev wide{};
-	bool wide_on = false;
-	int wide_stack = 0;
-	int opt_wide = -1;            // 1 = wherever the scene has a wide tree, 0 = never, -1 = by scene (node records in global memory)
-	int opt_wide_stack = kTraversalStack; // stack entries the wide tree may need (nodes at the top of the deepest paths stay pairs to fit: build_wide)
-	std::string wide_why;         // why the uploaded scene has no wide tree (printed under POLARIS_DEBUG)
 
 	// camera (tracer.go:175-179)
 	bool have_camera = false;
@@ -384,12 +375,6 @@ inline uint32_t grid_for(size_t n) { return (uint32_t)((n + WG - 1) / WG); }
 template <bool ANY_HIT>
 const void *trace_kernel(polaris_hip_tracer *h, int *block) {
 	*block = h->node_mode == kNodesLdsAll ? kTinyBlock : WG;
-	if (h->wide_on) {
-		*block = WG;
-		if (h->wide_stack <= 16) return (const void *)k_trace_wide<ANY_HIT, 16>;
-		if (h->wide_stack <= 24) return (const void *)k_trace_wide<ANY_HIT, 24>;
-		return (const void *)k_trace_wide<ANY_HIT, 32>;
-	}
 	if (h->node_mode == kNodesLdsAll) return (const void *)k_trace<ANY_HIT, 16, kNodesLdsAll>;
 	const bool top = h->node_mode == kNodesLdsTop;
 	if (h->max_stack <= 16) return top ? (const void *)k_trace<ANY_HIT, 16, kNodesLdsTop> : (const void *)k_trace<ANY_HIT, 16, kNodesGlobal>;
@@ -402,8 +387,7 @@ template <bool ANY_HIT>
 std::string trace_symbol(polaris_hip_tracer *h) {
 	char buf[96];
 	const char *a = ANY_HIT ? "true" : "false";
-	if (h->wide_on) snprintf(buf, sizeof buf, "pol::k_trace_wide<%s, %d>", a, h->wide_stack <= 16 ? 16 : (h->wide_stack <= 24 ? 24 : 32));
-	else if (h->node_mode == kNodesLdsAll) snprintf(buf, sizeof buf, "pol::k_trace<%s, 16, %d>", a, (int)kNodesLdsAll);
+	if (h->node_mode == kNodesLdsAll) snprintf(buf, sizeof buf, "pol::k_trace<%s, 16, %d>", a, (int)kNodesLdsAll);
 	else snprintf(buf, sizeof buf, "pol::k_trace<%s, %d, %d>", a, h->max_stack <= 16 ? 16 : (h->max_stack <= 24 ? 24 : 32), h->node_mode);
 	return buf;
 }
@@ -412,7 +396,7 @@ template <bool ANY_HIT>
 hipError_t launch_trace(polaris_hip_tracer *h, polaris_hip_tracer::Pipe &P, const Streams &st, uint32_t grid, uint32_t chunks, float4 *acc) {
 	int block = WG;
 	const void *fn = trace_kernel<ANY_HIT>(h, &block);
-	void *args[] = {(void *)&st, h->wide_on ? (void *)&h->wide : (void *)&h->bvh, (void *)&chunks, (void *)&acc, (void *)&h->d_stats};
+	void *args[] = {(void *)&st, (void *)&h->bvh, (void *)&chunks, (void *)&acc, (void *)&h->d_stats};
 	return hipLaunchKernel(fn, dim3(grid), dim3(block), args, 0, P.q);
 }
 
@@ -724,26 +708,10 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 		err = build_layout(*sc, L, 0);
 	}
 	if (!err.empty()) return fail(h, POLARIS_E_BAD_SCENE, "%s", err.c_str());
-	// The four-wide tree, for the scenes whose node records stay in global memory (or wherever option wide = 1 asks for it).  It
-	// keeps the caller's leaves: a subdivided leaf would put the reference's leaf box on an inner node, so such a scene is laid
-	// out once more without subdivision -- if its leaves are small enough as they come.
-	h->wide_why = "option wide = 0";
-	if (h->opt_wide == 1 || (h->opt_wide < 0 && L.pairs.size() > (size_t)(POLARIS_LDS_TOP_MAX_PAIRS) && (h->opt_node_mode < 0 || h->opt_node_mode == kNodesGlobal))) {
-		build_wide(L, h->opt_wide_stack);
-		if (L.wide_stack == 0 && L.subdivided) {
-			SceneLayout L0;
-			if (build_layout(*sc, L0, 0).empty()) {
-				build_wide(L0, h->opt_wide_stack);
-				if (L0.wide_stack > 0) L = std::move(L0);
-			}
-		}
-		h->wide_why = L.wide_why;
-	}
 	HIP_TRY(h, hipSetDevice(h->device));
 	HIP_TRY(h, sync_all(h));
 	free_pool(h->scene_bufs);
 	h->have_scene = false;
-	h->wide_on = false;
 	int rc = 0;
 	PairNode *pairs; int2 *leaves; TriRec *tris; InstRec *insts;
 	rc |= dev_upload(h, h->scene_bufs, &pairs, L.pairs.data(), L.pairs.size());
@@ -793,12 +761,6 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 	// the texture blob, padded: texels are fetched as the three dwords at their address whatever the format (shading.h, tex_fetch)
 	rc |= dev_alloc(h, h->scene_bufs, &tex_data, (size_t)sc->texture_data_bytes + 16);
 	if (!rc && sc->texture_data_bytes) HIP_TRY(h, hipMemcpyAsync(tex_data, sc->texture_data, sc->texture_data_bytes, hipMemcpyHostToDevice, h->stream));
-	float4 *wnodes = nullptr, *wleaf = nullptr, *winst = nullptr;
-	if (L.wide_stack > 0) {
-		rc |= dev_upload(h, h->scene_bufs, &wnodes, L.wide.data(), L.wide.size() * 4);
-		rc |= dev_upload(h, h->scene_bufs, &wleaf, L.leafrec.data(), L.leafrec.size() / 4);
-		rc |= dev_upload(h, h->scene_bufs, &winst, L.winst.data(), L.winst.size() * 6);
-	}
 	if (rc) { free_pool(h->scene_bufs); return rc; }
 	HIP_TRY(h, hipStreamSynchronize(h->stream)); // host vectors in L die at return
 	h->bvh = BvhDev{pairs, (uint32_t)L.pairs.size(), leaves, tris, insts, L.root_ref, 0, InstRec{}};
@@ -829,13 +791,6 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 	const bool tiny_ok = L.pairs.size() <= (size_t)kTinyPairs && L.tris.size() <= kTinyMaxIndex && L.insts.size() <= kTinyMaxIndex && L.big_leaves == 0 && L.max_stack <= 16;
 	h->node_mode = tiny_ok ? kNodesLdsAll : (L.pairs.size() <= (size_t)(POLARIS_LDS_TOP_MAX_PAIRS) ? kNodesLdsTop : kNodesGlobal);
 	if (h->opt_node_mode >= 0 && (h->opt_node_mode != kNodesLdsAll || tiny_ok)) h->node_mode = h->opt_node_mode;
-	if (L.wide_stack > 0) {
-		h->wide = WideDev{wnodes, wleaf, winst, L.wide_root, h->bvh.root_is_instance, h->bvh.root_inst};
-		if (h->bvh.root_is_instance) h->wide.root_inst.meta.x = L.winst[((uint32_t)~L.root_ref) >> 4].root_ref; // the mesh's WIDE root
-		h->wide_stack = L.wide_stack;
-		h->wide_on = true;
-	}
-	if (getenv("POLARIS_DEBUG")) fprintf(stderr, "[polaris] wide tree: %s\n", h->wide_on ? ("on, " + std::to_string(L.wide.size()) + " nodes, width " + std::to_string(L.wide_width) + ", stack " + std::to_string(L.wide_stack)).c_str() : h->wide_why.c_str());
 	h->trace_resident_per_cu = trace_occupancy<false>(h);
 	h->occl_resident_per_cu = trace_occupancy<true>(h);
 	h->have_scene = true;
@@ -875,8 +830,6 @@ int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value
 	else if (k == "overlap") h->opt_overlap = (int)std::max<int64_t>(1, std::min<int64_t>(value, polaris_hip_tracer::kMaxPipes));
 	else if (k == "trace_grid") h->opt_trace_grid = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20));
 	else if (k == "trace_wgs_per_cu") h->opt_trace_wgs_per_cu = (int)std::max<int64_t>(0, std::min<int64_t>(value, 64));
-	else if (k == "wide_stack") h->opt_wide_stack = (int)std::max<int64_t>(8, std::min<int64_t>(value, kTraversalStack)); // next upload
-	else if (k == "wide") h->opt_wide = (int)std::max<int64_t>(-1, std::min<int64_t>(value, 1)); // next upload
 	else if (k == "max_leaf_tris") h->opt_max_leaf_tris = (int)std::max<int64_t>(-1, std::min<int64_t>(value, 1 << 20)); // next upload
 	else return fail(h, POLARIS_E_BAD_ARGUMENT, "unknown option '%s'", key);
 	return POLARIS_OK;

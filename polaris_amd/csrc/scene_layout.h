@@ -66,28 +66,7 @@ struct SceneLayout {
 	// triangles, else 31 = no class).  The traversal kernels hand the word through to the hit record untouched; k_shade
 	// sorts a workgroup's rays by the class and masks it off.
 	uint32_t tri_bits = 31;
-	bool subdivided = false;        // big leaves were split at upload: the reference's leaf is then an INNER node of this tree
-
-	// ---- the four-wide tree (build_wide; kernels.h k_trace_wide) ------------------------------------------------------------
-	// The same leaves under nodes of up to four children whose boxes are quantised to 8 bits per coordinate, CONSERVATIVELY
-	// (every decoded box contains the exact one) -- 64 bytes per node, one gather per step like the pair node, about 0.57 x the
-	// steps.  A conservative box admits rays the reference's box rejects, so the EXACT reference box of a leaf (or of a
-	// top-level leaf = an instance) is tested once, on arrival; with every child box inside its parent's (checked here) a ray that
-	// passes the leaf's exact box passed every exact ancestor box (the slab test is monotone in the bounds), except where a
-	// flat box lies in a face of a non-flat ancestor and the ray runs in that plane (0 * inf): `flat_unsafe` bits per leaf.
-	struct WideNodeH { float org[3]; float scale_x; float scale_y, scale_z; uint8_t q[24]; int32_t ref[4]; }; // q[6 k + c]: child k, c = lo.xyz hi.xyz
-	std::vector<WideNodeH> wide;
-	std::vector<float> leafrec;     // float4 units: per triangle leaf [exact lo.xyz | flat_unsafe bits] [exact hi.xyz | 0] then its TriH records
-	struct WInstH { float r0[4], r1[4], r2[4]; int32_t root_ref; uint32_t rank; uint32_t pad[2]; float xlo[3]; uint32_t flat_unsafe; float xhi[3]; uint32_t pad2; };
-	std::vector<WInstH> winst;
-	int32_t wide_root = 0;
-	int wide_stack = 0;             // stack entries the wide tree needs; 0 = no wide tree (see wide_why)
-	int wide_width = 0;             // 4
-	uint32_t wide_narrow = 0;       // wide nodes left as pairs to keep the stack need within the limit
-	std::string wide_why;           // why the scene has no wide tree
 };
-static_assert(sizeof(SceneLayout::WideNodeH) == 64 && sizeof(SceneLayout::WInstH) == 96, "layout");
-constexpr int32_t kWideEmptyRef = (int32_t)0x80000003; // unused child slot of a wide node (below kFirstLeafRef: never a leaf reference)
 
 // Shading class of every material node = which BxDF leaves and texture operators the tree rooted at it can reach.  k_shade
 // groups the rays of a workgroup by the class of the triangle's material root before shading them (rays of one class run
@@ -453,7 +432,6 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out, in
 		slot_src.resize(NT);
 		for (uint32_t t = 0; t < NT; t++) slot_src[t] = t;
 	}
-	out.subdivided = subdivided;
 	n_nodes = (uint32_t)nodes.size();
 	n_slots = (uint32_t)slot_src.size();
 	out.pairs.assign(n_nodes, PairNodeH{});
@@ -683,294 +661,6 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out, in
 		d.orig = out.tri_bits < 31 ? (t | (uint32_t)node_class[sc.material_index[t]] << out.tri_bits) : t;
 	}
 	return "";
-}
-
-
-// The four-wide tree over the finished pair layout (see SceneLayout::wide).  Leaves L.wide_stack = 0 and says why when the scene
-// does not qualify: the pair kernels then serve it, as always.
-inline void build_wide(SceneLayout &L, int stack_limit = kTraversalStack) {
-	stack_limit = std::max(4, std::min(stack_limit, kTraversalStack));
-	L.wide.clear(); L.leafrec.clear(); L.winst.clear();
-	L.wide_stack = 0; L.wide_width = 0; L.wide_why.clear();
-	if (L.unbounded_boxes) { L.wide_why = "a box does not bound its subtree"; return; }
-	if (L.big_leaves) { L.wide_why = "a leaf holds more than 15 triangles"; return; }
-	if (L.subdivided) { L.wide_why = "leaves were subdivided at upload (the reference's leaf box would have to be tested at an inner node)"; return; }
-	const size_t NP = L.pairs.size();
-	struct Slot { const float *lo, *hi; int32_t ref; };
-	auto slots_of = [&](int32_t pair, Slot out[2]) {
-		const PairNodeH &P = L.pairs[pair];
-		out[0] = {P.lo0, P.hi0, P.ref0};
-		out[1] = {P.lo1, P.hi1, P.ref1};
-	};
-	// ---- containment of every child box in its parent's, flat_unsafe bits, leaf records: one walk per tree -----------------
-	// leaf_rec[key]: record of the triangle leaf with reference `ref` (a leaf has one parent slot: one record)
-	std::vector<int32_t> rec_of_first(L.tris.size() + 1, -1); // by first triangle slot
-	std::vector<uint32_t> inst_flat(L.insts.size(), 0);
-	std::vector<const float *> inst_lo(L.insts.size(), nullptr), inst_hi(L.insts.size(), nullptr);
-	bool ok = true;
-	std::string why;
-	// (parents by array, so that a leaf can look at ALL its ancestors' boxes)
-	std::vector<int32_t> parent(NP, -1);
-	std::vector<const float *> own_lo(NP, nullptr), own_hi(NP, nullptr);
-	std::vector<uint8_t> seen(NP, 0);
-	auto flat_bits = [&](const float *glo, const float *ghi, int32_t first_anc) -> uint32_t {
-		uint32_t bits = 0;
-		for (int a = 0; a < 3; a++) {
-			if (glo[a] != ghi[a]) continue;
-			for (int32_t p = first_anc; p >= 0 && own_lo[p]; p = parent[p]) {
-				const float lo = own_lo[p][a], hi = own_hi[p][a];
-				if (lo != hi && (lo == glo[a] || hi == glo[a])) { bits |= 1u << a; break; }
-			}
-		}
-		return bits;
-	};
-	auto visit_tree = [&](int32_t root_ref, bool top) {
-		if (root_ref < 0) { // the whole tree is one leaf: entered without a box test (the walk and the kernel know: "at the root")
-			const uint32_t code = (uint32_t)~root_ref;
-			if ((code & 15u) != 0 && rec_of_first[code >> 4] < 0) {
-				const float inf = std::numeric_limits<float>::infinity();
-				rec_of_first[code >> 4] = (int32_t)(L.leafrec.size() / 4);
-				const float f4[8] = {-inf, -inf, -inf, 0.0f, inf, inf, inf, 0.0f};
-				L.leafrec.insert(L.leafrec.end(), f4, f4 + 8);
-				for (uint32_t t = code >> 4; t < (code >> 4) + (code & 15u); t++) {
-					const float *tf = reinterpret_cast<const float *>(&L.tris[t]);
-					L.leafrec.insert(L.leafrec.end(), tf, tf + 12);
-				}
-			}
-			return;
-		}
-		std::vector<int32_t> stack{root_ref};
-		parent[root_ref] = -1; own_lo[root_ref] = own_hi[root_ref] = nullptr; // the root's own box is never tested
-		while (!stack.empty() && ok) {
-			const int32_t x = stack.back();
-			stack.pop_back();
-			if (seen[x]) continue; // (meshes are shared by instances: one walk per tree)
-			seen[x] = 1;
-			Slot sl[2];
-			slots_of(x, sl);
-			for (int k = 0; k < 2 && ok; k++) {
-				const Slot &c = sl[k];
-				for (int a = 0; a < 3; a++) if (!(c.lo[a] <= c.hi[a])) { ok = false; why = "an inverted or NaN box"; }
-				if (ok && own_lo[x])
-					for (int a = 0; a < 3; a++)
-						if (!(own_lo[x][a] <= c.lo[a] && c.hi[a] <= own_hi[x][a])) { ok = false; why = "a child box is not inside its parent's"; }
-				if (!ok) break;
-				if (c.ref >= 0) { parent[c.ref] = x; own_lo[c.ref] = c.lo; own_hi[c.ref] = c.hi; stack.push_back(c.ref); continue; }
-				const uint32_t code = (uint32_t)~c.ref;
-				// flat rule: ancestors = x's own box chain (x's own box included when x is not the root)
-				const uint32_t fb = flat_bits(c.lo, c.hi, own_lo[x] ? x : -1);
-				if ((code & 15u) == 0) { // a top-level leaf: the instance
-					if (!top) { ok = false; why = "an instance leaf inside a mesh tree"; break; }
-					const uint32_t inst = code >> 4;
-					if (inst >= L.insts.size() || inst_lo[inst]) { ok = false; why = "an instance with two top-level leaves"; break; }
-					inst_lo[inst] = c.lo; inst_hi[inst] = c.hi; inst_flat[inst] = fb;
-				} else {
-					const uint32_t first = code >> 4, cnt = code & 15u;
-					if (first >= rec_of_first.size() || rec_of_first[first] >= 0) { ok = false; why = "a triangle leaf with two parents"; break; }
-					rec_of_first[first] = (int32_t)(L.leafrec.size() / 4);
-					const float f4[8] = {c.lo[0], c.lo[1], c.lo[2], 0.0f, c.hi[0], c.hi[1], c.hi[2], 0.0f};
-					L.leafrec.insert(L.leafrec.end(), f4, f4 + 8);
-					memcpy(&L.leafrec[L.leafrec.size() - 5], &fb, 4); // (lo.w = the flat_unsafe bits)
-					for (uint32_t t = first; t < first + cnt; t++) {
-						const float *tf = reinterpret_cast<const float *>(&L.tris[t]);
-						L.leafrec.insert(L.leafrec.end(), tf, tf + 12);
-					}
-				}
-			}
-		}
-	};
-	visit_tree(L.root_ref, true);
-	for (size_t i = 0; i < L.insts.size() && ok; i++) visit_tree(L.insts[i].root_ref, false);
-	if (ok && L.leafrec.size() / 4 >= (1ull << 26)) { ok = false; why = "leaf records beyond 2^26 float4"; }
-	if (!ok) { L.leafrec.clear(); L.wide_why = why; return; }
-	auto leaf_ref = [&](int32_t ref) -> int32_t { // pair-tree leaf reference -> wide-tree leaf reference
-		const uint32_t code = (uint32_t)~ref;
-		if ((code & 15u) == 0) return ref; // instance: the id is in the reference
-		return ~(int32_t)(((uint32_t)rec_of_first[code >> 4] << 4) | (code & 15u));
-	};
-	// ---- wide nodes: a pair node's two children, the larger (by surface area) inner ones replaced by THEIR two, up to four -----
-	// A ray inside child i of a node may have the node's other used slots pending: a wide node of k children costs k - 1 stack
-	// entries where the pair tree costs 1 per level, so a deep tree collapsed four-wide everywhere can need more than
-	// `stack_limit` entries (the 1 M-triangle terrain: 37).  The width is therefore chosen per node against a budget handed
-	// down from the root: a subtree whose fully four-wide form fits its budget (w4) is collapsed four-wide throughout; above
-	// it, the node stays a PAIR (one pending entry) -- so the narrow nodes are the few at the top of the deepest paths, which a
-	// ray passes once, and the levels near the leaves, where a ray spends its steps, are always four-wide.
-	auto expand = [&](int32_t x, int width, Slot c[4]) -> int {
-		Slot two[2];
-		slots_of(x, two);
-		c[0] = two[0]; c[1] = two[1];
-		int k = 2;
-		while (k < width) {
-			int best = -1;
-			float ba = -1.0f;
-			for (int i = 0; i < k; i++) {
-				if (c[i].ref < 0) continue;
-				const float dx = c[i].hi[0] - c[i].lo[0], dy = c[i].hi[1] - c[i].lo[1], dz = c[i].hi[2] - c[i].lo[2];
-				const float area = dx * dy + dy * dz + dz * dx;
-				if (area > ba) { ba = area; best = i; }
-			}
-			if (best < 0) break;
-			slots_of(c[best].ref, two);
-			for (int i = k; i > best + 1; i--) c[i] = c[i - 1];
-			k++;
-			c[best] = two[0]; c[best + 1] = two[1];
-		}
-		return k;
-	};
-	auto is_inst = [](int32_t ref) { return ref < 0 && (((uint32_t)~ref) & 15u) == 0u; };
-	// need of the subtree of pair node x, collapsed `width`-wide throughout (w4) / left as pairs (w2); mesh trees first
-	std::vector<int> w4(NP, -1), w2(NP, -1);
-	auto fill = [&](std::vector<int> &need, int width, int32_t root) {
-		if (root < 0) return;
-		std::vector<int32_t> stq(1, root);
-		Slot c[4];
-		while (!stq.empty()) {
-			const int32_t q = stq.back();
-			if (need[q] >= 0) { stq.pop_back(); continue; }
-			const int k = expand(q, width, c);
-			bool ready = true;
-			int deepest = 0;
-			for (int i = 0; i < k; i++) {
-				int d = 0;
-				if (c[i].ref >= 0) { if (need[c[i].ref] < 0) { ready = false; stq.push_back(c[i].ref); } else d = need[c[i].ref]; }
-				else if (is_inst(c[i].ref)) { const int32_t mr = L.insts[((uint32_t)~c[i].ref) >> 4].root_ref; d = 1 + (mr >= 0 ? need[mr] : 0); } // (mesh trees are filled before the top-level tree)
-				deepest = std::max(deepest, d);
-			}
-			if (!ready) continue;
-			need[q] = k - 1 + deepest;
-			stq.pop_back();
-		}
-	};
-	for (size_t i = 0; i < L.insts.size(); i++) { fill(w4, 4, L.insts[i].root_ref); fill(w2, 2, L.insts[i].root_ref); }
-	fill(w4, 4, L.root_ref); fill(w2, 2, L.root_ref);
-	for (size_t x = 0; x < NP; x++) if (seen[x]) fill(w4, 4, (int32_t)x); // (every reachable pair node: below a narrow node the wide nodes start at other levels than in the all-wide tree)
-	{
-		std::vector<int32_t> wide_of(NP, -1), order;
-		std::vector<int> budget;        // per wide node: the stack entries its subtree may need
-		auto want = [&](int32_t ref, int b) -> int32_t {
-			if (ref < 0) return leaf_ref(ref);
-			if (wide_of[ref] < 0) { wide_of[ref] = (int32_t)order.size(); order.push_back(ref); budget.push_back(b); }
-			return wide_of[ref];
-		};
-		std::vector<SceneLayout::WideNodeH> W;
-		std::vector<int> mesh_budget(L.insts.size(), stack_limit - 1); // per instance: what its top-level leaf leaves for the mesh tree
-		std::vector<int32_t> iroot(L.insts.size(), 0);
-		size_t narrow = 0;
-		int32_t wroot;
-		if (L.root_ref < 0) { // the whole scene is one leaf (an instance: entered at ray set-up, its exit marker below everything)
-			wroot = leaf_ref(L.root_ref);
-			if (is_inst(L.root_ref)) mesh_budget[((uint32_t)~L.root_ref) >> 4] = stack_limit - 2;
-		} else {
-			if (w2[L.root_ref] > stack_limit - 1) { L.leafrec.clear(); L.wide_why = "the tree needs more than " + std::to_string(stack_limit) + " stack entries even as pairs"; return; }
-			wroot = want(L.root_ref, stack_limit - 1);
-		}
-		auto emit_from = [&](size_t head) {
-			for (; head < order.size() && ok; head++) {
-				Slot c[4];
-				const int32_t x = order[head];
-				const int B = budget[head];
-				const int width = w4[x] <= B ? 4 : 2;
-				const int k = expand(x, width, c);
-				if (width == 2) narrow++;
-				SceneLayout::WideNodeH w;
-				memset(&w, 0, sizeof w);
-				float blo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bhi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-				for (int i = 0; i < k; i++) for (int a = 0; a < 3; a++) { blo[a] = std::fmin(blo[a], c[i].lo[a]); bhi[a] = std::fmax(bhi[a], c[i].hi[a]); }
-				float scale[3];
-				for (int a = 0; a < 3; a++) {
-					w.org[a] = blo[a];
-					const float ext = bhi[a] - blo[a];
-					// the smallest power of two s with 255 s >= ext (a power of two: q * s is exact, the one rounding is the add)
-					float sc = 0.0f;
-					if (ext > 0.0f) { int ex; const float m = std::frexp(ext / 255.0f, &ex); sc = std::ldexp(1.0f, m == 0.5f ? ex - 1 : ex); if (!(sc > 0.0f)) sc = 1.17549435e-38f; }
-					scale[a] = sc;
-				}
-				w.scale_x = scale[0]; w.scale_y = scale[1]; w.scale_z = scale[2];
-				for (int i = 0; i < 4; i++) {
-					if (i >= k) { w.ref[i] = kWideEmptyRef; continue; }
-					for (int a = 0; a < 3; a++) {
-						float ql = 0.0f, qh = 255.0f;
-						if (scale[a] > 0.0f) {
-							ql = std::fmin(255.0f, std::fmax(0.0f, std::floor((c[i].lo[a] - blo[a]) / scale[a])));
-							qh = std::fmin(255.0f, std::fmax(0.0f, std::ceil((c[i].hi[a] - blo[a]) / scale[a])));
-							while (ql > 0.0f && std::fmaf(ql, scale[a], blo[a]) > c[i].lo[a]) ql -= 1.0f;   // decode = fma(q, scale, org): the kernel's instruction
-							while (qh < 255.0f && std::fmaf(qh, scale[a], blo[a]) < c[i].hi[a]) qh += 1.0f;
-							if (std::fmaf(ql, scale[a], blo[a]) > c[i].lo[a] || std::fmaf(qh, scale[a], blo[a]) < c[i].hi[a]) { ok = false; why = "a box cannot be quantised conservatively"; }
-						} else { // a flat node on this axis: every child is the plane itself; decode = org exactly
-							ql = qh = 0.0f;
-						}
-						w.q[6 * i + a] = (uint8_t)ql;
-						w.q[6 * i + 3 + a] = (uint8_t)qh;
-					}
-				}
-				for (int i = 0; i < k; i++) { // (after the slots are final: breadth-first numbering)
-					w.ref[i] = want(c[i].ref, B - (k - 1));
-					if (is_inst(c[i].ref)) { int &mb = mesh_budget[((uint32_t)~c[i].ref) >> 4]; mb = std::min(mb, B - (k - 1) - 1); }
-				}
-				W.push_back(w);
-			}
-		};
-		emit_from(0);                                   // the top-level tree: fixes every mesh tree's budget
-		const size_t top_nodes = order.size();
-		for (size_t i = 0; i < L.insts.size() && ok; i++) { // meshes are shared: a mesh tree gets the smallest budget of its instances
-			const int32_t mr = L.insts[i].root_ref;
-			int b = mesh_budget[i];
-			for (size_t j = 0; j < L.insts.size(); j++) if (L.insts[j].root_ref == mr) b = std::min(b, mesh_budget[j]);
-			if (mr >= 0 && w2[mr] > b) { ok = false; why = "a mesh tree needs more than its share of the " + std::to_string(stack_limit) + " stack entries even as pairs"; }
-			if (ok) iroot[i] = want(mr, b);
-		}
-		if (ok) emit_from(top_nodes);
-		if (!ok) { L.leafrec.clear(); L.wide_why = why; return; }
-		// stack entries a ray can hold: inside child i of a node the other used slots may all be pending
-		std::vector<int> need(W.size(), -1);
-		std::vector<int32_t> stq;
-		auto need_tree = [&](int32_t root) -> int {
-			if (root < 0) return 0;
-			stq.assign(1, root);
-			while (!stq.empty()) {
-				const int32_t q = stq.back();
-				if (need[q] >= 0) { stq.pop_back(); continue; }
-				bool ready = true;
-				int n = 0, deepest = 0;
-				for (int i = 0; i < 4; i++) {
-					const int32_t r = W[q].ref[i];
-					if (r == kWideEmptyRef) continue;
-					n++;
-					int d = 0;
-					if (r >= 0) { if (need[r] < 0) { ready = false; stq.push_back(r); } else d = need[r]; }
-					else if ((((uint32_t)~r) & 15u) == 0) { // instance: the exit marker + its mesh tree
-						const int32_t ir = iroot[((uint32_t)~r) >> 4];
-						if (ir >= 0 && need[ir] < 0) { ready = false; stq.push_back(ir); } else d = 1 + (ir >= 0 ? need[ir] : 0);
-					}
-					deepest = std::max(deepest, d);
-				}
-				if (!ready) continue;
-				need[q] = (n > 0 ? n - 1 : 0) + deepest;
-				stq.pop_back();
-			}
-			return need[root];
-		};
-		for (size_t i = 0; i < L.insts.size(); i++) (void)need_tree(iroot[i]);
-		int total = 0;
-		if (wroot >= 0) total = need_tree(wroot);
-		else if ((((uint32_t)~wroot) & 15u) == 0) { const int32_t ir = iroot[((uint32_t)~wroot) >> 4]; total = 1 + (ir >= 0 ? need[ir] : 0); }
-		if (total + 1 > stack_limit) { L.leafrec.clear(); L.wide_why = "internal: the budgeted wide tree needs " + std::to_string(total + 1) + " stack entries"; return; }
-		if (W.empty()) { SceneLayout::WideNodeH w; memset(&w, 0, sizeof w); for (int i = 0; i < 4; i++) w.ref[i] = kWideEmptyRef; W.push_back(w); } // never an empty device array
-		L.wide.swap(W);
-		L.wide_root = wroot;
-		L.wide_stack = total + 1;
-		L.wide_width = 4;
-		L.wide_narrow = (uint32_t)narrow;
-		L.winst.resize(L.insts.size());
-		for (size_t i = 0; i < L.insts.size(); i++) {
-			SceneLayout::WInstH &d = L.winst[i];
-			memset(&d, 0, sizeof d);
-			memcpy(d.r0, L.insts[i].r0, 16); memcpy(d.r1, L.insts[i].r1, 16); memcpy(d.r2, L.insts[i].r2, 16);
-			d.root_ref = iroot[i]; d.rank = L.insts[i].rank;
-			if (inst_lo[i]) { memcpy(d.xlo, inst_lo[i], 12); memcpy(d.xhi, inst_hi[i], 12); d.flat_unsafe = inst_flat[i]; }
-			else { for (int a = 0; a < 3; a++) { d.xlo[a] = -std::numeric_limits<float>::infinity(); d.xhi[a] = std::numeric_limits<float>::infinity(); } } // (the scene's root itself: never box-tested)
-		}
-	}
 }
 
 } // namespace pol

@@ -635,37 +635,6 @@ def test_frames_of_the_other_configs_against_the_oracle(built, oracle, name, W, 
     assert rmse(got, want, spp) <= 1e-6
 
 
-@pytest.mark.parametrize("name", ["cornell", "sphere", "cubes", "transformed", "many-materials", "terrain-small", "instanced-small"])
-def test_four_wide_tree_traces_the_reference_paths(built, oracle, name):
-    """kernels_wide.h k_trace_wide (four children per 64-byte node, boxes quantised conservatively, the exact reference box on
-    arrival at a leaf / an instance) asked for on scenes of every shape, exact and batched: counters identical, radiance
-    bit-equal (exact mode) to the CPU oracle -- or the scene has no wide tree and the pair kernels serve it."""
-    from oracle import pybind as ob
-    from polaris_amd import scenes
-
-    sc = scenes.SCENES[name](4 / 3)
-    W, H, spp, B = 64, 48, 3, 4
-    req = ob.make_request(W, H, spp=spp, bounces=B, rr=2)
-    seeds = scenes.make_seeds(spp, B, base=5)
-    want, wst, _ = oracle.trace(sc, req, seeds)
-    ran = 0
-    for opts in ({"max_leaf_tris": 0}, {}):
-        for exact in (1, 0):
-            tr = make_hip_tracer(sc, W, H, exact_accumulate=exact, time_kernels=1, wide=1, **opts)
-            try:
-                tr.Trace(req, seeds)
-                got, st = tr.read_accumulator(0), tr.last_trace_stats
-                ran += "k_trace_wide" in tr.kernel_symbol("intersect") and "k_trace_wide" in tr.kernel_symbol("occlusion")
-            finally:
-                tr.Close()
-            assert counters(st, B) == counters(wst, B), (opts, exact)
-            if exact:
-                assert np.array_equal(bits(got[..., :3]), bits(want[..., :3])), opts
-            else:
-                assert rmse(got, want, spp) <= 1e-6
-    assert ran >= 2, "the wide kernels never ran"
-
-
 @pytest.mark.parametrize("name", ["material-ball", "instanced"])
 def test_big_scene_kernel_variants_agree_with_the_oracle(built, oracle, name):
     """Scenes that select the other kernel variants -- the one-lane-per-ray kernel with its 24-entry stack and no LDS tree top,
@@ -681,16 +650,13 @@ def test_big_scene_kernel_variants_agree_with_the_oracle(built, oracle, name):
     want, wst, _ = oracle.trace(sc, req, seeds)
     assert wst.shaded_hits > 0
     for opts in ({}, {"max_leaf_tris": 0}, {"max_leaf_tris": 1}, {"max_leaf_tris": 2}, {"packet_primary": 0}, {"traversal": 0}, {"stage_lds": 0}, {"node_mode": 0},
-                 {"node_mode": 1}, {"node_mode": 2}, {"wide": 0}, {"wide": 1}, {"wide": 1, "packet_primary": 1}):
-        tr = make_hip_tracer(sc, W, H, exact_accumulate=1, time_kernels=1, **opts)
+                 {"node_mode": 1}, {"node_mode": 2}):
+        tr = make_hip_tracer(sc, W, H, exact_accumulate=1, **opts)
         try:
             tr.Trace(req, seeds)
             got, st = tr.read_accumulator(0), tr.last_trace_stats
-            symbol = tr.kernel_symbol("intersect")
         finally:
             tr.Close()
-        if "wide" in opts:  # the four-wide tree (kernels_wide.h) really is what ran / did not run
-            assert ("k_trace_wide" in symbol) == bool(opts["wide"]), (opts, symbol)
         assert counters(st, B) == counters(wst, B), opts
         assert np.array_equal(bits(got[..., :3]), bits(want[..., :3])), opts
 

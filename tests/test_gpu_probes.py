@@ -197,7 +197,6 @@ def test_arbitrary_rays_through_every_traversal_kernel(built, oracle, name):
     w_occ, _, _ = oracle.intersect(sc, rays, any_hit=True)
     assert 0.2 < w_hit.mean() < 1.0 and 0.0 < w_occ.mean()
     variants = [dict(traversal=1, node_mode=m) for m in (0, 1, 2)] + [dict(traversal=0), dict(packet_primary=1, packet_shadow=32)]
-    variants += [dict(wide=1), dict(wide=1, max_leaf_tris=0)]  # the four-wide tree (kernels_wide.h) where the scene has one
     for opts in variants:
         tr = make_hip_tracer(sc, 8, 8, **opts)
         try:

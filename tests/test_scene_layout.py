@@ -33,19 +33,19 @@ def harness():
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"),
                                "-I" + os.path.join(ROOT, "polaris_amd", "csrc"), SRC, "-o", LIB])
     lib = C.CDLL(LIB)
-    for fn in (lib.layout_check_traverse, lib.layout_check_traverse_wide):
+    for fn in (lib.layout_check_traverse,):
         fn.argtypes = [C.POINTER(T.SceneView), C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
     return lib
 
 
-def traverse(lib, sc, rays, max_leaf, any_hit=False, wide=False):
-    """Walk the uploaded layout on the CPU with k_trace's rules (wide=True: the four-wide tree with k_trace_wide's)."""
+def traverse(lib, sc, rays, max_leaf, any_hit=False):
+    """Walk the uploaded layout on the CPU with k_trace's rules."""
     rays = np.ascontiguousarray(rays, dtype=np.float32)
     hit = np.zeros((rays.shape[0], 6), np.int32)
-    cnt = np.zeros(8, np.uint64)
+    cnt = np.zeros(7, np.uint64)
     err = C.create_string_buffer(256)
     view = T.scene_view(sc)
-    fn = lib.layout_check_traverse_wide if wide else lib.layout_check_traverse
+    fn = lib.layout_check_traverse
     rc = fn(C.byref(view), max_leaf, rays.ctypes.data, rays.shape[0], int(any_hit), hit.ctypes.data, cnt.ctypes.data, err, 256)
     assert rc == 0, err.value.decode()
     return hit, cnt
@@ -200,96 +200,6 @@ QUAD_SCENES.update({"cornell": lambda tmp: scenes.cornell_box(), "terrain-small"
                     "instanced-small": lambda tmp: scenes.SCENES["instanced-small"](), "sphere": lambda tmp: scenes.sphere_scene()})
 
 
-WIDE_SCENES = {k: v for k, v in QUAD_SCENES.items() if k not in ("obj-room",)}   # (obj-room: instance boxes that do not bound: no wide tree)
-
-
-@pytest.mark.parametrize("name", list(WIDE_SCENES))
-def test_four_wide_quantised_tree_reaches_exactly_the_reference_leaves(harness, oracle, name, tmp_path):
-    """scene_layout.h build_wide: nodes of up to four children with boxes quantised CONSERVATIVELY to 8 bits per coordinate, the
-    exact reference box (and the flat rule) tested on arrival at a leaf or an instance.  The walk must return the hit records
-    of rayIntersectionQuery / the flags of rayIntersectionTest for every ray -- random ones, axis-parallel ones, and rays ON box
-    faces running parallel to them, where 0 * inf turns up in the slab test and a flat leaf in a face of its parent would let
-    a ray through that the reference stops one level higher."""
-    sc = WIDE_SCENES[name](tmp_path)
-    box_lo = np.minimum(sc.vertices[:, :3].min(axis=0), -1.0) - 0.5
-    box_hi = np.maximum(sc.vertices[:, :3].max(axis=0), 1.0) + 0.5
-    rng = np.random.default_rng(11)
-    n = 40000
-    rays = np.zeros((n, 8), np.float32)
-    rays[:, 0:3] = rng.uniform(box_lo, box_hi, size=(n, 3))
-    d = rng.normal(size=(n, 3))
-    rays[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True)
-    rays[:, 3] = np.float32(3.402823466e+38)
-    rays[: n // 8, 4 + (np.arange(n // 8) % 3)] = 0.0
-    rays = np.concatenate([rays, face_rays(sc, rng, 30000)])
-    shadow = rays.copy()
-    shadow[:, 3] = rng.uniform(0.05, 4.0, size=len(rays))
-    h, wuvt, it = oracle.intersect(sc, rays)
-    ha, _, _ = oracle.intersect(sc, shadow, any_hit=True)
-    hm = h != 0
-    assert 0 < hm.sum() < len(rays)
-    view_leaf = 0 if name in ("cornell-refbvh",) else 2   # (a subdivided tree has no wide form: keep the caller's leaves there)
-    tested = 0
-    for max_leaf in (0, view_leaf):
-        try:
-            got, cnt = traverse(harness, sc, rays, max_leaf, wide=True)
-        except AssertionError as e:
-            assert "no wide tree" in str(e), e              # a stated reason, never a wrong answer
-            continue
-        tested += 1
-        assert np.array_equal(got[:, 5] != 0, hm), f"{name}: hit flags differ (max_leaf_tris={max_leaf})"
-        assert np.array_equal(got[hm][:, [1, 0]], it[hm])
-        assert np.array_equal(got[hm][:, 2], wuvt[hm][:, 3].view(np.int32))
-        assert np.array_equal(got[hm][:, 3:5], wuvt[hm][:, 1:3].view(np.int32))
-        got_any, _ = traverse(harness, sc, shadow, max_leaf, any_hit=True, wide=True)
-        assert np.array_equal(got_any[:, 5] != 0, ha != 0)
-        assert 0 < cnt[5] <= 32 and cnt[6] <= cnt[5] and cnt[7] == 0
-        pair_hits, pair_cnt = traverse(harness, sc, rays, max_leaf)
-        assert np.array_equal(pair_hits, got)
-        print(f"{name} max_leaf={max_leaf}: {int(cnt[4])} wide nodes, steps {int(cnt[0])} vs {int(pair_cnt[0])} pair steps ({cnt[0] / max(int(pair_cnt[0]), 1):.2f}), "
-              f"leaves reached {int(cnt[2])} of which the exact test rejects {int(cnt[3])}, stack {int(cnt[5])} (deepest seen {int(cnt[6])}) vs {int(pair_cnt[5])}")
-    assert tested > 0 or name in ("cornell-refbvh",)
-
-
-@pytest.mark.parametrize("name", ["terrain-small", "instanced-small", "cornell"])
-def test_four_wide_tree_narrows_at_the_top_to_fit_a_smaller_stack(harness, oracle, name, tmp_path):
-    """build_wide against a stack limit below what the all-four-wide tree needs: nodes at the top of the deepest paths stay pairs
-    (counter 7), the static need stays within the limit, the deepest stack a ray really reaches too, and the hits are the oracle's."""
-    sc = WIDE_SCENES[name](tmp_path)
-    rng = np.random.default_rng(3)
-    n = 20000
-    rays = np.zeros((n, 8), np.float32)
-    lo = np.minimum(sc.vertices[:, :3].min(axis=0), -1.0) - 0.5
-    hi = np.maximum(sc.vertices[:, :3].max(axis=0), 1.0) + 0.5
-    rays[:, 0:3] = rng.uniform(lo, hi, size=(n, 3))
-    d = rng.normal(size=(n, 3))
-    rays[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True)
-    rays[:, 3] = np.float32(3.402823466e+38)
-    rays = np.concatenate([rays, face_rays(sc, rng, 10000)])
-    h, wuvt, it = oracle.intersect(sc, rays)
-    hm = h != 0
-    _, full = traverse(harness, sc, rays, 0, wide=True)
-    _, pair_cnt = traverse(harness, sc, rays, 0)
-    assert int(pair_cnt[5]) < int(full[5])                     # (the pair tree needs fewer entries than the all-wide one)
-    narrowed = []
-    try:
-        for limit in range(int(full[5]) - 1, int(pair_cnt[5]) - 1, -3):
-            harness.layout_check_wide_stack_limit(limit)
-            got, cnt = traverse(harness, sc, rays, 0, wide=True)
-            assert cnt[5] <= limit and cnt[6] <= cnt[5] and cnt[7] > 0, (limit, cnt)
-            assert np.array_equal(got[:, 5] != 0, hm)
-            assert np.array_equal(got[hm][:, [1, 0]], it[hm])
-            assert np.array_equal(got[hm][:, 2], wuvt[hm][:, 3].view(np.int32))
-            narrowed.append((limit, int(cnt[7]), int(cnt[0])))
-        harness.layout_check_wide_stack_limit(int(pair_cnt[5]) - 1)
-        with pytest.raises(AssertionError, match="even as pairs"):
-            traverse(harness, sc, rays, 0, wide=True)
-    finally:
-        harness.layout_check_wide_stack_limit(32)
-    assert narrowed
-    print(name, "all-wide need", int(full[5]), "steps", int(full[0]), "-> (limit, narrow nodes, steps)", narrowed, "pair steps", int(pair_cnt[0]))
-
-
 def test_subdivision_cuts_triangle_tests_on_big_leaves(harness, oracle):
     sc = scenes.cornell_box(compiler="reference")  # leaves of up to 10 triangles, as `polaris render` compiles them
     _, _, rays = camera_and_bounce_rays(oracle, sc)
@@ -340,7 +250,7 @@ def test_corrupted_scenes_are_rejected_not_followed(asan_harness, name, tmp_path
 
 def _layout_error(lib, sc, max_leaf=2):
     hit = np.zeros((1, 6), np.int32)
-    cnt = np.zeros(8, np.uint64)
+    cnt = np.zeros(7, np.uint64)
     rays = np.zeros((1, 8), np.float32)
     rays[0, 4] = 1.0
     err = C.create_string_buffer(256)
