@@ -68,6 +68,9 @@ struct BvhDev {
 	// dependent global loads per ray.  root_is_instance = 0 otherwise.
 	int root_is_instance;
 	InstRec root_inst;
+	// Tiny-scene mode (kNodesLdsAll): the workgroup's dynamic LDS block, sized by the host for the uploaded scene (polaris_hip.hip,
+	// plan_tiny_lds; layout in k_trace).
+	uint32_t tiny_stack_off, lds_tris; // byte offset of the first real stack row (>= one row); triangle slots kept in LDS
 };
 
 struct Streams {
@@ -395,6 +398,10 @@ constexpr uint32_t kTinyMaxIndex = 2046; // triangle slots and leaf ids must fit
 // its own there: -32768 (= ~(2047 << 4 | 15), a leaf code kTinyMaxIndex rules out).
 constexpr int kTinyExitMarker = -32768;
 
+// Tiny mode keeps ONE word per triangle slot beside the 36 bytes of its vertices: rank << 19 | shading class << 11 | triangle
+// (TriRec.e2.w, written at upload for scenes of <= kTinyMaxIndex triangle slots: scene_layout.h tiny_meta_word).  -1 = no hit.
+__device__ __forceinline__ int tiny_meta_tri(int word) { return word < 0 ? -1 : (int)(((uint32_t)word & 0x7FFu) | ((uint32_t)word >> 11 & 0xFFu) << 24); }
+
 template <bool ANY_HIT, int STACK, int NODES>
 __global__ __launch_bounds__(NODES == kNodesLdsAll ? kTinyBlock : WG)
 __attribute__((amdgpu_waves_per_eu(NODES == kNodesLdsAll ? 8 : ((!ANY_HIT && STACK == 16) ? 7 : 1), NODES == kNodesLdsAll ? 8 : ((!ANY_HIT && STACK == 16) ? 7 : 10))))
@@ -411,20 +418,36 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 	// The per-lane node stack: a column of an LDS array.  A lane keeps its stack pointer as the BYTE OFFSET of its top entry
 	// (sp0 = empty, + kRow per entry), so a pop reads at `sp` and a push writes at `sp + kRow` with no address arithmetic;
 	// row 0 is a dummy, so that "the entry below an empty stack" can be read (and ignored) without a clamp.
-	__shared__ StackEntry stk[STACK + 1][BLOCK];
+	// Tiny mode: ONE dynamic LDS block laid out by the host for the uploaded scene (polaris_hip.hip, plan_tiny_lds):
+	//   [num_pairs pair records, 64 B][lds_tris triangle records, 36 B: v0, e1, e2][lds_tris packed words, 4 B][stack rows]
+	// i.e. exactly the stack rows the tree needs, its pair records, and as many triangle records as the rest of half a CU's LDS
+	// holds (slots are in descending order of how often a ray reaches their leaf, scene_layout.h: what does not fit -- the tail of
+	// a small sphere's facets -- stays in global memory).  The dummy row below the stack is whatever precedes the stack (it is
+	// read and ignored, never written).  Two such workgroups share a CU's 160 KB (gfx950) = 8 waves per SIMD.
+	extern __shared__ __attribute__((aligned(16))) char tiny_lds[];
+	__shared__ StackEntry stk[TINY ? 1 : STACK + 1][TINY ? 1 : BLOCK];
 	constexpr uint32_t kRow = BLOCK * sizeof(StackEntry);
 	__shared__ uint32_t wg_cursor;
 	if (threadIdx.x == 0) wg_cursor = 0;
-	__shared__ float4 top[TINY ? kTinyPairs * 4 : (LDS_TOP ? kLdsTopNodes * 4 : 1)];
-	// tiny mode: the host's grid and occupancy heuristics assume TWO of these workgroups share a CU's 160 KB of LDS (gfx950)
-	static_assert(!TINY || 2 * (sizeof(stk) + sizeof(top) + 64) <= 160 * 1024, "tiny mode: two workgroups must fit one CU's LDS");
+	__shared__ float4 top_static[LDS_TOP ? kLdsTopNodes * 4 : 1];
+	float4 *const top = TINY ? reinterpret_cast<float4 *>(tiny_lds) : top_static;
+	float *const ltri = TINY ? reinterpret_cast<float *>(tiny_lds + (size_t)B.num_pairs * sizeof(PairNode)) : nullptr; // 9 floats per slot, slots [0, B.lds_tris)
+	uint32_t *const lmeta = TINY ? reinterpret_cast<uint32_t *>(ltri + 9 * (size_t)B.lds_tris) : nullptr;            // tiny_meta word per slot
 	if (LDS_TOP || TINY) {
-		const uint32_t n4 = min((uint32_t)(TINY ? kTinyPairs : kLdsTopNodes), B.num_pairs) * 4;
+		const uint32_t n4 = (TINY ? B.num_pairs : min((uint32_t)kLdsTopNodes, B.num_pairs)) * 4;
 		const float4 *src = reinterpret_cast<const float4 *>(B.pairs);
 		for (uint32_t i = threadIdx.x; i < n4; i += BLOCK) top[i] = src[i];
+		if (TINY) {
+			for (uint32_t i = threadIdx.x; i < B.lds_tris; i += BLOCK) { // (one thread per slot: three 16-byte loads, ten LDS words)
+				const TriRec T = B.tris[i];
+				float *t9 = ltri + 9 * i;
+				t9[0] = T.v0.x; t9[1] = T.v0.y; t9[2] = T.v0.z; t9[3] = T.e1.x; t9[4] = T.e1.y; t9[5] = T.e1.z; t9[6] = T.e2.x; t9[7] = T.e2.y; t9[8] = T.e2.z;
+				lmeta[i] = (uint32_t)fbits(T.e2.w);
+			}
+		}
 	}
 	__syncthreads();
-	char *const stk_bytes = reinterpret_cast<char *>(&stk[0][0]);
+	char *const stk_bytes = TINY ? tiny_lds + B.tiny_stack_off - kRow : reinterpret_cast<char *>(&stk[0][0]);
 	const int tid = threadIdx.x;
 	const uint32_t sp0 = (uint32_t)tid * (uint32_t)sizeof(StackEntry);
 	auto push_ref = [&](uint32_t at, int ref) { *reinterpret_cast<StackEntry *>(stk_bytes + at + kRow) = (StackEntry)ref; }; // onto a stack whose pointer is `at`
@@ -488,9 +511,8 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 			               I.r2.x * d.x + I.r2.y * d.y + I.r2.z * d.z};
 			o = no; d = nd;
 			irank = (uint32_t)I.meta.y;
-			push_ref(sp0, EXIT); // (nothing is ever pending below it: popping it ends the ray without a restore)
-			sp = sp0 + kRow;
-			cur = I.meta.x;
+			cur = I.meta.x; // (no exit marker: nothing is ever pending below this instance, so an empty stack ends the ray -- and the
+			                //  stack needs one row less: polaris_hip.hip plan_tiny_lds)
 		}
 		inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)}; // native_recip(ray.dir), intersect.cl:302
 		best_t = maxDist; best_tri = -1; best_u = best_v = 0.0f; best_irank = best_trank = 0;
@@ -573,7 +595,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 				}
 				unocc++;
 			} else {
-				st.hit[slot] = make_float4(best_u, best_v, best_t, ibits(best_tri));
+				st.hit[slot] = make_float4(best_u, best_v, best_t, ibits(TINY ? tiny_meta_tri(best_tri) : best_tri));
 			}
 			cur = kIdle;
 		}
@@ -641,13 +663,14 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 				bool occluded = false;
 				uint32_t i = 0; // (bottom-tested: some lane holds a leaf, and a leaf has at least one triangle)
 				// one triangle through Moeller-Trumbore (intersect.cl:255-292) without early exits; updates the lane's hit record
-				auto test_tri = [&](const TriRec &T) {
-					const f3 e1 = xyz(T.e1), e2 = xyz(T.e2);
+				// (tiny mode: `word` is the slot's tiny_meta word -- rank | class | triangle -- and best_tri holds the best hit's word:
+				// ranks are unique within a mesh and sit in the top bits, so comparing the words compares the ranks)
+				auto test_tri = [&](f3 v0, f3 e1, f3 e2, uint32_t trank, int word) {
 					const f3 pv = cross(d, e2);
 					const float det = dot(e1, pv);
 					bool ok = !(pm_fabs(det) < kEps);
 					const float idet = rcp_det(det);
-					const f3 tv = o - xyz(T.v0);
+					const f3 tv = o - v0;
 					const float u = dot(tv, pv) * idet;
 					ok = ok && !(u < 0.0f || u > 1.0f);
 					const f3 qv = cross(tv, e1);
@@ -658,20 +681,30 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 					if (ANY_HIT) {
 						occluded = occluded || (ok && tt < maxDist);
 					} else {
-						const uint32_t trank = (uint32_t)fbits(T.v0.w);
 						const bool closer = tt < best_t;
-						const bool tie = tt == best_t && best_tri >= 0 && (irank < best_irank || (irank == best_irank && trank < best_trank));
+						const bool lower = TINY ? (uint32_t)word < (uint32_t)best_tri : trank < best_trank;
+						const bool tie = tt == best_t && best_tri >= 0 && (irank < best_irank || (irank == best_irank && lower));
 						const bool take = ok && (closer || tie);
 						best_t = take ? tt : best_t; best_u = take ? u : best_u; best_v = take ? v : best_v;
-						best_tri = take ? fbits(T.e1.w) : best_tri;
-						best_irank = take ? irank : best_irank; best_trank = take ? trank : best_trank;
+						best_tri = take ? word : best_tri;
+						best_irank = take ? irank : best_irank;
+						if (!TINY) best_trank = take ? trank : best_trank;
 					}
 				};
 				// (round 4 A/B: two triangles per round -- six loads in flight, half the rounds -- where the tree is read from global
 				// memory, and 64-byte triangle records that never straddle a line: both within +-2 % on the terrain, C4 and C5,
 				// profiles/r04_tri_variants_ab.txt)
 				do {
-					if (i < ntri && !occluded) test_tri(B.tris[first + i]);
+					if (i < ntri && !occluded) {
+						const uint32_t s = first + i;
+						if (TINY && s < B.lds_tris) { // (two explicit paths: one fetch through a selected pointer would be a FLAT load)
+							const float *t9 = ltri + 9 * s;
+							test_tri(f3{t9[0], t9[1], t9[2]}, f3{t9[3], t9[4], t9[5]}, f3{t9[6], t9[7], t9[8]}, 0u, (int)lmeta[s]);
+						} else {
+							const TriRec T = B.tris[s];
+							test_tri(xyz(T.v0), xyz(T.e1), xyz(T.e2), (uint32_t)fbits(T.v0.w), fbits(TINY ? T.e2.w : T.e1.w));
+						}
+					}
 					i++;
 				} while (__ballot(i < ntri && !occluded) != 0ull);
 				if (tl) {

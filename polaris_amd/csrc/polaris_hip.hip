@@ -95,6 +95,8 @@ struct polaris_hip_tracer {
 	int opt_node_mode = -1;       // -1 = by scene size
 	uint32_t tex_bytes = 0; // size of the uploaded texture blob (without its padding)
 	int trace_resident_per_cu = 6, occl_resident_per_cu = 6; // workgroups of the selected k_trace<closest | any hit> variant a CU holds at once (occupancy API, at upload)
+	uint32_t tiny_lds_bytes = 0;  // tiny-scene mode: the dynamic LDS block of a k_trace workgroup (stack rows + tree + triangle records: plan_tiny_lds)
+	int opt_lds_tris = -1;        // tiny-scene mode: triangle records kept in LDS; -1 = as many as fit, 0 = none (A/B aid)
 
 	// camera (tracer.go:175-179)
 	bool have_camera = false;
@@ -397,7 +399,47 @@ hipError_t launch_trace(polaris_hip_tracer *h, polaris_hip_tracer::Pipe &P, cons
 	int block = WG;
 	const void *fn = trace_kernel<ANY_HIT>(h, &block);
 	void *args[] = {(void *)&st, (void *)&h->bvh, (void *)&chunks, (void *)&acc, (void *)&h->d_stats};
-	return hipLaunchKernel(fn, dim3(grid), dim3(block), args, 0, P.q);
+	return hipLaunchKernel(fn, dim3(grid), dim3(block), args, h->node_mode == kNodesLdsAll ? h->tiny_lds_bytes : 0, P.q);
+}
+
+// Tiny-scene mode: lay out the dynamic LDS block of a k_trace workgroup for the uploaded scene (kernels.h, k_trace) -- the stack
+// rows its tree needs, its pair records, and as many triangle records (slots in descending order of how often their leaf is
+// reached, scene_layout.h) as still fit while TWO workgroups share a CU's LDS, which the occupancy query confirms.
+int plan_tiny_lds(polaris_hip_tracer *h, size_t n_slots) {
+	// (no dummy row: the bytes in front of the stack serve; a scene that IS one instance is entered at ray set-up without an exit
+	// marker, which the layout's stack need counts)
+	const uint32_t rows = (uint32_t)std::max(1, h->max_stack - (h->bvh.root_is_instance ? 1 : 0));
+	constexpr uint32_t kRowBytes = kTinyBlock * (uint32_t)sizeof(int16_t), kTriBytes = 9 * sizeof(float) + sizeof(uint32_t);
+	const uint32_t nodes = h->bvh.num_pairs * (uint32_t)sizeof(PairNode);
+	hipDeviceProp_t prop;
+	size_t lds_per_cu = 160 * 1024;
+	if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.maxSharedMemoryPerMultiProcessor > 0) lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;
+	const size_t half = lds_per_cu / 2;
+	const size_t slack = 256; // the kernel's static LDS (work cursor, dummy arrays)
+	auto stack_off = [&](uint32_t tris) { return std::max<uint32_t>(kRowBytes, (nodes + tris * kTriBytes + 15u) & ~15u); };
+	if (stack_off(0) + rows * kRowBytes + slack > half) return fail(h, POLARIS_E_DEVICE, "tiny-scene mode: stack and tree do not fit half a CU's LDS (%zu bytes)", half);
+	uint32_t tris = (uint32_t)std::min<size_t>(n_slots, (half - slack - rows * kRowBytes - nodes - 16) / kTriBytes);
+	// a wave with lanes on both fetch paths pays for both: below half of the slots the LDS copy costs more than it saves (measured:
+	// 150 of the Cornell box's 808 slots +2 % frame time, 300 -1.5 %, 532 -3.5 %)
+	if (tris < n_slots / 2) tris = 0;
+	if (h->opt_lds_tris >= 0) tris = std::min<uint32_t>(tris, (uint32_t)h->opt_lds_tris);
+	for (;;) {
+		h->bvh.tiny_stack_off = stack_off(tris);
+		h->bvh.lds_tris = tris;
+		h->tiny_lds_bytes = h->bvh.tiny_stack_off + rows * kRowBytes;
+		int worst = 8;
+		for (int any = 0; any < 2; any++) {
+			const void *fn = any ? (const void *)k_trace<true, 16, kNodesLdsAll> : (const void *)k_trace<false, 16, kNodesLdsAll>;
+			HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->tiny_lds_bytes));
+			int n = 0;
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, kTinyBlock, h->tiny_lds_bytes) != hipSuccess) { (void)hipGetLastError(); n = 2; } // (no answer: trust the arithmetic)
+			worst = std::min(worst, n);
+		}
+		if (worst >= 2 || tris == 0) break;
+		tris = tris > 32 ? tris - 32 : 0; // the allocation granularity was coarser than assumed: give some back
+	}
+	if (getenv("POLARIS_DEBUG")) fprintf(stderr, "[polaris] tiny mode: %u stack rows at %u, %u pair records, %u of %zu triangle records in LDS (%u bytes per workgroup)\n", rows, h->bvh.tiny_stack_off, h->bvh.num_pairs, h->bvh.lds_tris, n_slots, h->tiny_lds_bytes);
+	return POLARIS_OK;
 }
 
 // Resident workgroups per CU of the k_trace variant launch_trace<ANY_HIT> picks.
@@ -405,7 +447,7 @@ template <bool ANY_HIT>
 int trace_occupancy(polaris_hip_tracer *h) {
 	int block = WG, n = 0;
 	const void *fn = trace_kernel<ANY_HIT>(h, &block);
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, block, 0) != hipSuccess || n < 1) n = h->node_mode == kNodesLdsAll ? 1 : (h->max_stack <= 24 ? 6 : 5);
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, block, h->node_mode == kNodesLdsAll ? h->tiny_lds_bytes : 0) != hipSuccess || n < 1) n = h->node_mode == kNodesLdsAll ? 1 : (h->max_stack <= 24 ? 6 : 5);
 	if (getenv("POLARIS_DEBUG")) fprintf(stderr, "[polaris] k_trace<%d> node mode %d: %d resident workgroups of %d threads per CU\n", (int)ANY_HIT, h->node_mode, n, block);
 	return std::min(n, 8);
 }
@@ -763,7 +805,7 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 	if (!rc && sc->texture_data_bytes) HIP_TRY(h, hipMemcpyAsync(tex_data, sc->texture_data, sc->texture_data_bytes, hipMemcpyHostToDevice, h->stream));
 	if (rc) { free_pool(h->scene_bufs); return rc; }
 	HIP_TRY(h, hipStreamSynchronize(h->stream)); // host vectors in L die at return
-	h->bvh = BvhDev{pairs, (uint32_t)L.pairs.size(), leaves, tris, insts, L.root_ref, 0, InstRec{}};
+	h->bvh = BvhDev{pairs, (uint32_t)L.pairs.size(), leaves, tris, insts, L.root_ref, 0, InstRec{}, 0, 0};
 	if (L.root_ref < 0 && (((uint32_t)~L.root_ref) & 15u) == 0u && !(((uint32_t)~L.root_ref) & kBigLeafFlag)) { // the top-level tree is a single leaf ...
 		const size_t root_inst = ((uint32_t)~L.root_ref) >> 4; // (... which, in the top-level tree, is an instance: its id is in the reference)
 		if (root_inst < L.insts.size()) { // its record goes with the kernel arguments
@@ -785,12 +827,19 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 	// origin stream unwritten); on the 58 K-triangle ball the packet's dependent scalar node fetches cost more than the per-ray
 	// kernel's gathers (camera rays 5.5 vs 4.1 ms per 32 spp, frame -1.8 %); in a scene of many instances the packet's lanes part
 	// ways inside the instances (-5 % frame time per-ray on the 1 024-instance scene, -26 % on the 1 M-triangle terrain)
+	// (round 4, later: with the triangle records in LDS the per-ray kernel of the tiny-scene mode is ahead -- camera rays 0.93 vs
+	// 1.20 ms isolated, frame 10.96 vs 11.03 ms, three alternating runs: see below, after the node mode is known)
 	if (h->opt_packet_primary < 0) h->packet_primary = sc->num_triangles <= 32768u && sc->num_mesh_instances == 1;
 	// node records: whole tree in LDS for tiny scenes, its top for small ones, global memory otherwise (kernels.h NodeMode)
 	// (16-bit stack entries: triangle slots and instance ids must fit 11 bits, and no leaf reference may carry kBigLeafFlag)
 	const bool tiny_ok = L.pairs.size() <= (size_t)kTinyPairs && L.tris.size() <= kTinyMaxIndex && L.insts.size() <= kTinyMaxIndex && L.big_leaves == 0 && L.max_stack <= 16;
 	h->node_mode = tiny_ok ? kNodesLdsAll : (L.pairs.size() <= (size_t)(POLARIS_LDS_TOP_MAX_PAIRS) ? kNodesLdsTop : kNodesGlobal);
 	if (h->opt_node_mode >= 0 && (h->opt_node_mode != kNodesLdsAll || tiny_ok)) h->node_mode = h->opt_node_mode;
+	h->tiny_lds_bytes = 0;
+	if (h->node_mode == kNodesLdsAll) {
+		if (int prc = plan_tiny_lds(h, L.tris.size())) return prc;
+		if (h->opt_packet_primary < 0 && h->bvh.lds_tris > 0) h->packet_primary = false;
+	}
 	h->trace_resident_per_cu = trace_occupancy<false>(h);
 	h->occl_resident_per_cu = trace_occupancy<true>(h);
 	h->have_scene = true;
@@ -830,6 +879,7 @@ int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value
 	else if (k == "overlap") h->opt_overlap = (int)std::max<int64_t>(1, std::min<int64_t>(value, polaris_hip_tracer::kMaxPipes));
 	else if (k == "trace_grid") h->opt_trace_grid = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20));
 	else if (k == "trace_wgs_per_cu") h->opt_trace_wgs_per_cu = (int)std::max<int64_t>(0, std::min<int64_t>(value, 64));
+	else if (k == "lds_tris") h->opt_lds_tris = (int)std::max<int64_t>(-1, std::min<int64_t>(value, 1 << 20)); // next upload
 	else if (k == "max_leaf_tris") h->opt_max_leaf_tris = (int)std::max<int64_t>(-1, std::min<int64_t>(value, 1 << 20)); // next upload
 	else return fail(h, POLARIS_E_BAD_ARGUMENT, "unknown option '%s'", key);
 	return POLARIS_OK;

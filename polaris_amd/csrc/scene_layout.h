@@ -44,6 +44,8 @@ struct LeafInfoH { int32_t ldata, rdata; };
 struct TriH { float v0[3]; uint32_t rank; float e1[3]; uint32_t orig; float e2[3]; uint32_t pad2; };
 struct InstH { float r0[4], r1[4], r2[4]; int32_t root_ref; uint32_t rank; uint32_t pad[2]; };
 static_assert(sizeof(PairNodeH) == 64 && sizeof(TriH) == 48 && sizeof(InstH) == 64, "layout");
+// rank << 19 | shading class << 11 | scene triangle: one word per triangle slot for scenes of < 2 047 triangles (kernels.h tiny_meta_tri)
+inline uint32_t tiny_meta_word(uint32_t rank, uint32_t orig) { return rank << 19 | (orig >> 24 & 0xFFu) << 11 | (orig & 0x7FFu); }
 
 constexpr float kCullMargin = 1.001f; // a subtree is skipped when its box starts beyond kCullMargin x the best hit distance
 constexpr float kSplitCost = 1.0f;  // cost of one added pair-of-boxes step, in triangle tests (leaf subdivision)
@@ -648,6 +650,49 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out, in
 		for (uint32_t i = 0; i < NI; i++) out.insts[i].root_ref = remap(out.insts[i].root_ref);
 	}
 
+	// ---- small scenes: triangle slots in the order of how often a ray reaches their leaf ------------------------------------------
+	// The tiny-scene traversal mode (kernels.h, kNodesLdsAll) keeps as many triangle records as fit beside the tree in LDS: the
+	// slots [0, lds_tris).  A leaf is reached about as often as its box is large (surface area), so the leaves take their slots in
+	// descending order of that -- the walls of a room before the facets of a small sphere.  (Bigger scenes keep the depth-first
+	// order: there the neighbours of a record in memory are its neighbours in space, which is what the caches want.)
+	if (n_slots <= 2046u && out.big_leaves == 0) { // (2046: kernels.h kTinyMaxIndex)
+		struct HotLeaf { float area; uint32_t first, count; };
+		std::vector<HotLeaf> hot;
+		auto note_leaf = [&](int32_t ref, const float *lo, const float *hi) {
+			if (ref >= 0) return;
+			const uint32_t code = (uint32_t)~ref;
+			if ((code & 15u) == 0u) return; // an instance
+			float area = std::numeric_limits<float>::infinity(); // (a tree that is one leaf: no box, always reached)
+			if (lo) { const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2]; area = dx * dy + dy * dz + dz * dx; if (!(area >= 0.0f)) area = 0.0f; }
+			hot.push_back({area, code >> 4, code & 15u});
+		};
+		for (const PairNodeH &P : out.pairs) { note_leaf(P.ref0, P.lo0, P.hi0); note_leaf(P.ref1, P.lo1, P.hi1); }
+		note_leaf(out.root_ref, nullptr, nullptr);
+		for (uint32_t i = 0; i < NI; i++) note_leaf(out.insts[i].root_ref, nullptr, nullptr);
+		std::stable_sort(hot.begin(), hot.end(), [](const HotLeaf &a, const HotLeaf &b) { return a.area > b.area; });
+		std::vector<uint32_t> new_first(n_slots, 0xFFFFFFFFu), new_src;
+		new_src.reserve(n_slots);
+		bool clean = true; // every slot in exactly one leaf (leaves shared by two parents keep one place)
+		for (const HotLeaf &h : hot) {
+			if (h.first + h.count > n_slots) { clean = false; break; }
+			if (new_first[h.first] != 0xFFFFFFFFu) continue; // (the same leaf under a second parent: a mesh shared by instances)
+			new_first[h.first] = (uint32_t)new_src.size();
+			for (uint32_t q = h.first; q < h.first + h.count; q++) new_src.push_back(slot_src[q]);
+		}
+		if (clean && new_src.size() == n_slots) {
+			auto moved = [&](int32_t ref) -> int32_t {
+				if (ref >= 0) return ref;
+				const uint32_t code = (uint32_t)~ref;
+				if ((code & 15u) == 0u) return ref;
+				return ~(int32_t)((new_first[code >> 4] << 4) | (code & 15u));
+			};
+			for (PairNodeH &P : out.pairs) { P.ref0 = moved(P.ref0); P.ref1 = moved(P.ref1); }
+			out.root_ref = moved(out.root_ref);
+			for (uint32_t i = 0; i < NI; i++) out.insts[i].root_ref = moved(out.insts[i].root_ref);
+			slot_src.swap(new_src);
+		}
+	}
+
 	std::vector<uint8_t> node_class;
 	shading_classes(sc, node_class);
 	out.tri_bits = NT <= (1u << 24) ? 24 : 31;
@@ -659,6 +704,7 @@ inline std::string build_layout(const PolarisSceneView &sc, SceneLayout &out, in
 		for (int k = 0; k < 3; k++) { d.v0[k] = v0[k]; d.e1[k] = v1[k] - v0[k]; d.e2[k] = v2[k] - v0[k]; }
 		d.rank = tri_rank[t] == 0xFFFFFFFFu ? t : tri_rank[t];
 		d.orig = out.tri_bits < 31 ? (t | (uint32_t)node_class[sc.material_index[t]] << out.tri_bits) : t;
+		d.pad2 = (n_slots <= 2046u && NT <= 2046u) ? tiny_meta_word(d.rank, d.orig) : 0u; // (what the tiny-scene traversal mode keeps per slot)
 	}
 	return "";
 }
