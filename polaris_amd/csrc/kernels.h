@@ -545,7 +545,10 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 		// NEXT ray staged in eight registers, loaded in front of the inner phase -- which issues no vector-memory instruction
 		// in the tiny mode -- and an idle lane restarts from them without touching memory.  60 / 63 VGPRs, no spill, bit-exact,
 		// and closest hit 4.4 against 4.0 ms, any hit 2.7 against 2.4: vmcnt is in order, so the first triangle fetch after
-		// a top-up waits for the top-up as well, and the wave is parked there instead of here.)
+		// a top-up waits for the top-up as well, and the wave is parked there instead of here.  Round 4 tried it a fourth time
+		// with the triangle records in LDS -- no vector-memory wait left in either loop, checked in the ISA -- and it is still
+		// 5 % slower per kernel: with 8 waves per SIMD the parked wave costs nothing, the kernel is bound by instruction issue,
+		// and the staging adds instructions.  EXPERIMENTS.md.)
 		{
 			const unsigned long long freem = __ballot(cur == kIdle);
 			if (!drained && (freem == ~0ull || __popcll(freem) >= (ANY_HIT ? kRefillMinAny : kRefillMin)))
