@@ -369,6 +369,23 @@ __device__ __forceinline__ bool slab_hit_hw(float4 lo, float4 hi, f3 o, f3 inv, 
 	return !(minmax < 0) && !(maxmin > minmax) && !(maxmin >= maxDist) && maxmin < kFltMax;
 }
 
+// The same predicate with fewer compares, for a caller that hands in boxDist = minNum(maxDist, FLT_MAX) (v_min_f32: a NaN or
+// infinite maxDist becomes FLT_MAX):
+//   !(maxmin >= maxDist) && maxmin < FLT_MAX  ==  maxmin < boxDist     for every maxmin and maxDist: a finite maxDist <= FLT_MAX
+//       makes the second compare redundant for ordered maxmin and both sides are false for a NaN maxmin; for maxDist = +inf or
+//       NaN the left side is "maxmin < FLT_MAX", which is the right side with boxDist = FLT_MAX;
+//   !(minmax < 0) && !(maxmin > minmax)       ==  !(maxNum(maxmin, 0) > minmax): a NaN minmax passes on both sides, a NaN maxmin
+//       leaves "!(0 > minmax)" = "!(minmax < 0)" on both, and for ordered values both say 0 <= minmax and maxmin <= minmax
+//       (the sign of a zero makes no difference to > or <).
+__device__ __forceinline__ bool slab_hit_fast(float4 lo, float4 hi, f3 o, f3 inv, float boxDist, float &t) {
+	float t0x = (lo.x - o.x) * inv.x, t0y = (lo.y - o.y) * inv.y, t0z = (lo.z - o.z) * inv.z;
+	float t1x = (hi.x - o.x) * inv.x, t1y = (hi.y - o.y) * inv.y, t1z = (hi.z - o.z) * inv.z;
+	float minmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)), __builtin_fmaxf(t0z, t1z));
+	float maxmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)), __builtin_fminf(t0z, t1z));
+	t = maxmin;
+	return !(__builtin_fmaxf(maxmin, 0.0f) > minmax) && maxmin < boxDist;
+}
+
 // The closest-hit kernel with the 16-entry stack is asked for 7 waves per SIMD (20 KB of LDS per workgroup: -2.4 % kernel
 // time on the Cornell box, -9 % on the sphere scene); the any-hit variant fits 7 by itself since the rewrite.
 // negative node codes that are not leaf references (a leaf code first << 4 | count never has all of bits 4..30 set)
@@ -402,11 +419,15 @@ constexpr int kTinyExitMarker = -32768;
 // (TriRec.e2.w, written at upload for scenes of <= kTinyMaxIndex triangle slots: scene_layout.h tiny_meta_word).  -1 = no hit.
 __device__ __forceinline__ int tiny_meta_tri(int word) { return word < 0 ? -1 : (int)(((uint32_t)word & 0x7FFu) | ((uint32_t)word >> 11 & 0xFFu) << 24); }
 
-template <bool ANY_HIT, int STACK, int NODES>
+// ONE = the scene IS one mesh instance (BvhDev::root_is_instance) and every box of its tree bounds its subtree -- the usual
+// small scene.  The tiny mode has a variant compiled for that: no instance leaves, no exit markers, no instance rank to carry
+// or compare, one cull limit per ray (best distance x 1.001, refreshed when a leaf changes it) instead of one product per child.
+template <bool ANY_HIT, int STACK, int NODES, bool ONE = false>
 __global__ __launch_bounds__(NODES == kNodesLdsAll ? kTinyBlock : WG)
 __attribute__((amdgpu_waves_per_eu(NODES == kNodesLdsAll ? 8 : ((!ANY_HIT && STACK == 16) ? 7 : 1), NODES == kNodesLdsAll ? 8 : ((!ANY_HIT && STACK == 16) ? 7 : 10))))
 void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned long long *stats) {
 	constexpr bool LDS_TOP = NODES == kNodesLdsTop, TINY = NODES == kNodesLdsAll;
+	static_assert(!ONE || TINY, "the single-instance variant exists for the tiny mode only");
 	constexpr int BLOCK = TINY ? kTinyBlock : WG; // threads per workgroup (a CHUNK of rays is always WG = 256 slots)
 	typedef typename std::conditional<TINY, int16_t, int>::type StackEntry;
 	constexpr int EXIT = TINY ? kTinyExitMarker : kExitMarker; // the instance exit marker as this variant's stack holds it
@@ -463,6 +484,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 	uint32_t slot = 0; // per-lane ray state
 	f3 o = {0, 0, 0}, d = {0, 0, 0}, inv = {0, 0, 0};
 	float maxDist = 0.0f;
+	float boxDist = 0.0f, best_cull = 0.0f; // ONE: minNum(maxDist, FLT_MAX) for the box tests (slab_hit_fast); best_t x kCullMargin
 	uint32_t sp = sp0;
 	int cur = kIdle, cell = 0;
 	uint32_t irank = 0, unocc = 0;
@@ -503,7 +525,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 		sp = sp0;
 		cur = B.root_ref;
 		irank = 0;
-		if (B.root_is_instance) { // enter the scene's one instance right away (intersect.cl:239-252; mul4x1 / mul3x1, util/transform.cl:9-26)
+		if (ONE || B.root_is_instance) { // enter the scene's one instance right away (intersect.cl:239-252; mul4x1 / mul3x1, util/transform.cl:9-26)
 			const InstRec &I = B.root_inst;
 			const f3 no = {I.r0.x * o.x + I.r0.y * o.y + I.r0.z * o.z + I.r0.w, I.r1.x * o.x + I.r1.y * o.y + I.r1.z * o.z + I.r1.w,
 			               I.r2.x * o.x + I.r2.y * o.y + I.r2.z * o.z + I.r2.w};
@@ -516,6 +538,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 		}
 		inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)}; // native_recip(ray.dir), intersect.cl:302
 		best_t = maxDist; best_tri = -1; best_u = best_v = 0.0f; best_irank = best_trank = 0;
+		if (ONE) { boxDist = __builtin_fminf(maxDist, kFltMax); best_cull = best_t * kCullMargin; }
 	};
 	// the next rays of the workgroup's chunks go to the lanes for which wants() holds (take(slot) must make it false)
 	auto draw = [&](auto wants, auto take) {
@@ -539,6 +562,15 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 			off += share;
 		}
 	};
+#ifdef POLARIS_PROFILE_LOOPS
+	// profiling build (scripts/loop_profile.sh): wave-level iteration counts and the lanes that were live in them -- closest hit in
+	// ST_DEBUG + 0..7, any hit in + 8..15: [0] outer iterations [1] lanes holding a ray in them [2] node steps [3] lanes descending
+	// [4] triangle rounds [5] lanes testing [6] refills [7] rays started
+	unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PROF(i, v) pc[i] += (unsigned long long)(v)
+#else
+#define PROF(i, v) ((void)0)
+#endif
 	for (;;) {
 		// ---- refill idle lanes from the workgroup's chunks -------------------------------------------
 		// (Round 3 tried the asynchronous version once more, now that the kernel has registers to spare: every lane keeps its
@@ -551,17 +583,22 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 		// and the staging adds instructions.  EXPERIMENTS.md.)
 		{
 			const unsigned long long freem = __ballot(cur == kIdle);
-			if (!drained && (freem == ~0ull || __popcll(freem) >= (ANY_HIT ? kRefillMinAny : kRefillMin)))
+			if (!drained && (freem == ~0ull || __popcll(freem) >= (ANY_HIT ? kRefillMinAny : kRefillMin))) {
+				PROF(6, 1); PROF(7, -(long long)__popcll(__ballot(cur != kIdle)));
 				draw([&]() { return cur == kIdle; }, [&](uint32_t ray_slot) { start_ray(ray_slot, src_o[ray_slot], src_d[ray_slot]); });
+				PROF(7, __popcll(__ballot(cur != kIdle)));
+			}
 			if (__ballot(cur != kIdle) == 0ull) {
 				if (drained) break;
 				continue;
 			}
+			PROF(0, 1); PROF(1, __popcll(__ballot(cur != kIdle)));
 		}
 		// ---- phase 1: descend through inner nodes (intersect.cl:296-328) ---------------------------------
 		// left early once fewer than kStragglers lanes are still descending (they continue next round)
 		// (one step always if anybody descends, further steps while at least kStragglers lanes still do)
 		if (__ballot(cur >= 0) != 0ull) do {
+			PROF(2, 1); PROF(3, __popcll(__ballot(cur >= 0)));
 			if (cur >= 0) {
 				PairNode P;
 				if (TINY || (LDS_TOP && cur < kLdsTopNodes)) { P.lo0 = top[4 * cur]; P.hi0 = top[4 * cur + 1]; P.lo1 = top[4 * cur + 2]; P.hi1 = top[4 * cur + 3]; }
@@ -572,10 +609,12 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 				const bool empty = sp == sp0;
 				const uint32_t spm = sp - kRow;
 				float t0, t1;
-				const bool e0 = slab_hit_hw(P.lo0, P.hi0, o, inv, maxDist, t0), e1 = slab_hit_hw(P.lo1, P.hi1, o, inv, maxDist, t1);
-				// closest hit: cull subtrees that start beyond the best hit (+inf factor = box does not bound its subtree)
-				const bool h0 = e0 && (ANY_HIT || !(t0 > best_t * P.hi0.w));
-				const bool h1 = e1 && (ANY_HIT || !(t1 > best_t * P.hi1.w));
+				const bool e0 = ONE ? slab_hit_fast(P.lo0, P.hi0, o, inv, boxDist, t0) : slab_hit_hw(P.lo0, P.hi0, o, inv, maxDist, t0);
+				const bool e1 = ONE ? slab_hit_fast(P.lo1, P.hi1, o, inv, boxDist, t1) : slab_hit_hw(P.lo1, P.hi1, o, inv, maxDist, t1);
+				// closest hit: cull subtrees that start beyond the best hit (+inf factor = box does not bound its subtree; ONE: every
+				// factor is kCullMargin, and best_cull is that product)
+				const bool h0 = e0 && (ANY_HIT || !(t0 > (ONE ? best_cull : best_t * P.hi0.w)));
+				const bool h1 = e1 && (ANY_HIT || !(t1 > (ONE ? best_cull : best_t * P.hi1.w)));
 				// nearer child first for closest hits (what makes the cull bite); stored order for shadow rays
 				const bool second_first = h1 && (!h0 || (!ANY_HIT && t1 < t0));
 				const int c0 = fbits(P.lo0.w), c1 = fbits(P.lo1.w);
@@ -602,7 +641,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 			}
 			cur = kIdle;
 		}
-		if (cur == EXIT) { // leaving the instance: back to the world-space ray (intersect.cl:330-335)
+		if (!ONE && cur == EXIT) { // leaving the instance: back to the world-space ray (intersect.cl:330-335)
 			if (KEEP_WORLD) { o = wo; d = wd; }
 			else {
 				const float4 o4 = src_o[slot], d4 = src_d[slot];
@@ -611,7 +650,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 			inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)};
 			pop();
 		}
-		if (cur < 0 && cur >= kFirstLeafRef && (((uint32_t)~cur) & 15u) == 0u) { // a top-level leaf, or a leaf of more than 15 triangles
+		if (!ONE && cur < 0 && cur >= kFirstLeafRef && (((uint32_t)~cur) & 15u) == 0u) { // a top-level leaf, or a leaf of more than 15 triangles
 			const uint32_t code = (uint32_t)~cur;
 			if (!(code & kBigLeafFlag)) { // top-level leaf: enter the mesh instance (intersect.cl:239-252); its id is in the reference
 				const InstRec I = B.insts[code >> 4];
@@ -658,7 +697,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 		}
 		// ---- inline leaves (1..15 triangles): Moeller-Trumbore, intersect.cl:255-292, without early exits ----
 		{
-			const bool tl = cur < 0 && cur >= kFirstLeafRef && (((uint32_t)~cur) & 15u) != 0u;
+			const bool tl = cur < 0 && cur >= kFirstLeafRef && (ONE || (((uint32_t)~cur) & 15u) != 0u);
 			if (__ballot(tl) != 0ull) {
 				const uint32_t code = (uint32_t)~cur;
 				const uint32_t first = code >> 4, ntri = tl ? (code & 15u) : 0u;
@@ -686,11 +725,11 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 					} else {
 						const bool closer = tt < best_t;
 						const bool lower = TINY ? (uint32_t)word < (uint32_t)best_tri : trank < best_trank;
-						const bool tie = tt == best_t && best_tri >= 0 && (irank < best_irank || (irank == best_irank && lower));
+						const bool tie = tt == best_t && best_tri >= 0 && (ONE ? lower : (irank < best_irank || (irank == best_irank && lower)));
 						const bool take = ok && (closer || tie);
 						best_t = take ? tt : best_t; best_u = take ? u : best_u; best_v = take ? v : best_v;
 						best_tri = take ? word : best_tri;
-						best_irank = take ? irank : best_irank;
+						if (!ONE) best_irank = take ? irank : best_irank;
 						if (!TINY) best_trank = take ? trank : best_trank;
 					}
 				};
@@ -698,6 +737,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 				// memory, and 64-byte triangle records that never straddle a line: both within +-2 % on the terrain, C4 and C5,
 				// profiles/r04_tri_variants_ab.txt)
 				do {
+					PROF(4, 1); PROF(5, __popcll(__ballot(i < ntri && !occluded)));
 					if (i < ntri && !occluded) {
 						const uint32_t s = first + i;
 						if (TINY && s < B.lds_tris) { // (two explicit paths: one fetch through a selected pointer would be a FLAT load)
@@ -710,6 +750,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 					}
 					i++;
 				} while (__ballot(i < ntri && !occluded) != 0ull);
+				if (ONE && !ANY_HIT) best_cull = best_t * kCullMargin;
 				if (tl) {
 					if (ANY_HIT && occluded) { cur = kIdle; if (!acc) st.vis[slot] = 0; } // blocked: nothing to add
 					else {
@@ -722,6 +763,9 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 			}
 		}
 	}
+#ifdef POLARIS_PROFILE_LOOPS
+	if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&stats[ST_DEBUG + (ANY_HIT ? 8 : 0) + i], pc[i]);
+#endif
 	if (ANY_HIT) {
 		// wave sum -> workgroup sum in LDS -> ONE global atomic per workgroup (contended atomics on a single address run
 		// at ~80/us; see k_shade)

@@ -95,6 +95,8 @@ struct polaris_hip_tracer {
 	int opt_node_mode = -1;       // -1 = by scene size
 	uint32_t tex_bytes = 0; // size of the uploaded texture blob (without its padding)
 	int trace_resident_per_cu = 6, occl_resident_per_cu = 6; // workgroups of the selected k_trace<closest | any hit> variant a CU holds at once (occupancy API, at upload)
+	bool tiny_one = false;        // tiny-scene mode: the scene is one instance whose boxes all bound their subtrees (kernels.h k_trace, ONE); option tiny_one = 0 keeps the general variant
+	int opt_tiny_one = 1;
 	uint32_t tiny_lds_bytes = 0;  // tiny-scene mode: the dynamic LDS block of a k_trace workgroup (stack rows + tree + triangle records: plan_tiny_lds)
 	int opt_lds_tris = -1;        // tiny-scene mode: triangle records kept in LDS; -1 = as many as fit, 0 = none (A/B aid)
 
@@ -377,7 +379,7 @@ inline uint32_t grid_for(size_t n) { return (uint32_t)((n + WG - 1) / WG); }
 template <bool ANY_HIT>
 const void *trace_kernel(polaris_hip_tracer *h, int *block) {
 	*block = h->node_mode == kNodesLdsAll ? kTinyBlock : WG;
-	if (h->node_mode == kNodesLdsAll) return (const void *)k_trace<ANY_HIT, 16, kNodesLdsAll>;
+	if (h->node_mode == kNodesLdsAll) return h->tiny_one ? (const void *)k_trace<ANY_HIT, 16, kNodesLdsAll, true> : (const void *)k_trace<ANY_HIT, 16, kNodesLdsAll, false>;
 	const bool top = h->node_mode == kNodesLdsTop;
 	if (h->max_stack <= 16) return top ? (const void *)k_trace<ANY_HIT, 16, kNodesLdsTop> : (const void *)k_trace<ANY_HIT, 16, kNodesGlobal>;
 	if (h->max_stack <= 24) return top ? (const void *)k_trace<ANY_HIT, 24, kNodesLdsTop> : (const void *)k_trace<ANY_HIT, 24, kNodesGlobal>;
@@ -389,8 +391,8 @@ template <bool ANY_HIT>
 std::string trace_symbol(polaris_hip_tracer *h) {
 	char buf[96];
 	const char *a = ANY_HIT ? "true" : "false";
-	if (h->node_mode == kNodesLdsAll) snprintf(buf, sizeof buf, "pol::k_trace<%s, 16, %d>", a, (int)kNodesLdsAll);
-	else snprintf(buf, sizeof buf, "pol::k_trace<%s, %d, %d>", a, h->max_stack <= 16 ? 16 : (h->max_stack <= 24 ? 24 : 32), h->node_mode);
+	if (h->node_mode == kNodesLdsAll) snprintf(buf, sizeof buf, "pol::k_trace<%s, 16, %d, %s>", a, (int)kNodesLdsAll, h->tiny_one ? "true" : "false");
+	else snprintf(buf, sizeof buf, "pol::k_trace<%s, %d, %d, false>", a, h->max_stack <= 16 ? 16 : (h->max_stack <= 24 ? 24 : 32), h->node_mode);
 	return buf;
 }
 
@@ -429,8 +431,11 @@ int plan_tiny_lds(polaris_hip_tracer *h, size_t n_slots) {
 		h->tiny_lds_bytes = h->bvh.tiny_stack_off + rows * kRowBytes;
 		int worst = 8;
 		for (int any = 0; any < 2; any++) {
-			const void *fn = any ? (const void *)k_trace<true, 16, kNodesLdsAll> : (const void *)k_trace<false, 16, kNodesLdsAll>;
-			HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->tiny_lds_bytes));
+			int block_unused = 0;
+			const void *fn = any ? trace_kernel<true>(h, &block_unused) : trace_kernel<false>(h, &block_unused);
+			// (the attribute belongs to the kernel, not to this handle: always the most any scene may ask for, so that handles
+			// with different scenes in one process do not lower it under each other)
+			HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(half - slack)));
 			int n = 0;
 			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, kTinyBlock, h->tiny_lds_bytes) != hipSuccess) { (void)hipGetLastError(); n = 2; } // (no answer: trust the arithmetic)
 			worst = std::min(worst, n);
@@ -836,6 +841,7 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 	h->node_mode = tiny_ok ? kNodesLdsAll : (L.pairs.size() <= (size_t)(POLARIS_LDS_TOP_MAX_PAIRS) ? kNodesLdsTop : kNodesGlobal);
 	if (h->opt_node_mode >= 0 && (h->opt_node_mode != kNodesLdsAll || tiny_ok)) h->node_mode = h->opt_node_mode;
 	h->tiny_lds_bytes = 0;
+	h->tiny_one = h->node_mode == kNodesLdsAll && h->opt_tiny_one && h->bvh.root_is_instance && L.unbounded_boxes == 0;
 	if (h->node_mode == kNodesLdsAll) {
 		if (int prc = plan_tiny_lds(h, L.tris.size())) return prc;
 		if (h->opt_packet_primary < 0 && h->bvh.lds_tris > 0) h->packet_primary = false;
@@ -879,6 +885,7 @@ int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value
 	else if (k == "overlap") h->opt_overlap = (int)std::max<int64_t>(1, std::min<int64_t>(value, polaris_hip_tracer::kMaxPipes));
 	else if (k == "trace_grid") h->opt_trace_grid = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20));
 	else if (k == "trace_wgs_per_cu") h->opt_trace_wgs_per_cu = (int)std::max<int64_t>(0, std::min<int64_t>(value, 64));
+	else if (k == "tiny_one") h->opt_tiny_one = value != 0; // next upload
 	else if (k == "lds_tris") h->opt_lds_tris = (int)std::max<int64_t>(-1, std::min<int64_t>(value, 1 << 20)); // next upload
 	else if (k == "max_leaf_tris") h->opt_max_leaf_tris = (int)std::max<int64_t>(-1, std::min<int64_t>(value, 1 << 20)); // next upload
 	else return fail(h, POLARIS_E_BAD_ARGUMENT, "unknown option '%s'", key);
@@ -1008,6 +1015,17 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 	HIP_TRY(h, hipStreamSynchronize(q));
 	drain.armed = false; // the join above made q wait for every pipeline
 	collect_timers(h);
+#ifdef POLARIS_PROFILE_LOOPS
+	if (getenv("POLARIS_DEBUG")) { // kernels.h, PROF
+		for (int a = 0; a < 2; a++) {
+			const unsigned long long *c = hs + ST_DEBUG + 8 * a;
+			fprintf(stderr, "[polaris] %s: %llu rays; per ray: %.2f outer iterations, %.2f node steps, %.2f triangle rounds | live lanes: outer %.1f, node step %.1f, triangle round %.1f | "
+			        "wave-level: %llu outer, %llu node, %llu triangle, %llu refills (%.1f rays each)\n", a ? "any hit" : "closest hit", c[7],
+			        (double)c[1] / std::max(1ull, c[7]), (double)c[3] / std::max(1ull, c[7]), (double)c[5] / std::max(1ull, c[7]),
+			        (double)c[1] / std::max(1ull, c[0]), (double)c[3] / std::max(1ull, c[2]), (double)c[5] / std::max(1ull, c[4]), c[0], c[2], c[4], c[6], (double)c[7] / std::max(1ull, c[6]));
+		}
+	}
+#endif
 	for (uint32_t b = 0; b < POLARIS_MAX_BOUNCES; b++) {
 		h->last_shade_counts[3 * b] = b < B ? hs[ST_HITS_BOUNCE + b] : 0;
 		h->last_shade_counts[3 * b + 1] = b < B ? hs[ST_MISSES_BOUNCE + b] : 0;

@@ -74,6 +74,8 @@ def test_hip_vs_oracle_exact_and_batched(built, oracle, name):
                 # where k_trace reads its node records: global memory / top of the tree in LDS / (tiny scenes) whole tree in LDS
                 ({"exact_accumulate": 1, "node_mode": 0}, True), ({"exact_accumulate": 1, "node_mode": 1}, True),
                 ({"exact_accumulate": 1, "node_mode": 2}, True), ({"node_mode": 1, "samples_per_batch": 3}, False),
+                # tiny scenes: the general kernel where the single-instance variant would run; no / few triangle records in LDS
+                ({"exact_accumulate": 1, "tiny_one": 0}, True), ({"exact_accumulate": 1, "lds_tris": 0}, True), ({"tiny_one": 0, "lds_tris": 29, "samples_per_batch": 3}, False),
                 ({"exact_accumulate": 1, "shade_wave": 0}, True), ({"exact_accumulate": 1, "shade_wave_from": 0}, True),
                 ({"shade_wave": 0, "stage_lds": 0, "samples_per_batch": 3}, False), ({"shade_wave_from": 1, "samples_per_batch": 2}, False),
                 # shading order: never sorted by class / sorted from bounce 2 / sorted with the tables in global memory

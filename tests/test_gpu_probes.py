@@ -198,6 +198,7 @@ def test_arbitrary_rays_through_every_traversal_kernel(built, oracle, name):
     assert 0.2 < w_hit.mean() < 1.0 and 0.0 < w_occ.mean()
     variants = [dict(traversal=1, node_mode=m) for m in (0, 1, 2)] + [dict(traversal=0), dict(packet_primary=1, packet_shadow=32)]
     variants += [dict(node_mode=2, lds_tris=0), dict(node_mode=2, lds_tris=37)]  # tiny mode: no / a few triangle records in LDS (both fetch paths in one wave)
+    variants += [dict(node_mode=2, tiny_one=0), dict(node_mode=2, tiny_one=0, lds_tris=37)]  # ... and its general variant where the single-instance one would run
     for opts in variants:
         tr = make_hip_tracer(sc, 8, 8, **opts)
         try:
