@@ -47,6 +47,19 @@ __device__ __forceinline__ float rcp_det(float x) {
 }
 
 
+// native_recip(ray.dir) of intersect.cl:302 as the correctly rounded 1 / x (polaris_math.h pm_rcp) for the three components of
+// a direction: where every lane of the wave has all three magnitudes inside [2^-126, 2^126) -- i.e. always, except for rays that
+// run exactly along an axis plane -- the three-instruction form above is that quotient, bit for bit (the same sweep); otherwise
+// the wave takes the division.  (A NaN component slips through the min / max: both forms return a NaN for it, and no NaN's
+// payload is ever looked at.)
+__device__ __forceinline__ void rcp_dir(float dx, float dy, float dz, float &ix, float &iy, float &iz) {
+	const float ax = __builtin_fabsf(dx), ay = __builtin_fabsf(dy), az = __builtin_fabsf(dz);
+	const float lo = __builtin_fminf(__builtin_fminf(ax, ay), az), hi = __builtin_fmaxf(__builtin_fmaxf(ax, ay), az);
+	const bool fast = lo >= 1.17549435e-38f && hi < 8.50705917e37f; // 2^-126, 2^126
+	if (__ballot(!fast) == 0ull) { ix = rcp_det(dx); iy = rcp_det(dy); iz = rcp_det(dz); }
+	else { ix = pm_rcp(dx); iy = pm_rcp(dy); iz = pm_rcp(dz); }
+}
+
 struct PairNode { float4 lo0, hi0, lo1, hi1; };  // .w of lo0/lo1 carry the child refs (int bits)
 struct TriRec { float4 v0, e1, e2; };             // v0.w = DFS rank, e1.w = scene triangle index (uint bits)
 struct InstRec { float4 r0, r1, r2; int4 meta; }; // meta.x = root ref, meta.y = rank
@@ -536,7 +549,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 			cur = I.meta.x; // (no exit marker: nothing is ever pending below this instance, so an empty stack ends the ray -- and the
 			                //  stack needs one row less: polaris_hip.hip plan_tiny_lds)
 		}
-		inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)}; // native_recip(ray.dir), intersect.cl:302
+		rcp_dir(d.x, d.y, d.z, inv.x, inv.y, inv.z); // native_recip(ray.dir), intersect.cl:302
 		best_t = maxDist; best_tri = -1; best_u = best_v = 0.0f; best_irank = best_trank = 0;
 		if (ONE) { boxDist = __builtin_fminf(maxDist, kFltMax); best_cull = best_t * kCullMargin; }
 	};
@@ -647,7 +660,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 				const float4 o4 = src_o[slot], d4 = src_d[slot];
 				o = xyz(o4); d = xyz(d4);
 			}
-			inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)};
+			rcp_dir(d.x, d.y, d.z, inv.x, inv.y, inv.z);
 			pop();
 		}
 		if (!ONE && cur < 0 && cur >= kFirstLeafRef && (((uint32_t)~cur) & 15u) == 0u) { // a top-level leaf, or a leaf of more than 15 triangles
@@ -663,7 +676,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 				const f3 nd = {I.r0.x * d.x + I.r0.y * d.y + I.r0.z * d.z, I.r1.x * d.x + I.r1.y * d.y + I.r1.z * d.z,
 				               I.r2.x * d.x + I.r2.y * d.y + I.r2.z * d.z};
 				o = no; d = nd;
-				inv = {pm_rcp(d.x), pm_rcp(d.y), pm_rcp(d.z)};
+				rcp_dir(d.x, d.y, d.z, inv.x, inv.y, inv.z);
 				cur = I.meta.x;
 			} else { // more than 15 triangles: re-filed as a run of inline leaves is not possible (count > 15): walk it here
 				const int2 li = B.leaves[(code & (kBigLeafFlag - 1u)) >> 4];

@@ -180,6 +180,12 @@ def _random_rays(sc, n, rng):
     # axis-parallel directions (infinite reciprocals in the slab test)
     k = min(n, 64)
     rays[:k, 4:7] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, k)] * rng.choice([-1.0, 1.0], (k, 1)).astype(np.float32)
+    # one direction component at the edge of / below the normal range: denormal, 2^-127, 2^-126 and its neighbours, both signs (the
+    # kernels' three-instruction reciprocal is only taken for magnitudes in [2^-126, 2^126): kernels.h rcp_dir)
+    tiny = np.array([1e-39, 2.0 ** -127, 2.0 ** -126, np.nextafter(np.float32(2.0 ** -126), np.float32(0)), np.nextafter(np.float32(2.0 ** -126), np.float32(1)), 1e-45, 0.0],
+                    np.float32)
+    for j in range(k, min(n, k + 96)):
+        rays[j, 4 + j % 3] = tiny[j % len(tiny)] * (-1.0 if (j // 7) % 2 else 1.0)
     return rays
 
 
