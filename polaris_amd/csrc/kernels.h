@@ -387,16 +387,15 @@ __device__ __forceinline__ bool slab_hit_hw(float4 lo, float4 hi, f3 o, f3 inv, 
 //   !(maxmin >= maxDist) && maxmin < FLT_MAX  ==  maxmin < boxDist     for every maxmin and maxDist: a finite maxDist <= FLT_MAX
 //       makes the second compare redundant for ordered maxmin and both sides are false for a NaN maxmin; for maxDist = +inf or
 //       NaN the left side is "maxmin < FLT_MAX", which is the right side with boxDist = FLT_MAX;
-//   !(minmax < 0) && !(maxmin > minmax)       ==  !(maxNum(maxmin, 0) > minmax): a NaN minmax passes on both sides, a NaN maxmin
-//       leaves "!(0 > minmax)" = "!(minmax < 0)" on both, and for ordered values both say 0 <= minmax and maxmin <= minmax
-//       (the sign of a zero makes no difference to > or <).
+// (Folding the other two compares into !(maxNum(maxmin, 0) > minmax) is equivalent as well, but costs an instruction more than it
+// saves: the compiler quiets the max3's result with a v_max x, x in front of the maxNum.)
 __device__ __forceinline__ bool slab_hit_fast(float4 lo, float4 hi, f3 o, f3 inv, float boxDist, float &t) {
 	float t0x = (lo.x - o.x) * inv.x, t0y = (lo.y - o.y) * inv.y, t0z = (lo.z - o.z) * inv.z;
 	float t1x = (hi.x - o.x) * inv.x, t1y = (hi.y - o.y) * inv.y, t1z = (hi.z - o.z) * inv.z;
 	float minmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)), __builtin_fmaxf(t0z, t1z));
 	float maxmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)), __builtin_fminf(t0z, t1z));
 	t = maxmin;
-	return !(__builtin_fmaxf(maxmin, 0.0f) > minmax) && maxmin < boxDist;
+	return !(minmax < 0) && !(maxmin > minmax) && maxmin < boxDist;
 }
 
 // The closest-hit kernel with the 16-entry stack is asked for 7 waves per SIMD (20 KB of LDS per workgroup: -2.4 % kernel
@@ -481,9 +480,11 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 		}
 	}
 	__syncthreads();
-	char *const stk_bytes = TINY ? tiny_lds + B.tiny_stack_off - kRow : reinterpret_cast<char *>(&stk[0][0]);
+	// (tiny mode: a lane's stack pointer is its offset in the dynamic block itself -- the block's address is a link-time constant,
+	// so it folds into the instruction's offset field and no access pays an add for the stack's run-time position)
+	char *const stk_bytes = TINY ? tiny_lds : reinterpret_cast<char *>(&stk[0][0]);
 	const int tid = threadIdx.x;
-	const uint32_t sp0 = (uint32_t)tid * (uint32_t)sizeof(StackEntry);
+	const uint32_t sp0 = (TINY ? B.tiny_stack_off - kRow : 0u) + (uint32_t)tid * (uint32_t)sizeof(StackEntry);
 	auto push_ref = [&](uint32_t at, int ref) { *reinterpret_cast<StackEntry *>(stk_bytes + at + kRow) = (StackEntry)ref; }; // onto a stack whose pointer is `at`
 	auto read_ref = [&](uint32_t at) -> int { return (int)*reinterpret_cast<const StackEntry *>(stk_bytes + at); };         // the top entry of such a stack
 	const uint32_t lane = tid & 63;
@@ -513,7 +514,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 		const int popped = read_ref(sp);
 		const bool empty = sp == sp0;
 		const uint32_t spm = sp - kRow;
-		cur = (empty || (popped == EXIT && spm == sp0)) ? kDone : popped;
+		cur = (empty || (!ONE && popped == EXIT && spm == sp0)) ? kDone : popped;
 		sp = empty ? sp : spm;
 	};
 
@@ -634,7 +635,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 				const int nearc = second_first ? c1 : c0, farc = second_first ? c0 : c1;
 				push_ref(sp, farc); // kept only when both children are hit (sp advances); otherwise the slot stays free
 				const bool both = h0 && h1, none = !(h0 || h1);
-				const int after_pop = (empty || (popped == EXIT && spm == sp0)) ? kDone : popped;
+				const int after_pop = (empty || (!ONE && popped == EXIT && spm == sp0)) ? kDone : popped;
 				cur = none ? after_pop : nearc;
 				sp = both ? sp + kRow : ((none && !empty) ? spm : sp);
 			}
@@ -769,7 +770,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 					else {
 						const bool empty = sp == sp0;
 						const uint32_t spm = sp - kRow;
-						cur = (empty || (popped == EXIT && spm == sp0)) ? kDone : popped;
+						cur = (empty || (!ONE && popped == EXIT && spm == sp0)) ? kDone : popped;
 						sp = empty ? sp : spm;
 					}
 				}
