@@ -1189,15 +1189,21 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(POLARIS_SHAD
 	__shared__ uint32_t s_emit[8];                     // this step's emit mask: bit c = the ray with canonical index c emitted an indirect ray
 	__shared__ uint32_t s_tot[6];                      // indirect rays, shadow rays, hits, misses, emitter hits of the chunk; waves finished
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	// The lane's ray is requested FIRST, from its own slot whether or not the slot is live (a chunk always has its 256 slots:
+	// a dead slot's bytes are read and never looked at) -- so the request does not wait for the chunk's live count, and the
+	// count, the ray, the emit mask and the tables all come back in ONE round trip instead of two (round 4: a workgroup lives
+	// for about four dependent round trips, and 25 % of the sorted kernel's time was spent before the sort).
+	const size_t base = (size_t)blockIdx.x * WG;
+	const size_t my = base + tid;
+	float4 d4 = st.ray_d[my], t4 = FIRST ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : st.thr[my], h4 = st.hit[my]; // (camera rays carry no throughput: it is 1)
+	// (the sample's seed and the chunk's position in the reference's buffer: requested with everything else, used by shade_ray)
+	const uint32_t s = blockIdx.x / (A.Npad / WG);
+	const uint32_t seed = A.seeds[(size_t)(A.first_sample + s) * A.seed_stride + 1 + A.bounce], pfx0 = st.pfx[blockIdx.x];
 	const uint32_t cnt = st.cnt_ray[blockIdx.x];
 	if (cnt == 0) { // uniform exit: nothing live in this workgroup
 		if (tid == 0) { st.cnt_occ[blockIdx.x] = 0; st.wg_stat[blockIdx.x] = 0; } // (no rays come out of it: its emit mask will not be read)
 		return;
 	}
-	// the lane's ray is requested before the tables are staged: both round trips are in flight together
-	const size_t base = (size_t)blockIdx.x * WG;
-	const size_t my = base + (tid < cnt ? tid : 0u); // (idle lanes re-read slot 0: no select behind the loads, so nothing waits for them here)
-	float4 d4 = st.ray_d[my], t4 = FIRST ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : st.thr[my], h4 = st.hit[my]; // (camera rays carry no throughput: it is 1)
 	uint32_t pmask[8]; // the previous step's emit mask of this chunk (uniform)
 #pragma unroll
 	for (int w = 0; w < 8; w++) pmask[w] = FIRST ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)A.emask_in[(size_t)blockIdx.x * 8 + w]); // (kept in scalar registers)
@@ -1205,7 +1211,6 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(POLARIS_SHAD
 	if (tid < 6) s_tot[tid] = 0;
 	// in-place safety without SORT: this wave's rays are in registers before the staging barrier (the empty asm consumes them)
 	const SceneT<LDS> S = stage_scene<LDS>(Sg, lds, [&]() { if (!SORT) asm volatile("" ::"v"(d4.w), "v"(t4.w), "v"(h4.w)); });
-	const uint32_t s = blockIdx.x / (A.Npad / WG);
 	const unsigned long long below = (1ull << lane) - 1ull;
 	if (SORT) {
 		uint32_t key = 16; // no ray
@@ -1244,8 +1249,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(POLARIS_SHAD
 		uint32_t canon = 0;
 		if (tid < cnt) {
 			canon = FIRST ? tid : canonical_index(pmask, (uint32_t)fbits(t4.w));
-			const uint32_t seed = A.seeds[(size_t)(A.first_sample + s) * A.seed_stride + 1 + A.bounce];
-			shade_ray(S, A, s, seed, st.pfx[blockIdx.x] + canon, d4, t4, h4, R, [&](float4 oo, float4 od, float4 oe) {
+			shade_ray(S, A, s, seed, pfx0 + canon, d4, t4, h4, R, [&](float4 oo, float4 od, float4 oe) {
 				// the lanes that get here emit a shadow ray: one of them reserves their slots, all store at once
 				const unsigned long long m = __ballot(true);
 				const int first = __ffsll((long long)m) - 1;
