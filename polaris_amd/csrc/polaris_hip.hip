@@ -119,7 +119,6 @@ struct polaris_hip_tracer {
 		uint32_t nee_bounces = 0; // how many of them are allocated
 		std::vector<DevBuf> bufs;
 		hipEvent_t done = nullptr; // recorded after the pipe's last resolve
-		hipEvent_t stagger = nullptr; // option stagger: recorded after the batch's first trace / shade / shadow launch; the next batch starts behind it
 	};
 	static constexpr int kMaxPipes = 8;
 	Pipe pipe[kMaxPipes];
@@ -147,7 +146,6 @@ struct polaris_hip_tracer {
 	int opt_shade_wave_from = -1; // first bounce shaded by k_shade_wave; -1 = the bounce AFTER Russian roulette starts thinning the
 	                              // chunks (min_bounces_for_rr + 1: the RR bounce itself still shades dense chunks); earlier bounces use k_shade
 	int opt_shade_sort = -1; // first bounce whose rays k_shade groups by shading class; -1 = default (1), POLARIS_MAX_BOUNCES = never
-	int opt_stagger = 0;   // A/B aid: batch i + 1 starts behind batch i's first trace (1) / first shade (2) launch instead of beside it
 	int opt_traversal = 1; // 1 = persistent waves with lane refill (k_trace), 0 = one ray per lane (k_intersect/k_occlusion)
 
 	// per-kernel timing (option time_kernels)
@@ -463,14 +461,13 @@ int trace_occupancy(polaris_hip_tracer *h) {
 // Returns the first launch error of the batch (checked after every batch by the caller: a failed launch in batch 1 is reported
 // before batch 2 is queued behind it).
 hipError_t launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest *r, uint32_t s0, uint32_t K, uint32_t N, uint32_t Npad,
-                        bool exact, hipEvent_t resolve_after, hipEvent_t start_after = nullptr) {
+                        bool exact, hipEvent_t resolve_after) {
 	hipError_t first_err = hipSuccess;
 	auto note = [&](hipError_t e) { if (first_err == hipSuccess && e != hipSuccess) first_err = e; };
 	polaris_hip_tracer::Pipe &P = h->pipe[p];
 	const uint32_t B = r->num_bounces, stride = 1 + B;
 	const uint32_t wgs_per_sample = Npad / WG, wgs = K * wgs_per_sample;
 	hipStream_t q = P.q;
-	if (start_after) note(hipStreamWaitEvent(q, start_after, 0));
 	{
 		Timed t(h, "generate", q);
 		if (h->opt_time_kernels) h->timer_symbol["generate"] = "pol::k_generate";
@@ -525,7 +522,6 @@ hipError_t launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest 
 			else
 				hipLaunchKernelGGL(k_intersect, dim3(wgs), dim3(WG), 0, q, S, h->bvh);
 		}
-		if (b == 0 && h->opt_stagger == 1) note(hipEventRecord(P.stagger, q));
 		A.bounce = b;
 		A.last_bounce = (b + 1 == B) ? 1 : 0;
 		A.emask_in = b == 0 ? nullptr : P.st.emask[(b + 1) & 1]; // the masks the previous step wrote
@@ -564,7 +560,6 @@ hipError_t launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest 
 				note(hipLaunchKernel(fn, dim3(wgs), dim3(WG), args, 0, q));
 			}
 		}
-		if (b == 0 && h->opt_stagger == 2) note(hipEventRecord(P.stagger, q));
 		{
 			Timed t(h, "scan", q);
 			hipLaunchKernelGGL(k_scan, dim3(K), dim3(1024), 0, q, S, wgs_per_sample, b, A.last_bounce ? 0 : 1, h->d_stats);
@@ -580,7 +575,6 @@ hipError_t launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest 
 				hipLaunchKernelGGL(k_occlusion, dim3(wgs), dim3(WG), 0, q, S, h->bvh, occl_acc, h->d_stats);
 		}
 	}
-	if (B == 0 || h->opt_stagger >= 3 || h->opt_stagger <= 0) note(hipEventRecord(P.stagger, q)); // (never left unrecorded for a waiter)
 	if (!exact && B > 0) { // accumulateEmissiveSamples of the whole batch: the marked NEE records of every bounce into the per-path radiance
 		FoldArgs F{};
 		for (uint32_t b = 0; b < B; b++) { F.nee[b] = P.nee[b]; F.vis[b] = P.vis[b]; F.cnt[b] = P.cnt_occ_b[b]; }
@@ -640,7 +634,6 @@ int polaris_hip_create(int device_index, polaris_hip_tracer **out) {
 	h->pipe[0].q = h->stream;
 	for (int p = 1; p < polaris_hip_tracer::kMaxPipes && e == hipSuccess; p++) e = hipStreamCreateWithFlags(&h->pipe[p].q, hipStreamNonBlocking);
 	for (int p = 0; p < polaris_hip_tracer::kMaxPipes && e == hipSuccess; p++) e = hipEventCreateWithFlags(&h->pipe[p].done, hipEventDisableTiming);
-	for (int p = 0; p < polaris_hip_tracer::kMaxPipes && e == hipSuccess; p++) e = hipEventCreateWithFlags(&h->pipe[p].stagger, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->merge_stream, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_merged, hipEventDisableTiming);
@@ -677,7 +670,6 @@ void polaris_hip_destroy(polaris_hip_tracer *h) {
 		for (auto &P : h->pipe) {
 			free_pool(P.bufs);
 			if (P.done) (void)hipEventDestroy(P.done);
-			if (P.stagger) (void)hipEventDestroy(P.stagger);
 		}
 		if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
 		for (int p = 1; p < polaris_hip_tracer::kMaxPipes; p++)
@@ -894,7 +886,6 @@ int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value
 	else if (k == "trace_grid") h->opt_trace_grid = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20));
 	else if (k == "trace_wgs_per_cu") h->opt_trace_wgs_per_cu = (int)std::max<int64_t>(0, std::min<int64_t>(value, 64));
 	else if (k == "tiny_one") h->opt_tiny_one = value != 0; // next upload
-	else if (k == "stagger") h->opt_stagger = (int)std::max<int64_t>(0, std::min<int64_t>(value, 2));
 	else if (k == "lds_tris") h->opt_lds_tris = (int)std::max<int64_t>(-1, std::min<int64_t>(value, 1 << 20)); // next upload
 	else if (k == "max_leaf_tris") h->opt_max_leaf_tris = (int)std::max<int64_t>(-1, std::min<int64_t>(value, 1 << 20)); // next upload
 	else return fail(h, POLARIS_E_BAD_ARGUMENT, "unknown option '%s'", key);
@@ -1013,8 +1004,7 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 	uint32_t bi = 0;
 	for (uint32_t s0 = 0; s0 < spp; s0 += K, bi++) {
 		const int p = (int)(bi % (uint32_t)n_pipes), prev = (int)((bi + (uint32_t)n_pipes - 1) % (uint32_t)n_pipes);
-		HIP_TRY(h, launch_batch(h, p, r, s0, std::min(K, spp - s0), N, Npad, exact, (n_pipes > 1 && bi > 0) ? h->pipe[prev].done : nullptr,
-		                        (n_pipes > 1 && bi > 0 && h->opt_stagger > 0 && h->opt_stagger < 3) ? h->pipe[prev].stagger : nullptr));
+		HIP_TRY(h, launch_batch(h, p, r, s0, std::min(K, spp - s0), N, Npad, exact, (n_pipes > 1 && bi > 0) ? h->pipe[prev].done : nullptr));
 	}
 	for (int p = 1; p < n_pipes; p++) HIP_TRY(h, hipStreamWaitEvent(q, h->pipe[p].done, 0)); // join
 	HIP_TRY(h, hipGetLastError());
