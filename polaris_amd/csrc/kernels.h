@@ -1189,10 +1189,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(POLARIS_SHAD
 	__shared__ uint32_t s_emit[8];                     // this step's emit mask: bit c = the ray with canonical index c emitted an indirect ray
 	__shared__ uint32_t s_tot[6];                      // indirect rays, shadow rays, hits, misses, emitter hits of the chunk; waves finished
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	// The lane's ray is requested FIRST, from its own slot whether or not the slot is live (a chunk always has its 256 slots:
-	// a dead slot's bytes are read and never looked at) -- so the request does not wait for the chunk's live count, and the
-	// count, the ray, the emit mask and the tables all come back in ONE round trip instead of two (round 4: a workgroup lives
-	// for about four dependent round trips, and 25 % of the sorted kernel's time was spent before the sort).
+	// The lane's ray is requested first, from its own slot whether or not the slot is live (a chunk always has its 256 slots: a
+	// dead slot's bytes are read and never looked at), so the request does not wait for the chunk's live count: count, ray, emit
+	// mask, seed and tables are one round trip.  (Round 4 timing builds: a quarter of the sorted kernel's time passes before the
+	// sort, 7 % in the sort, the rest in shade_ray and its stores.  That first quarter is the ray streams themselves coming from
+	// HBM -- taking the count's scalar round trip out of it, as here, measured +-0.)
 	const size_t base = (size_t)blockIdx.x * WG;
 	const size_t my = base + tid;
 	float4 d4 = st.ray_d[my], t4 = FIRST ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : st.thr[my], h4 = st.hit[my]; // (camera rays carry no throughput: it is 1)
