@@ -65,21 +65,20 @@ def kernel_algorithmic_bytes(st, shade_counts, B: int, packet_camera: bool):
     A kernel's `frac` uses the SMALLER of the two; both are carried.  st = PolarisTraceStats of one frame, shade_counts =
     HipTracer.shade_counts(B) of the same frame."""
     prim, rays, occl = int(st.primary_rays), [int(v) for v in st.rays_per_bounce], [int(v) for v in st.occl_per_bounce]
-    closest = int(st.indirect_rays) + (0 if packet_camera else prim)
+    cam_per_ray = 0 if packet_camera else prim       # camera rays traced by k_trace: their common origin is a kernel-side constant
     ref = {
         # camera rays: SURVEY's 52 B minus what is constant for a camera ray and therefore not stored (origin | max distance,
         # throughput) = 20 B -- plus the 16 B per path slot of the batch's per-path radiance, which k_generate zeroes
-        # (and the origin after all when the per-ray kernel, which reads it, traces the camera rays)
-        "generate": (20 + 16 + (0 if packet_camera else 16)) * prim,
+        "generate": (20 + 16) * prim,
         "intersect_packet": 44 * prim if packet_camera else 0,
-        "intersect": 60 * closest,
+        "intersect": 60 * int(st.indirect_rays) + 44 * cam_per_ray,   # (a camera ray: SURVEY's 60 B minus the 16 B origin nobody stores)
         "occlusion": 36 * int(st.occlusion_rays),            # rayIntersectionTest: 32 B ray in, 4 B flag out
         "fold": 44 * int(st.unoccluded),                     # accumulateEmissiveSamples: 4 + 4 + 12 B in, 24 B read-modify-write
     }
     lay = {
-        "generate": (16 + 16 + (0 if packet_camera else 16)) * prim,       # ray_d + lsum (+ ray_o) stores
+        "generate": (16 + 16) * prim,                                      # ray_d + lsum stores
         "intersect_packet": (16 + 16) * prim if packet_camera else 0,      # ray_d load, hit store
-        "intersect": (32 + 16) * closest,                                  # ray_o + ray_d loads, hit store
+        "intersect": (32 + 16) * int(st.indirect_rays) + (16 + 16) * cam_per_ray,  # ray_o + ray_d loads, hit store (camera rays: no ray_o)
         "occlusion": 32 * int(st.occlusion_rays) + 4 * int(st.unoccluded),   # occ_o + occ_d loads; an unoccluded ray marks its NEE record (4 B)
         "fold": 16 * int(st.occlusion_rays) + 32 * prim,                     # every NEE record once + the per-path cells read and written once per batch
     }

@@ -437,7 +437,10 @@ __device__ __forceinline__ int tiny_meta_tri(int word) { return word < 0 ? -1 : 
 template <bool ANY_HIT, int STACK, int NODES, bool ONE = false>
 __global__ __launch_bounds__(NODES == kNodesLdsAll ? kTinyBlock : WG)
 __attribute__((amdgpu_waves_per_eu(NODES == kNodesLdsAll ? 8 : ((!ANY_HIT && STACK == 16) ? 7 : 1), NODES == kNodesLdsAll ? 8 : ((!ANY_HIT && STACK == 16) ? 7 : 10))))
-void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned long long *stats) {
+void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned long long *stats, uint32_t o_mask) {
+	// o_mask: ~0, or 0 for the camera rays of a batch -- they all start at the eye with no distance limit, so k_generate does
+	// not write 16 bytes of origin per path and this kernel does not read them: st.ray_o then points at ONE record (eye | FLT_MAX)
+	// and every lane reads slot (its slot & 0).
 	constexpr bool LDS_TOP = NODES == kNodesLdsTop, TINY = NODES == kNodesLdsAll;
 	static_assert(!ONE || TINY, "the single-instance variant exists for the tiny mode only");
 	constexpr int BLOCK = TINY ? kTinyBlock : WG; // threads per workgroup (a CHUNK of rays is always WG = 256 slots)
@@ -599,7 +602,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 			const unsigned long long freem = __ballot(cur == kIdle);
 			if (!drained && (freem == ~0ull || __popcll(freem) >= (ANY_HIT ? kRefillMinAny : kRefillMin))) {
 				PROF(6, 1); PROF(7, -(long long)__popcll(__ballot(cur != kIdle)));
-				draw([&]() { return cur == kIdle; }, [&](uint32_t ray_slot) { start_ray(ray_slot, src_o[ray_slot], src_d[ray_slot]); });
+				draw([&]() { return cur == kIdle; }, [&](uint32_t ray_slot) { start_ray(ray_slot, src_o[ray_slot & o_mask], src_d[ray_slot]); });
 				PROF(7, __popcll(__ballot(cur != kIdle)));
 			}
 			if (__ballot(cur != kIdle) == 0ull) {
@@ -658,7 +661,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 		if (!ONE && cur == EXIT) { // leaving the instance: back to the world-space ray (intersect.cl:330-335)
 			if (KEEP_WORLD) { o = wo; d = wd; }
 			else {
-				const float4 o4 = src_o[slot], d4 = src_d[slot];
+				const float4 o4 = src_o[slot & o_mask], d4 = src_d[slot];
 				o = xyz(o4); d = xyz(d4);
 			}
 			rcp_dir(d.x, d.y, d.z, inv.x, inv.y, inv.z);

@@ -126,6 +126,7 @@ struct polaris_hip_tracer {
 	uint32_t *d_seeds = nullptr;
 	size_t seeds_cap = 0;
 	unsigned long long *d_stats = nullptr;
+	float4 *d_cam_o = nullptr; // eye | FLT_MAX: the one origin record of every camera ray (launch_trace, camera)
 	int num_cus = 256;
 	void *staging = nullptr; // peer-merge staging strip
 	size_t staging_bytes = 0;
@@ -396,11 +397,16 @@ std::string trace_symbol(polaris_hip_tracer *h) {
 	return buf;
 }
 
+// camera: the closest-hit launch of a batch's camera rays -- their common origin comes from the handle's one-record buffer
+// (kernels.h k_trace, o_mask), the origin stream is neither written nor read for them.
 template <bool ANY_HIT>
-hipError_t launch_trace(polaris_hip_tracer *h, polaris_hip_tracer::Pipe &P, const Streams &st, uint32_t grid, uint32_t chunks, float4 *acc) {
+hipError_t launch_trace(polaris_hip_tracer *h, polaris_hip_tracer::Pipe &P, const Streams &st_in, uint32_t grid, uint32_t chunks, float4 *acc, bool camera = false) {
 	int block = WG;
 	const void *fn = trace_kernel<ANY_HIT>(h, &block);
-	void *args[] = {(void *)&st, (void *)&h->bvh, (void *)&chunks, (void *)&acc, (void *)&h->d_stats};
+	Streams st = st_in;
+	uint32_t o_mask = ~0u;
+	if (camera && !ANY_HIT) { st.ray_o = h->d_cam_o; o_mask = 0u; }
+	void *args[] = {(void *)&st, (void *)&h->bvh, (void *)&chunks, (void *)&acc, (void *)&h->d_stats, (void *)&o_mask};
 	return hipLaunchKernel(fn, dim3(grid), dim3(block), args, h->node_mode == kNodesLdsAll ? h->tiny_lds_bytes : 0, P.q);
 }
 
@@ -472,7 +478,7 @@ hipError_t launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest 
 		Timed t(h, "generate", q);
 		if (h->opt_time_kernels) h->timer_symbol["generate"] = "pol::k_generate";
 		hipLaunchKernelGGL(k_generate, dim3(wgs), dim3(WG), 0, q, P.st, h->cam, h->d_seeds, stride, s0, N, Npad, h->W, r->block_y,
-		                   exact ? 0 : 1, (B > 0 && h->packet_primary) ? 0 : 1); // (the wave-packet kernel does not read the origin stream)
+		                   exact ? 0 : 1, (B > 0 && (h->packet_primary || h->opt_traversal)) ? 0 : 1); // (neither the wave-packet kernel nor k_trace's camera launch reads the origin stream)
 	}
 	ShadeArgs A{};
 	A.seeds = h->d_seeds; A.seed_stride = stride; A.first_sample = s0;
@@ -518,7 +524,7 @@ hipError_t launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest 
 			if (b == 0 && h->packet_primary)
 				hipLaunchKernelGGL((k_trace_packet<false, true>), dim3(wgs), dim3(WG), 0, q, S, h->bvh, (float4 *)nullptr, h->d_stats, h->cam.eye);
 			else if (h->opt_traversal)
-				note(launch_trace<false>(h, P, S, persistent, wgs, nullptr));
+				note(launch_trace<false>(h, P, S, persistent, wgs, nullptr, b == 0));
 			else
 				hipLaunchKernelGGL(k_intersect, dim3(wgs), dim3(WG), 0, q, S, h->bvh);
 		}
@@ -638,6 +644,7 @@ int polaris_hip_create(int device_index, polaris_hip_tracer **out) {
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->merge_stream, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_merged, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipMalloc((void **)&h->d_stats, ST_COUNT * sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipMalloc((void **)&h->d_cam_o, sizeof(float4));
 	if (e == hipSuccess) {
 		hipDeviceProp_t p;
 		if (hipGetDeviceProperties(&p, device_index) == hipSuccess && p.multiProcessorCount > 0) h->num_cus = p.multiProcessorCount;
@@ -688,6 +695,7 @@ void polaris_hip_destroy(polaris_hip_tracer *h) {
 		if (h->framebuffer) (void)hipFree(h->framebuffer);
 		if (h->d_seeds) (void)hipFree(h->d_seeds);
 		if (h->d_stats) (void)hipFree(h->d_stats);
+		if (h->d_cam_o) (void)hipFree(h->d_cam_o);
 		if (h->staging) (void)hipFree(h->staging);
 		if (h->ev_start) (void)hipEventDestroy(h->ev_start);
 		if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
@@ -861,6 +869,10 @@ int polaris_hip_set_camera(polaris_hip_tracer *h, const float eye[3], const floa
 	h->cam.bl = make_float4(fr[8], fr[9], fr[10], fr[11]);
 	h->cam.br = make_float4(fr[12], fr[13], fr[14], fr[15]);
 	h->cam.eye = make_float3(eye[0], eye[1], eye[2]);
+	const float4 o4 = make_float4(eye[0], eye[1], eye[2], kFltMax); // what k_generate would write per camera ray (kernels.h)
+	HIP_TRY(h, hipSetDevice(h->device));
+	HIP_TRY(h, sync_all(h));                                        // (no Trace is running: the caller holds mu; queued work of an earlier one may be)
+	HIP_TRY(h, hipMemcpy(h->d_cam_o, &o4, sizeof o4, hipMemcpyHostToDevice));
 	h->have_camera = true;
 	return POLARIS_OK;
 }
