@@ -83,7 +83,13 @@ int polaris_hip_set_camera(polaris_hip_tracer *h, const float eye[3], const floa
  *                        the reference's order (forces one sample per batch; bit-exact with
  *                        the CPU oracle), 0 = per-path radiance + ordered resolve (default)
  *   "packet_primary"     1 = wave-packet traversal for primary rays, 0 = per-ray, -1 = by scene
- *                        (default: packets for single-instance scenes of up to 32 K triangles)
+ *                        (default: packets for single-instance scenes of up to 32 K triangles,
+ *                        except where the tiny-scene mode keeps the triangle records in LDS)
+ *   "lds_tris"           NEXT upload, tiny-scene mode: triangle records kept in LDS beside the tree
+ *                        (default -1: as many as fit half a CU's LDS, none if that is under half
+ *                        of them; 0 = none)
+ *   "tiny_one"           NEXT upload: 0 = the general tiny-scene kernel even where the variant for
+ *                        single-instance scenes with bounding boxes applies (default 1)
  *   "time_kernels"       1 = bracket every kernel with HIP events (polaris_hip_kernel_ms)
  *   "overlap"            batches in flight on separate streams (1-8, default 4)
  *   "max_leaf_tris"      applies to the NEXT upload_scene: triangle leaves with more triangles
@@ -91,7 +97,7 @@ int polaris_hip_set_camera(polaris_hip_tracer *h, const float eye[3], const floa
  *                        2 up to 32 K triangles, 4 above; 0 = keep the caller's leaves).  Never
  *                        changes a result: DESIGN.md 2 (HBM data layout)
  *   further A/B switches of the kernels ("traversal", "node_mode", "packet_shadow", "shade_wave",
- *   "shade_wave_from", "shade_sort", "shade_wgs_per_cu", "stage_lds", "trace_wgs_per_cu"): see
+ *   "shade_wave_from", "shade_sort", "shade_wgs_per_cu", "stage_lds", "trace_wgs_per_cu", "trace_grid"): see
  *   DESIGN.md 3.  Apart from "exact_accumulate" (the order of the float sums) no option changes a
  *   result; an unknown key is POLARIS_E_BAD_ARGUMENT.  The batch size chosen automatically
  *   ("samples_per_batch" = 0) is clamped by the FREE device memory, and with it the order of the

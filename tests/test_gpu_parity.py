@@ -663,6 +663,35 @@ def test_big_scene_kernel_variants_agree_with_the_oracle(built, oracle, name):
         assert np.array_equal(bits(got[..., :3]), bits(want[..., :3])), opts
 
 
+@pytest.mark.parametrize("name,one", [("cornell", True), ("sphere", True), ("cubes", False), ("transformed", False)])
+def test_tiny_scene_kernel_variants_are_selected_as_documented(built, oracle, name, one):
+    """Tiny-scene mode (whole tree + triangle records in LDS): scenes that ARE one instance with bounding boxes run the variant
+    compiled for them (k_trace<.., ONE = true>), scenes of several instances the general one; option tiny_one = 0 forces the
+    general one; every combination with the triangle records in LDS or not traces the oracle's frame bit for bit."""
+    from oracle import pybind as ob
+    from polaris_amd import scenes
+
+    sc = scenes.SCENES[name]()
+    W, H, spp, B = 64, 48, 2, 4
+    req = ob.make_request(W, H, spp=spp, bounces=B, rr=2)
+    seeds = scenes.make_seeds(spp, B, base=77)
+    want, wst, _ = oracle.trace(sc, req, seeds)
+    for opts in ({}, {"tiny_one": 0}, {"lds_tris": 0}, {"tiny_one": 0, "lds_tris": 0}, {"lds_tris": 5}):
+        tr = make_hip_tracer(sc, W, H, exact_accumulate=1, time_kernels=1, **opts)
+        try:
+            tr.Trace(req, seeds)
+            got, st = tr.read_accumulator(0), tr.last_trace_stats
+            symbols = [tr.kernel_symbol("intersect"), tr.kernel_symbol("occlusion")]
+        finally:
+            tr.Close()
+        expect_one = one and opts.get("tiny_one", 1) != 0
+        for sym in symbols:
+            assert sym.startswith("pol::k_trace<") and ", 16, 2, " in sym, sym                      # the tiny-scene mode
+            assert sym.endswith(", true>" if expect_one else ", false>"), (name, opts, sym)
+        assert counters(st, B) == counters(wst, B), (name, opts)
+        assert np.array_equal(bits(got[..., :3]), bits(want[..., :3])), (name, opts)
+
+
 def test_soak_one_handle_many_shapes_scenes_and_options(built):
     """150 Trace calls on one handle with random frame sizes, row blocks, scenes, bounce counts,
     overlap depths and accumulation modes (tests/tools/soak.py): every call succeeds, radiance stays

@@ -200,6 +200,30 @@ QUAD_SCENES.update({"cornell": lambda tmp: scenes.cornell_box(), "terrain-small"
                     "instanced-small": lambda tmp: scenes.SCENES["instanced-small"](), "sphere": lambda tmp: scenes.sphere_scene()})
 
 
+@pytest.mark.parametrize("name", ["cornell", "sphere", "cubes", "cornell-refbvh"])
+def test_small_scenes_order_their_triangle_slots_by_leaf_area_and_pack_one_word_per_slot(harness, name, tmp_path):
+    """scene_layout.h, for scenes of < 2 047 triangle slots (the tiny-scene traversal mode keeps a prefix of the slots in LDS):
+    leaves take their slots in descending order of their box's surface area, and every slot carries
+    rank << 19 | shading class << 11 | triangle -- which decodes back to the (rank, triangle | class << 24) the other modes use."""
+    sc = QUAD_SCENES[name](tmp_path)
+    cap = 4096
+    area = np.zeros(cap, np.float32)
+    word, rank, orig = (np.zeros(cap, np.uint32) for _ in range(3))
+    err = C.create_string_buffer(256)
+    view = T.scene_view(sc)
+    harness.layout_check_slots.argtypes = [C.POINTER(T.SceneView), C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+    for max_leaf in (0, 2):
+        n = harness.layout_check_slots(C.byref(view), max_leaf, cap, area.ctypes.data, word.ctypes.data, rank.ctypes.data, orig.ctypes.data, err, 256)
+        assert n > 0, err.value.decode()
+        a = area[:n].copy()
+        a[a < 0] = np.inf                                       # (a mesh tree that is ONE leaf has no box: it is always reached, and comes first)
+        assert (np.diff(a) <= 0).all(), "slots are not in descending order of their leaf's box area"
+        w, r, o = word[:n].astype(np.uint64), rank[:n].astype(np.uint64), orig[:n].astype(np.uint64)
+        assert ((w >> np.uint64(19)) == r).all() and (w >> np.uint64(30) == 0).all()
+        assert (((w & np.uint64(0x7FF)) | (((w >> np.uint64(11)) & np.uint64(0xFF)) << np.uint64(24))) == o).all()
+        assert len(set(o.tolist())) == len(set((o & np.uint64(0xFFFFFF)).tolist()))   # (one class per triangle)
+
+
 def test_subdivision_cuts_triangle_tests_on_big_leaves(harness, oracle):
     sc = scenes.cornell_box(compiler="reference")  # leaves of up to 10 triangles, as `polaris render` compiles them
     _, _, rays = camera_and_bounce_rays(oracle, sc)

@@ -150,4 +150,28 @@ int layout_check_traverse(const PolarisSceneView *sc, int max_leaf_tris, const f
 	}
 	return 0;
 }
+
+// Small scenes: the triangle slots as the tiny-scene traversal mode wants them (scene_layout.h): leaves in descending order of
+// their box's surface area, every slot's packed word = rank << 19 | shading class << 11 | triangle.
+// out_area[slot] = surface-area measure of the box of the leaf that holds the slot (-1: the tree is one leaf),
+// out_word[slot] = TriH::pad2, out_rank / out_orig = the fields it packs.  Returns the number of slots, < 0 on error.
+int layout_check_slots(const PolarisSceneView *sc, int max_leaf_tris, uint32_t cap, float *out_area, uint32_t *out_word, uint32_t *out_rank, uint32_t *out_orig,
+                       char *err, size_t err_len) {
+	SceneLayout L;
+	std::string e = build_layout(*sc, L, max_leaf_tris);
+	if (e == "@retry-without-subdivision") { L = SceneLayout(); e = build_layout(*sc, L, 0); }
+	if (!e.empty()) { if (err && err_len) { strncpy(err, e.c_str(), err_len - 1); err[err_len - 1] = 0; } return -1; }
+	if (L.tris.size() > cap) return -2;
+	std::vector<float> area(L.tris.size(), -1.0f);
+	auto note = [&](int32_t ref, const float *lo, const float *hi) {
+		if (ref >= 0) return;
+		const uint32_t code = (uint32_t)~ref;
+		if ((code & 15u) == 0u || (code & kBigLeafFlag)) return;
+		const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+		for (uint32_t q = code >> 4; q < (code >> 4) + (code & 15u) && q < area.size(); q++) area[q] = dx * dy + dy * dz + dz * dx;
+	};
+	for (const PairNodeH &P : L.pairs) { note(P.ref0, P.lo0, P.hi0); note(P.ref1, P.lo1, P.hi1); }
+	for (size_t q = 0; q < L.tris.size(); q++) { out_area[q] = area[q]; out_word[q] = L.tris[q].pad2; out_rank[q] = L.tris[q].rank; out_orig[q] = L.tris[q].orig; }
+	return (int)L.tris.size();
+}
 }
