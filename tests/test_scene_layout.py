@@ -216,8 +216,8 @@ def test_small_scenes_order_their_triangle_slots_by_leaf_area_and_pack_one_word_
         n = harness.layout_check_slots(C.byref(view), max_leaf, cap, area.ctypes.data, word.ctypes.data, rank.ctypes.data, orig.ctypes.data, err, 256)
         assert n > 0, err.value.decode()
         a = area[:n].copy()
-        a[a < 0] = np.inf                                       # (a mesh tree that is ONE leaf has no box: it is always reached, and comes first)
-        assert (np.diff(a) <= 0).all(), "slots are not in descending order of their leaf's box area"
+        a[a < 0] = np.float32(3.0e38)                           # (a mesh tree that is ONE leaf has no box: it is always reached, and comes first)
+        assert (a[1:] <= a[:-1]).all(), "slots are not in descending order of their leaf's box area"
         w, r, o = word[:n].astype(np.uint64), rank[:n].astype(np.uint64), orig[:n].astype(np.uint64)
         assert ((w >> np.uint64(19)) == r).all() and (w >> np.uint64(30) == 0).all()
         assert (((w & np.uint64(0x7FF)) | (((w >> np.uint64(11)) & np.uint64(0xFF)) << np.uint64(24))) == o).all()
