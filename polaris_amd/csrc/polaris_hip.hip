@@ -871,7 +871,7 @@ int polaris_hip_set_camera(polaris_hip_tracer *h, const float eye[3], const floa
 	h->cam.eye = make_float3(eye[0], eye[1], eye[2]);
 	const float4 o4 = make_float4(eye[0], eye[1], eye[2], kFltMax); // what k_generate would write per camera ray (kernels.h)
 	HIP_TRY(h, hipSetDevice(h->device));
-	HIP_TRY(h, sync_all(h));                                        // (no Trace is running: the caller holds mu; queued work of an earlier one may be)
+	// (nothing of this handle reads the record now: the caller holds mu, and a Trace returns only when its kernels are done)
 	HIP_TRY(h, hipMemcpy(h->d_cam_o, &o4, sizeof o4, hipMemcpyHostToDevice));
 	h->have_camera = true;
 	return POLARIS_OK;
