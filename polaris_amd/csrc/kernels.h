@@ -99,7 +99,19 @@ struct Streams {
 	// index c emitted a ray -- so a ray's own canonical index is the number of set bits below its parent's.
 	uint32_t *emask[2];
 	int *hit_inst; // optional (test tap): instance id per slot, may be null
+	// hit12 != 0: the hit records are 12 bytes (u, v, triangle word), not 16 (u, v, t, triangle word) -- nothing in a Trace reads t
+	// (shadeHits rebuilds the hit point from the barycentrics, intersect.cl:283-286 / pt_integrator.cl), so the traversal kernels
+	// do not store it and the shade kernels do not load it: 8 B per ray less through HBM.  The taps and probes keep 16 (they return t).
+	uint32_t hit12;
 };
+__device__ __forceinline__ void store_hit(const Streams &st, size_t slot, float u, float v, float t, int tri) {
+	if (st.hit12) { float *h = reinterpret_cast<float *>(st.hit) + 3 * slot; h[0] = u; h[1] = v; h[2] = __int_as_float(tri); }
+	else st.hit[slot] = make_float4(u, v, t, __int_as_float(tri));
+}
+__device__ __forceinline__ float4 load_hit(const Streams &st, size_t slot) {
+	if (st.hit12) { const float *h = reinterpret_cast<const float *>(st.hit) + 3 * slot; return make_float4(h[0], h[1], 0.0f, h[2]); }
+	return st.hit[slot];
+}
 
 // device-side counters of one Trace call (mirrors PolarisTraceStats, all uint64)
 // (shaded hits / misses / emitter hits are kept per bounce: the totals of PolarisTraceStats are their sums, and bench.py prices
@@ -268,7 +280,7 @@ __global__ __launch_bounds__(WG) void k_intersect(Streams st, BvhDev B) {
 	const float4 o4 = st.ray_o[slot], d4 = st.ray_d[slot];
 	HitRec h;
 	traverse<false>(B, xyz(o4), xyz(d4), o4.w, stk, h);
-	st.hit[slot] = make_float4(h.u, h.v, h.t, ibits(h.tri));
+	store_hit(st, slot, h.u, h.v, h.t, h.tri);
 	if (st.hit_inst) st.hit_inst[slot] = h.inst;
 }
 
@@ -654,7 +666,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 				}
 				unocc++;
 			} else {
-				st.hit[slot] = make_float4(best_u, best_v, best_t, ibits(TINY ? tiny_meta_tri(best_tri) : best_tri));
+				store_hit(st, slot, best_u, best_v, best_t, TINY ? tiny_meta_tri(best_tri) : best_tri);
 			}
 			cur = kIdle;
 		}
@@ -945,7 +957,7 @@ __global__ __launch_bounds__(WG) void k_trace_packet(Streams st, BvhDev B, float
 		const unsigned long long m = __ballot(clear);
 		if (lane == 0 && m) atomicAdd(&stats[ST_UNOCCLUDED], (unsigned long long)__popcll(m));
 	} else if (valid) {
-		st.hit[slot] = make_float4(best.u, best.v, best.t, ibits(best.tri));
+		store_hit(st, slot, best.u, best.v, best.t, best.tri);
 		if (st.hit_inst) st.hit_inst[slot] = best.inst;
 	}
 }
@@ -1199,7 +1211,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(POLARIS_SHAD
 	// HBM -- taking the count's scalar round trip out of it, as here, measured +-0.)
 	const size_t base = (size_t)blockIdx.x * WG;
 	const size_t my = base + tid;
-	float4 d4 = st.ray_d[my], t4 = FIRST ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : st.thr[my], h4 = st.hit[my]; // (camera rays carry no throughput: it is 1)
+	float4 d4 = st.ray_d[my], t4 = FIRST ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : st.thr[my], h4 = load_hit(st, my); // (camera rays carry no throughput: it is 1)
 	// (the sample's seed and the chunk's position in the reference's buffer: requested with everything else, used by shade_ray)
 	const uint32_t s = blockIdx.x / (A.Npad / WG);
 	const uint32_t seed = A.seeds[(size_t)(A.first_sample + s) * A.seed_stride + 1 + A.bounce], pfx0 = st.pfx[blockIdx.x];
@@ -1363,7 +1375,7 @@ void k_shade_wave(Streams st, SceneDev Sg, ShadeArgs A, uint32_t num_chunks) {
 				canon = canonical_index(pmask, (uint32_t)fbits(t4.w));
 				const uint32_t s = chunk / wgs_per_sample;
 				const uint32_t seed = A.seeds[(size_t)(A.first_sample + s) * A.seed_stride + 1 + A.bounce];
-				shade_ray(S, A, s, seed, st.pfx[chunk] + canon, st.ray_d[base + idx], t4, st.hit[base + idx], R, [&](float4 oo, float4 od, float4 oe) {
+				shade_ray(S, A, s, seed, st.pfx[chunk] + canon, st.ray_d[base + idx], t4, load_hit(st, base + idx), R, [&](float4 oo, float4 od, float4 oe) {
 					const size_t d = base + atomicAdd(&w_cnt[wave][k][1], 1u); // (shadow rays have no order to keep)
 					st.occ_o[d] = oo; st.occ_d[d] = od; st.occ_e[d] = oe;
 				});
