@@ -78,7 +78,7 @@ def kernel_algorithmic_bytes(st, shade_counts, B: int, packet_camera: bool):
     lay = {
         "generate": (16 + 16) * prim,                                      # ray_d + lsum stores
         "intersect_packet": (16 + 12) * prim if packet_camera else 0,      # ray_d load, hit store (12 B: u, v, triangle word -- no t inside a Trace)
-        "intersect": (32 + 12) * int(st.indirect_rays) + (16 + 12) * cam_per_ray,  # ray_o + ray_d loads, hit store (camera rays: no ray_o)
+        "intersect": (12 + 16 + 12) * int(st.indirect_rays) + (16 + 12) * cam_per_ray,  # ray_o (12 B: no max distance inside a Trace) + ray_d loads, hit store (camera rays: no ray_o)
         "occlusion": 32 * int(st.occlusion_rays) + 4 * int(st.unoccluded),   # occ_o + occ_d loads; an unoccluded ray marks its NEE record (4 B)
         "fold": 17 * int(st.occlusion_rays) + 16 * prim,                     # every NEE record + visibility byte once, the per-path terminal cells read once (k_fold_resolve)
     }
@@ -89,9 +89,9 @@ def kernel_algorithmic_bytes(st, shade_counts, B: int, packet_camera: bool):
         emitted = rays[b + 1] if b + 1 < B else 0
         # reference: 68 B per shaded hit, 60 per shaded miss, 24 per emitter hit, 32 per emitted bounce ray, 44 per shadow ray
         ref[c["timer"]] += 68 * c["hits"] + 60 * c["misses"] + 24 * c["emitters"] + 32 * emitted + 44 * occl[b]
-        # layout: every shaded ray loads ray_d + its 12-byte hit record (+ thr after the first bounce); an emitted bounce ray is three float4 stores
+        # layout: every shaded ray loads ray_d + its 12-byte hit record (+ thr after the first bounce); an emitted bounce ray is 12 + 16 + 16 B of stores
         # (ray_o, ray_d, thr), a shadow ray three (occ_o, occ_d, occ_e); a miss / emitter hit is a 16 B load + 12 B store of its cell
-        lay[c["timer"]] += (28 if b == 0 else 44) * (c["hits"] + c["misses"]) + 28 * (c["misses"] + c["emitters"]) + 48 * emitted + 48 * occl[b]
+        lay[c["timer"]] += (28 if b == 0 else 44) * (c["hits"] + c["misses"]) + 28 * (c["misses"] + c["emitters"]) + 44 * emitted + 48 * occl[b]
     return ref, lay
 
 

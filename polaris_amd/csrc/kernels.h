@@ -103,7 +103,19 @@ struct Streams {
 	// (shadeHits rebuilds the hit point from the barycentrics, intersect.cl:283-286 / pt_integrator.cl), so the traversal kernels
 	// do not store it and the shade kernels do not load it: 8 B per ray less through HBM.  The taps and probes keep 16 (they return t).
 	uint32_t hit12;
+	// o12 != 0: the origins of the closest-hit rays (ray_o) are 12 bytes -- inside a Trace their max distance is FLT_MAX for every
+	// one of them (camera rays, camera.cl; bounce rays, pt_integrator.cl:209), so it is neither stored nor loaded.  (Shadow rays
+	// carry a real distance in occ_o.w; the probes and taps pass arbitrary ones: 16 bytes there.)
+	uint32_t o12;
 };
+__device__ __forceinline__ float4 load_ray_o(const Streams &st, size_t slot) {
+	if (st.o12) { const float *p = reinterpret_cast<const float *>(st.ray_o) + 3 * slot; return make_float4(p[0], p[1], p[2], 3.402823466e+38f); }
+	return st.ray_o[slot];
+}
+__device__ __forceinline__ void store_ray_o(const Streams &st, size_t slot, float4 o) {
+	if (st.o12) { float *p = reinterpret_cast<float *>(st.ray_o) + 3 * slot; p[0] = o.x; p[1] = o.y; p[2] = o.z; }
+	else st.ray_o[slot] = o;
+}
 __device__ __forceinline__ void store_hit(const Streams &st, size_t slot, float u, float v, float t, int tri) {
 	if (st.hit12) { float *h = reinterpret_cast<float *>(st.hit) + 3 * slot; h[0] = u; h[1] = v; h[2] = __int_as_float(tri); }
 	else st.hit[slot] = make_float4(u, v, t, __int_as_float(tri));
@@ -154,7 +166,7 @@ __global__ __launch_bounds__(WG) void k_generate(Streams st, CameraArgs cam, con
 	float rx = pm_mix(cam.tr.x, cam.br.x, ty), ry = pm_mix(cam.tr.y, cam.br.y, ty), rz = pm_mix(cam.tr.z, cam.br.z, ty), rw = pm_mix(cam.tr.w, cam.br.w, ty);
 	float dx = pm_mix(lx, rx, tx), dy = pm_mix(ly, ry, tx), dz = pm_mix(lz, rz, tx), dw = pm_mix(lw, rw, tx);
 	float inv = 1.0f / pm_sqrt(dx * dx + dy * dy + dz * dz + dw * dw);
-	if (write_origin) st.ray_o[slot] = make_float4(cam.eye.x, cam.eye.y, cam.eye.z, kFltMax); // (the wave-packet kernel takes the eye from its arguments)
+	if (write_origin) store_ray_o(st, slot, make_float4(cam.eye.x, cam.eye.y, cam.eye.z, kFltMax)); // (the wave-packet kernel takes the eye from its arguments)
 	st.ray_d[slot] = make_float4(dx * inv, dy * inv, dz * inv, ibits((int)idx));
 	// (the throughput of a camera ray is 1: the first shade step does not read it, so it is not written)
 	if (zero_lsum) st.lsum[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -277,7 +289,7 @@ __global__ __launch_bounds__(WG) void k_intersect(Streams st, BvhDev B) {
 	__shared__ int stk[kTraversalStack][WG];
 	if (threadIdx.x >= st.cnt_ray[blockIdx.x]) return;
 	const size_t slot = (size_t)blockIdx.x * WG + threadIdx.x;
-	const float4 o4 = st.ray_o[slot], d4 = st.ray_d[slot];
+	const float4 o4 = load_ray_o(st, slot), d4 = st.ray_d[slot];
 	HitRec h;
 	traverse<false>(B, xyz(o4), xyz(d4), o4.w, stk, h);
 	store_hit(st, slot, h.u, h.v, h.t, h.tri);
@@ -614,7 +626,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 			const unsigned long long freem = __ballot(cur == kIdle);
 			if (!drained && (freem == ~0ull || __popcll(freem) >= (ANY_HIT ? kRefillMinAny : kRefillMin))) {
 				PROF(6, 1); PROF(7, -(long long)__popcll(__ballot(cur != kIdle)));
-				draw([&]() { return cur == kIdle; }, [&](uint32_t ray_slot) { start_ray(ray_slot, src_o[ray_slot & o_mask], src_d[ray_slot]); });
+				draw([&]() { return cur == kIdle; }, [&](uint32_t ray_slot) { start_ray(ray_slot, ANY_HIT ? src_o[ray_slot] : load_ray_o(st, ray_slot & o_mask), src_d[ray_slot]); });
 				PROF(7, __popcll(__ballot(cur != kIdle)));
 			}
 			if (__ballot(cur != kIdle) == 0ull) {
@@ -673,7 +685,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 		if (!ONE && cur == EXIT) { // leaving the instance: back to the world-space ray (intersect.cl:330-335)
 			if (KEEP_WORLD) { o = wo; d = wd; }
 			else {
-				const float4 o4 = src_o[slot & o_mask], d4 = src_d[slot];
+				const float4 o4 = ANY_HIT ? src_o[slot] : load_ray_o(st, slot & o_mask), d4 = src_d[slot];
 				o = xyz(o4); d = xyz(d4);
 			}
 			rcp_dir(d.x, d.y, d.z, inv.x, inv.y, inv.z);
@@ -836,7 +848,7 @@ __global__ __launch_bounds__(WG) void k_trace_packet(Streams st, BvhDev B, float
 	if (wave * 64 >= cnt) return; // nothing live in this wave's 64 slots (uniform per wave)
 	const bool valid = tid < cnt;
 	const size_t slot = (size_t)blockIdx.x * WG + tid;
-	const float4 o4 = CAMERA ? make_float4(eye.x, eye.y, eye.z, kFltMax) : (valid ? src_o[slot] : make_float4(0, 0, 0, 0));
+	const float4 o4 = CAMERA ? make_float4(eye.x, eye.y, eye.z, kFltMax) : (valid ? (ANY_HIT ? src_o[slot] : load_ray_o(st, slot)) : make_float4(0, 0, 0, 0));
 	const float4 d4 = valid ? src_d[slot] : make_float4(1, 1, 1, 0);
 	bool occluded = false; // ANY_HIT: a lane that found its blocker leaves the packet for good
 	const f3 O = xyz(o4), D = xyz(d4);
@@ -1290,7 +1302,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(POLARIS_SHAD
 			atomicOr(&s_emit[canon >> 5], 1u << (canon & 31));
 			const size_t d = base + at_ind + __popcll(m_ind & below);
 			R.thr.w = ibits((int)canon); // the child's parent, in canonical order
-			st.ray_o[d] = R.ro; st.ray_d[d] = R.rd; st.thr[d] = R.thr;
+			store_ray_o(st, d, R.ro); st.ray_d[d] = R.rd; st.thr[d] = R.thr;
 		}
 	}
 	// ---- the last wave to get here publishes the chunk's counts and emit mask -------------------
@@ -1384,7 +1396,7 @@ void k_shade_wave(Streams st, SceneDev Sg, ShadeArgs A, uint32_t num_chunks) {
 				atomicOr(&w_emit[wave][k][canon >> 5], 1u << (canon & 31));
 				const size_t d = base + atomicAdd(&w_cnt[wave][k][0], 1u); // any free slot of the ray's chunk: the order is in thr.w
 				R.thr.w = ibits((int)canon);
-				st.ray_o[d] = R.ro; st.ray_d[d] = R.rd; st.thr[d] = R.thr;
+				store_ray_o(st, d, R.ro); st.ray_d[d] = R.rd; st.thr[d] = R.thr;
 			}
 			if (live && (R.hit | R.miss | R.emit) != 0) atomicAdd(&w_cnt[wave][k][2], R.hit | (R.miss << 10) | (R.emit << 20));
 		}

@@ -148,6 +148,7 @@ struct polaris_hip_tracer {
 	                              // chunks (min_bounces_for_rr + 1: the RR bounce itself still shades dense chunks); earlier bounces use k_shade
 	int opt_shade_sort = -1; // first bounce whose rays k_shade groups by shading class; -1 = default (1), POLARIS_MAX_BOUNCES = never
 	int opt_hit12 = 1;     // 12-byte hit records inside a Trace (A/B aid: 0 = 16)
+	int opt_o12 = 1;       // 12-byte origins of the closest-hit rays inside a Trace (A/B aid: 0 = 16)
 	int opt_traversal = 1; // 1 = persistent waves with lane refill (k_trace), 0 = one ray per lane (k_intersect/k_occlusion)
 
 	// per-kernel timing (option time_kernels)
@@ -476,6 +477,7 @@ hipError_t launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest 
 	const uint32_t wgs_per_sample = Npad / WG, wgs = K * wgs_per_sample;
 	hipStream_t q = P.q;
 	P.st.hit12 = h->opt_hit12 ? 1u : 0u; // (a Trace never reads a hit's distance: kernels.h Streams::hit12)
+	P.st.o12 = h->opt_o12 ? 1u : 0u;     // (... and its closest-hit rays all have the max distance FLT_MAX: Streams::o12)
 	{
 		Timed t(h, "generate", q);
 		if (h->opt_time_kernels) h->timer_symbol["generate"] = "pol::k_generate";
@@ -898,6 +900,7 @@ int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value
 	else if (k == "trace_wgs_per_cu") h->opt_trace_wgs_per_cu = (int)std::max<int64_t>(0, std::min<int64_t>(value, 64));
 	else if (k == "tiny_one") h->opt_tiny_one = value != 0; // next upload
 	else if (k == "hit12") h->opt_hit12 = value != 0;
+	else if (k == "o12") h->opt_o12 = value != 0;
 	else if (k == "lds_tris") h->opt_lds_tris = (int)std::max<int64_t>(-1, std::min<int64_t>(value, 1 << 20)); // next upload
 	else if (k == "max_leaf_tris") h->opt_max_leaf_tris = (int)std::max<int64_t>(-1, std::min<int64_t>(value, 1 << 20)); // next upload
 	else return fail(h, POLARIS_E_BAD_ARGUMENT, "unknown option '%s'", key);
@@ -1400,6 +1403,7 @@ int polaris_hip_tap_primary(polaris_hip_tracer *h, const PolarisBlockRequest *r,
 	if (int rc = ensure_streams(h, 0, std::max<size_t>(h->pipe[0].slots, Npad), true)) return rc;
 	Streams &st0 = h->pipe[0].st;
 	st0.hit12 = 0; // (the tap returns the hit distance: 16-byte records)
+	st0.o12 = 0;
 	if (h->seeds_cap < 1) {
 		HIP_TRY(h, hipMalloc((void **)&h->d_seeds, 64 * sizeof(uint32_t)));
 		h->seeds_cap = 64;
@@ -1488,6 +1492,7 @@ int polaris_hip_probe_intersect(polaris_hip_tracer *h, const float *rays, uint32
 	if (int rc = ensure_streams(h, 0, std::max<size_t>(h->pipe[0].slots, npad), false)) return rc;
 	polaris_hip_tracer::Pipe &P = h->pipe[0];
 	P.st.hit12 = 0; // (the probe returns the hit distance: 16-byte records)
+	P.st.o12 = 0;   // (... and takes arbitrary max distances)
 	hipStream_t q = P.q;
 	float *d_rays = nullptr;
 	HIP_TRY(h, hipMalloc((void **)&d_rays, (size_t)n * 8 * sizeof(float)));
