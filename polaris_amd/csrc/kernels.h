@@ -6,6 +6,7 @@
 // (one 16 B access per lane = the coalescing sweet spot of the guide):
 //     ray_o  = origin.xyz | max distance          ray_d = direction.xyz | path word
 //     thr    = path throughput.xyz | -            hit   = u | v | t | triangle (-1 = miss)
+//     (inside a Trace ray_o and hit are 12-byte records -- origin.xyz, and u | v | triangle: Streams::o12, hit12)
 //     occ_o / occ_d / occ_e = shadow ray origin|maxDist, dir|accumulator cell, NEE radiance|accumulator cell
 //     vis    = one byte per shadow ray: 1 = unoccluded (batched mode: what the any-hit kernels write; k_fold_resolve reads it)
 //     lsum   = per-path radiance of this batch (resolved into the trace accumulator in
