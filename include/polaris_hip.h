@@ -97,7 +97,7 @@ int polaris_hip_set_camera(polaris_hip_tracer *h, const float eye[3], const floa
  *                        2 up to 32 K triangles, 4 above; 0 = keep the caller's leaves).  Never
  *                        changes a result: DESIGN.md 2 (HBM data layout)
  *   further A/B switches of the kernels ("traversal", "node_mode", "packet_shadow", "shade_wave",
- *   "shade_wave_from", "shade_sort", "shade_wgs_per_cu", "stage_lds", "trace_wgs_per_cu", "trace_grid"): see
+ *   "shade_wave_from", "shade_sort", "shade_wgs_per_cu", "stage_lds", "trace_wgs_per_cu", "trace_grid", "hit12", "o12"): see
  *   DESIGN.md 3.  Apart from "exact_accumulate" (the order of the float sums) no option changes a
  *   result; an unknown key is POLARIS_E_BAD_ARGUMENT.  The batch size chosen automatically
  *   ("samples_per_batch" = 0) is clamped by the FREE device memory, and with it the order of the
