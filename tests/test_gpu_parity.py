@@ -438,6 +438,28 @@ def test_edge_shapes(built, oracle):
         assert counters(gs, B) == counters(ws, B)
 
 
+def test_edge_shapes_in_batched_mode(built, oracle):
+    """The shapes of test_edge_shapes through the default (batched) path -- k_fold_resolve walks pixel blocks that are not full,
+    batches of one sample, several batches in flight, a single bounce: counters equal, per-pixel RMSE <= 1e-6."""
+    from oracle import pybind as ob
+    from polaris_amd import scenes
+
+    sc = scenes.SCENES["cubes"]()
+    for (W, H, by, bh, spp, B, opts) in [(70, 9, 4, 1, 3, 4, {}), (1, 5, 0, 5, 4, 2, {"samples_per_batch": 1}), (257, 3, 1, 2, 7, 1, {"samples_per_batch": 2, "overlap": 3}),
+                                         (300, 2, 0, 2, 5, 3, {"samples_per_batch": 5}), (33, 7, 0, 7, 0, 3, {})]:
+        seeds = scenes.make_seeds(max(spp, 1), B)
+        tr = make_hip_tracer(sc, W, H, **opts)
+        try:
+            req = ob.make_request(W, H, spp=spp, bounces=B, block_y=by, block_h=bh)
+            tr.Trace(req, seeds)
+            got, gs = tr.read_accumulator(0), tr.last_trace_stats
+        finally:
+            tr.Close()
+        want, ws, _ = oracle.trace(sc, ob.make_request(W, H, spp=spp, bounces=B, block_y=by, block_h=bh), seeds)
+        assert counters(gs, B) == counters(ws, B), (W, H, by, bh, spp, B)
+        assert rmse(got, want, max(spp, 1)) <= 1e-6, (W, H, by, bh, spp, B)
+
+
 def test_error_behaviour(built):
     """ErrNoSceneData before an upload (tracer.go:203-205), bad requests and bad scenes are status
     codes with a message."""
