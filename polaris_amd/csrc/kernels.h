@@ -436,11 +436,12 @@ constexpr int kFirstLeafRef = (int)0x80000010;
 //                 two-way fetch compiles to ONE flat_load through a selected pointer (small trees: -13 % kernel time)
 //   kNodesLdsAll  "tiny scene" mode (<= kTinyPairs pair records, < 2047 triangle slots and nodes, stack <= 16): the WHOLE tree
 //                 sits in LDS and is read with ds_read_b128 (no FLAT path, no L1 gathers for nodes).  What makes that fit at
-//                 full occupancy: workgroups of 1024 threads share ONE copy of the tree (32 KB) and the stack entries are
-//                 16-bit node codes (34 KB for 1024 lanes x (16 entries + the dummy row below an empty stack)) -- 66 KB per
-//                 workgroup, two workgroups (132 KB of a CU's 160 KB) = 8 waves per SIMD: this mode exists for gfx950's LDS
-//                 and is static_assert-ed against it in k_trace.  (Round 1 tried the whole tree in LDS with 256-thread
-//                 workgroups: 48 KB each, 3 per CU, +-0.)
+//                 full occupancy: workgroups of 1024 threads share ONE copy of the tree (<= 32 KB) and the stack entries are
+//                 16-bit node codes (2 KB per row for the 1024 lanes).  Since round 4 the block is laid out per scene -- the
+//                 rows the tree needs, its pair records, and the triangle records that still fit half a CU's 160 KB
+//                 (polaris_hip.hip plan_tiny_lds; the layout is in k_trace): two workgroups per CU = 8 waves per SIMD.  This
+//                 mode exists for gfx950's LDS.  (Round 1 tried the whole tree in LDS with 256-thread workgroups: 48 KB each,
+//                 3 per CU, +-0.)
 enum NodeMode { kNodesGlobal = 0, kNodesLdsTop = 1, kNodesLdsAll = 2 };
 constexpr int kTinyPairs = 512;
 constexpr int kTinyBlock = 1024;
