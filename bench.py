@@ -80,7 +80,7 @@ def kernel_algorithmic_bytes(st, shade_counts, B: int, packet_camera: bool):
         "intersect_packet": (16 + 12) * prim if packet_camera else 0,      # ray_d load, hit store (12 B: u, v, triangle word -- no t inside a Trace)
         "intersect": (12 + 16 + 12) * int(st.indirect_rays) + (16 + 12) * cam_per_ray,  # ray_o (12 B: no max distance inside a Trace) + ray_d loads, hit store (camera rays: no ray_o)
         "occlusion": 32 * int(st.occlusion_rays) + 4 * int(st.unoccluded),   # occ_o + occ_d loads; an unoccluded ray marks its NEE record (4 B)
-        "fold": 17 * int(st.occlusion_rays) + 16 * prim,                     # every NEE record + visibility byte once, the per-path terminal cells read once (k_fold_resolve)
+        "fold": 16 * int(st.occlusion_rays) + 32 * prim,                     # every NEE record once + the per-path cells read and written once per batch
     }
     for name in SHADE_TIMERS:
         ref[name] = lay[name] = 0

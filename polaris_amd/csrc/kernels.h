@@ -8,7 +8,7 @@
 //     thr    = path throughput.xyz | -            hit   = u | v | t | triangle (-1 = miss)
 //     (inside a Trace ray_o and hit are 12-byte records -- origin.xyz, and u | v | triangle: Streams::o12, hit12)
 //     occ_o / occ_d / occ_e = shadow ray origin|maxDist, dir|accumulator cell, NEE radiance|accumulator cell
-//     vis    = one byte per shadow ray: 1 = unoccluded (batched mode: what the any-hit kernels write; k_fold_resolve reads it)
+//     vis    = one byte per shadow ray: 1 = unoccluded (batched mode: what the any-hit kernels write; k_fold_nee reads it)
 //     lsum   = per-path radiance of this batch (resolved into the trace accumulator in
 //              sample order at the end of the batch)
 // path word = path index (24 bit, the reference keeps it as a float in dir.w,
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(WG) void k_intersect(Streams st, BvhDev B) {
 //   acc == null  (batched mode) -- DEFERRED: every shadow ray writes ONE BYTE, vis[slot] = unoccluded (a dense array: the
 //                stores of a chunk's rays fill whole sectors -- a 4-byte flag inside the 16-byte record, tried first, cost 19
 //                bytes of write traffic per flag); the NEE records of every bounce are kept (one occ_e / vis array per
-//                bounce) and k_fold_resolve adds the unoccluded ones to the per-path radiance once per batch, bounce after
+//                bounce) and k_fold_nee adds the unoccluded ones to the per-path radiance once per batch, bounce after
 //                bounce -- the same sums in the same order.  Until round 4 every unoccluded ray did a read-modify-write of its
 //                16-byte cell of lsum, scattered over the chunk's 4 KB: whole lines moved per bounce (1.55 x the kernel's
 //                algorithmic bytes), and the any-hit kernel loaded the NEE radiance and the cell beside every ray.
@@ -676,7 +676,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 					float *c = reinterpret_cast<float *>(acc + cell);
 					c[0] = acc_old.x + nee.x; c[1] = acc_old.y + nee.y; c[2] = acc_old.z + nee.z;
 				} else {
-					st.vis[slot] = 1; // deferred: k_fold_resolve adds the ray's NEE record
+					st.vis[slot] = 1; // deferred: k_fold_nee adds the ray's NEE record
 				}
 				unocc++;
 			} else {
@@ -998,7 +998,7 @@ struct ShadeOut {
 
 // A path's TERMINAL contribution -- background radiance of a missed ray (pt_integrator.cl:214-275) or the radiance of a directly
 // hit emitter (:101-107): a path gets at most one, at its end.  Exact mode adds it to the trace accumulator in the reference's
-// order.  Batched mode: the per-path cell of lsum holds nothing else until k_fold_resolve (the NEE terms are deferred), so it is a
+// order.  Batched mode: the per-path cell of lsum holds nothing else until k_fold_nee (the NEE terms are deferred), so it is a
 // plain 16-byte store, not a read-modify-write.
 __device__ __forceinline__ void terminal_add(const ShadeArgs &A, uint32_t cell, f3 add) {
 	if (A.exact) {
@@ -1567,56 +1567,58 @@ __global__ __launch_bounds__(1024) void k_scan(Streams st, uint32_t wgs_per_samp
 	}
 }
 
-// accumulateEmissiveSamples (pt_integrator.cl:278-296) for a whole batch at once, and the batch's resolve (k_fold_resolve below):
-// a chunk's unoccluded shadow rays (nee_result: vis) add their NEE records, bounce after bounce, to the chunk's 256 per-path
-// cells in LDS.  A path has at most one shadow ray per bounce, so the adds of one bounce never collide, and the barrier between
-// bounces keeps a path's terms in the reference's order: ((nee_0 + nee_1) + ...) + terminal contribution -- the sums the
-// per-bounce read-modify-writes used to produce, bit for bit.
+// accumulateEmissiveSamples (pt_integrator.cl:278-296) for a whole batch at once: one workgroup per chunk adds the NEE records its
+// unoccluded shadow rays left (nee_result: vis), bounce after bounce, to the chunk's 256 per-path cells and writes them back
+// as one coalesced 4 KB store.  A path has at most one shadow ray per bounce, so the adds of one bounce never collide, and the
+// barrier between bounces keeps a path's terms in the reference's order: ((nee_0 + nee_1) + ...) + terminal contribution -- the
+// sums the per-bounce read-modify-writes used to produce, bit for bit.
 struct FoldArgs { const float4 *nee[POLARIS_MAX_BOUNCES]; const uint8_t *vis[POLARIS_MAX_BOUNCES]; const uint32_t *cnt[POLARIS_MAX_BOUNCES]; uint32_t bounces; };
-// A workgroup owns 256 pixels of the block, walks the batch's samples in ascending order, folds each sample's chunk (four
-// bounces at a time: their counts, then their records, are requested together -- two memory round trips per group, the adds stay
-// in bounce order) and adds the resulting per-path radiance to its pixel's running sum: trace accumulator += per-path radiance,
-// samples in ascending order.  (Until round 4 two kernels -- k_fold_nee wrote the folded cells, k_resolve read them back: the same
-// bits, 1.07 GB per headline frame more through HBM and a launch more per batch; frame -0.5 %.)
-__global__ __launch_bounds__(WG) void k_fold_resolve(FoldArgs F, const float4 *lsum, float4 *out, uint32_t K, uint32_t N, uint32_t Npad, uint32_t pixel0) {
+__global__ __launch_bounds__(WG) void k_fold_nee(FoldArgs F, float4 *lsum) {
 	__shared__ float acc[3][WG];
-	const uint32_t tid = threadIdx.x, idx = blockIdx.x * WG + tid;
-	const uint32_t wgs_per_sample = Npad / WG;
-	float4 a = idx < N ? out[pixel0 + idx] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-	for (uint32_t s = 0; s < K; s++) {
-		const uint32_t chunk = s * wgs_per_sample + blockIdx.x, base = chunk * WG;
-		acc[0][tid] = 0.0f; acc[1][tid] = 0.0f; acc[2][tid] = 0.0f;
-		const float4 term = lsum[base + tid]; // the path's terminal contribution (or 0)
-		__syncthreads();
-		uint32_t any = 0;
-		for (uint32_t b0 = 0; b0 < F.bounces; b0 += 4) {
-			uint32_t n[4];
+	const uint32_t tid = threadIdx.x;
+	const uint32_t base = blockIdx.x * WG;
+	acc[0][tid] = 0.0f; acc[1][tid] = 0.0f; acc[2][tid] = 0.0f;
+	const float4 term = lsum[base + tid]; // the path's terminal contribution (or 0): requested before the records
+	__syncthreads();
+	uint32_t any = 0;
+	// four bounces at a time: their counts, then their records, are requested together (two memory round trips per group, not
+	// two per bounce: the kernel is a chain of dependent loads, 1 GB per batch), the adds stay in bounce order
+	for (uint32_t b0 = 0; b0 < F.bounces; b0 += 4) {
+		uint32_t n[4];
 #pragma unroll
-			for (uint32_t k = 0; k < 4; k++) n[k] = b0 + k < F.bounces ? F.cnt[b0 + k][chunk] : 0u;
-			float4 r[4];
-			uint32_t v[4];
+		for (uint32_t k = 0; k < 4; k++) n[k] = b0 + k < F.bounces ? F.cnt[b0 + k][blockIdx.x] : 0u;
+		float4 r[4];
+		uint32_t v[4];
 #pragma unroll
-			for (uint32_t k = 0; k < 4; k++) {
-				v[k] = 0;
-				r[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-				if (tid < n[k]) { v[k] = F.vis[b0 + k][base + tid]; r[k] = F.nee[b0 + k][base + tid]; }
-			}
-#pragma unroll
-			for (uint32_t k = 0; k < 4; k++) {
-				if (v[k]) {
-					const uint32_t local = (uint32_t)fbits(r[k].w) - base;
-					acc[0][local] += r[k].x; acc[1][local] += r[k].y; acc[2][local] += r[k].z;
-				}
-				any |= n[k];
-				__syncthreads();
-			}
+		for (uint32_t k = 0; k < 4; k++) {
+			v[k] = 0;
+			r[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			if (tid < n[k]) { v[k] = F.vis[b0 + k][base + tid]; r[k] = F.nee[b0 + k][base + tid]; }
 		}
-		// (a chunk without shadow rays: the cell IS the terminal contribution, not 0 + it -- the sign of a zero)
-		const float cx = any ? acc[0][tid] + term.x : term.x, cy = any ? acc[1][tid] + term.y : term.y, cz = any ? acc[2][tid] + term.z : term.z;
-		a.x += cx; a.y += cy; a.z += cz;
-		__syncthreads(); // (the next sample clears the cells)
+#pragma unroll
+		for (uint32_t k = 0; k < 4; k++) {
+			if (v[k]) {
+				const uint32_t local = (uint32_t)fbits(r[k].w) - base; // the ray's path: a cell of this chunk (rays never leave their chunk)
+				acc[0][local] += r[k].x; acc[1][local] += r[k].y; acc[2][local] += r[k].z;
+			}
+			any |= n[k];
+			__syncthreads();
+		}
 	}
-	if (idx < N) out[pixel0 + idx] = a;
+	if (any == 0) return; // (uniform) no shadow ray in any bounce: the cells already hold what they should
+	lsum[base + tid] = make_float4(acc[0][tid] + term.x, acc[1][tid] + term.y, acc[2][tid] + term.z, 0.0f);
+}
+
+// Batch epilogue: trace accumulator += per-path radiance, samples added in ascending order.
+__global__ __launch_bounds__(WG) void k_resolve(const float4 *lsum, float4 *acc, uint32_t K, uint32_t N, uint32_t Npad, uint32_t pixel0) {
+	const uint32_t idx = blockIdx.x * WG + threadIdx.x;
+	if (idx >= N) return;
+	float4 a = acc[pixel0 + idx];
+	for (uint32_t s = 0; s < K; s++) {
+		const float4 l = lsum[(size_t)s * Npad + idx];
+		a.x += l.x; a.y += l.y; a.z += l.z;
+	}
+	acc[pixel0 + idx] = a;
 }
 
 // aggregateAccumulator, kernels/accumulator.cl:13-19 (rows of one block)

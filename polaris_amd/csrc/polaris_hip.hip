@@ -111,7 +111,7 @@ struct polaris_hip_tracer {
 		hipStream_t q = nullptr;
 		size_t slots = 0; // capacity in slots
 		Streams st{};
-		// batched mode: one NEE record array (occ_e) and one shadow-ray count array (cnt_occ) PER BOUNCE, kept until k_fold_resolve has
+		// batched mode: one NEE record array (occ_e) and one shadow-ray count array (cnt_occ) PER BOUNCE, kept until k_fold_nee has
 		// added the batch's unoccluded records to the per-path radiance (kernels.h, nee_unoccluded); [0] are st.occ_e / st.cnt_occ
 		float4 *nee[POLARIS_MAX_BOUNCES] = {};
 		uint8_t *vis[POLARIS_MAX_BOUNCES] = {};
@@ -517,7 +517,7 @@ hipError_t launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest 
 	const uint32_t persistent = grid_of(h->trace_resident_per_cu), persistent_occl = grid_of(h->occl_resident_per_cu);
 	for (uint32_t b = 0; b < B; b++) {
 		Streams S = P.st; // (in place: k_shade / k_shade_wave read a chunk's rays before they write into it)
-		if (!exact) { S.occ_e = P.nee[b]; S.vis = P.vis[b]; S.cnt_occ = P.cnt_occ_b[b]; } // this bounce's NEE records, visibility bytes and shadow-ray counts stay until k_fold_resolve
+		if (!exact) { S.occ_e = P.nee[b]; S.vis = P.vis[b]; S.cnt_occ = P.cnt_occ_b[b]; } // this bounce's NEE records, visibility bytes and shadow-ray counts stay until k_fold_nee
 		float4 *const occl_acc = exact ? A.acc : nullptr;                // batched: unoccluded rays only mark their record (deferred)
 		{
 			Timed t(h, (b == 0 && h->packet_primary) ? "intersect_packet" : "intersect", q);
@@ -585,16 +585,19 @@ hipError_t launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest 
 				hipLaunchKernelGGL(k_occlusion, dim3(wgs), dim3(WG), 0, q, S, h->bvh, occl_acc, h->d_stats);
 		}
 	}
-	if (!exact) {
-		// accumulateEmissiveSamples of the whole batch and the batch's resolve in one pass (kernels.h k_fold_resolve); batches
-		// resolve into the trace accumulator in sample order: wait for the previous batch's
+	if (!exact && B > 0) { // accumulateEmissiveSamples of the whole batch: the marked NEE records of every bounce into the per-path radiance
 		FoldArgs F{};
 		for (uint32_t b = 0; b < B; b++) { F.nee[b] = P.nee[b]; F.vis[b] = P.vis[b]; F.cnt[b] = P.cnt_occ_b[b]; }
 		F.bounces = B;
-		if (resolve_after) note(hipStreamWaitEvent(q, resolve_after, 0));
 		Timed t(h, "fold", q);
-		if (h->opt_time_kernels) h->timer_symbol["fold"] = "pol::k_fold_resolve";
-		hipLaunchKernelGGL(k_fold_resolve, dim3(Npad / WG), dim3(WG), 0, q, F, (const float4 *)P.st.lsum, h->trace_acc, K, N, Npad, r->block_y * h->W);
+		if (h->opt_time_kernels) h->timer_symbol["fold"] = "pol::k_fold_nee";
+		hipLaunchKernelGGL(k_fold_nee, dim3(wgs), dim3(WG), 0, q, F, P.st.lsum);
+	}
+	if (!exact) {
+		// batches resolve into the trace accumulator in sample order: wait for the previous batch's resolve
+		if (resolve_after) note(hipStreamWaitEvent(q, resolve_after, 0));
+		Timed t(h, "resolve", q);
+		hipLaunchKernelGGL(k_resolve, dim3(grid_for(N)), dim3(WG), 0, q, P.st.lsum, h->trace_acc, K, N, Npad, r->block_y * h->W);
 	}
 	note(hipEventRecord(P.done, q));
 	note(hipGetLastError()); // (launches through hipLaunchKernelGGL report here)

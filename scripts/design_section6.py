@@ -50,8 +50,7 @@ store one by one as their rays end: partial sectors).  The kernel is bound by ve
 frame got 2 % faster: for this kernel the fraction measures how few bytes the formulation needs, not how well it runs.
 Isolated kernel times add up to {iso:.2f} ms per frame; two batches in flight bring the frame to {d['ms_per_frame']:.2f}.
 (`k_generate` reads nothing and writes two streams: its rate is the rate at which stores are taken by L2 / the Infinity Cache — a
-write-only kernel retires before its lines are in HBM — so its `frac` says "as fast as stores go", not an HBM measurement.
-`k_fold_resolve` is a chain of dependent loads, 64 samples deep per workgroup: latency, not bandwidth.)
+write-only kernel retires before its lines are in HBM — so its `frac` says "as fast as stores go", not an HBM measurement.)
 
 All configurations (`scripts/configs.py` → `r04_configs.json`; every one at its FULL frame size and sample count; three timed frames
 each, which reads 1-3 % above `bench.py`'s twenty):
@@ -64,7 +63,7 @@ each, which reads 1-3 % above `bench.py`'s twenty):
 Against round 3: headline 11.53 → {cfg['headline']['ms_per_frame']:.2f} ms in this table's three-frame timing, C2 6.34 → {cfg['C2']['ms_per_frame']:.2f}, C3 85.8 → {cfg['C3']['ms_per_frame']:.1f}
 (the tiny-mode work of §3.1); C5 4 843 Mrays/s at 16 spp → {cfg['C5-16spp']['Mrays_per_s']:.0f} ({cfg['C5']['Mrays_per_s']:.0f} at its full 1 024 spp: the instance handling); C4 361 → {cfg['C4']['ms_per_frame']:.0f} ms and the
 terrain 22.3 → {cfg['terrain']['ms_per_frame']:.1f} (gather-bound, §3.1: the ray set-up's cheaper reciprocal, one stack write less per ray and the
-fused fold are all they got).
+12-byte records are all they got).
 
 CPU baseline (oracle, sample-parallel OpenMP on the 16 CPUs the box grants): {d['cpu_baseline']['sample'].split(',')[1].strip()} of the same frame: {d['cpu_baseline']['value']:.1f} Mrays/s,
 {d['cpu_baseline']['ms_per_frame_extrapolated']/1e3:.2f} s per 128-spp frame — baseline only.  The boundary hands over no per-frame host buffers (scene and camera are
