@@ -849,7 +849,9 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 	if (h->opt_packet_primary < 0) h->packet_primary = sc->num_triangles <= 32768u && sc->num_mesh_instances == 1;
 	// node records: whole tree in LDS for tiny scenes, its top for small ones, global memory otherwise (kernels.h NodeMode)
 	// (16-bit stack entries: triangle slots and instance ids must fit 11 bits, and no leaf reference may carry kBigLeafFlag)
-	const bool tiny_ok = L.pairs.size() <= (size_t)kTinyPairs && L.tris.size() <= kTinyMaxIndex && L.insts.size() <= kTinyMaxIndex && L.big_leaves == 0 && L.max_stack <= 16;
+	// (... and the packed word of a slot holds the scene triangle in 11 bits too: scene_layout.h tiny_meta_word)
+	const bool tiny_ok = L.pairs.size() <= (size_t)kTinyPairs && L.tris.size() <= kTinyMaxIndex && sc->num_triangles <= kTinyMaxIndex && L.insts.size() <= kTinyMaxIndex &&
+	                     L.big_leaves == 0 && L.max_stack <= 16;
 	h->node_mode = tiny_ok ? kNodesLdsAll : (L.pairs.size() <= (size_t)(POLARIS_LDS_TOP_MAX_PAIRS) ? kNodesLdsTop : kNodesGlobal);
 	if (h->opt_node_mode >= 0 && (h->opt_node_mode != kNodesLdsAll || tiny_ok)) h->node_mode = h->opt_node_mode;
 	h->tiny_lds_bytes = 0;
