@@ -439,7 +439,7 @@ def test_edge_shapes(built, oracle):
 
 
 def test_edge_shapes_in_batched_mode(built, oracle):
-    """The shapes of test_edge_shapes through the default (batched) path -- k_fold_resolve walks pixel blocks that are not full,
+    """The shapes of test_edge_shapes through the default (batched) path -- k_fold_nee / k_resolve on chunks and pixel blocks that are not full,
     batches of one sample, several batches in flight, a single bounce: counters equal, per-pixel RMSE <= 1e-6."""
     from oracle import pybind as ob
     from polaris_amd import scenes
