@@ -216,8 +216,11 @@ def main() -> None:
                     "trace accumulator through HIP IPC mappings (polaris_hip_merge_ipc; falls back to `strips` if a mapping cannot be opened), "
                     "`strips`: point-to-point transfers of the strips on --backend")
     ap.add_argument("--backend", default="nccl", help="--exchange strips: torch.distributed backend of the strip transfers (nccl = RCCL; gloo only to test that flow on one GPU)")
-    ap.add_argument("--test-ipc-failure", action="store_true", help="testing aid: rank 0 refuses to map the peers' rings, as if hipIpcOpenMemHandle had failed -- "
-                    "the run must fall back to the strip transfers inside the same processes")
+    ap.add_argument("--test-ipc-failure", nargs="?", const="open", default="", choices=("open", "export"), help="testing aid: `open` (the default when the flag is "
+                    "given bare): rank 0 refuses to map the peers' rings, as if hipIpcOpenMemHandle had failed; `export`: the last rank's export fails, as if "
+                    "hipIpcGetMemHandle had -- either way the run must fall back to the strip transfers inside the same processes, on every rank")
+    ap.add_argument("--test-delay-rank", default="", help="testing aid, R:MS -- rank R sleeps MS milliseconds after every Trace, so that the others run as far "
+                    "ahead as the exchange protocol lets them (a ring slot reused too early then shows in the assembled frame)")
     ap.add_argument("--no-second-scheduler", action="store_true", help="N > 1: skip the second timed region (the perfect scheduler when --scheduler naive)")
     ap.add_argument("--same-device", action="store_true", help="testing aid: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--emulate-rank", default="", help="R/N: on ONE GPU, trace only the row block rank R of N would own "
@@ -333,10 +336,14 @@ def main() -> None:
 
         if args.exchange == "ipc":
             port = HipPort(tr, make_req)
-            if args.test_ipc_failure:
+            if args.test_ipc_failure == "open":
                 def refuse(blob):
                     raise RuntimeError("hipIpcOpenMemHandle: refused (--test-ipc-failure)")
                 port.open = refuse
+            elif args.test_ipc_failure == "export" and rank == world - 1:
+                def refuse_export(depth):
+                    raise RuntimeError("hipIpcGetMemHandle: refused (--test-ipc-failure export)")
+                port.export = refuse_export
             px = PeerExchange(dist, rank, world, W, H, port, scheduler=args.scheduler)
             if px.setup():
                 exchange = (f"hip-ipc: rank 0's merge stream reads every rank's rows through an IPC mapping of its trace accumulator ring "
@@ -347,11 +354,30 @@ def main() -> None:
                 exchange = f"fallback after a failed IPC mapping ({px.why_not[:120]}): "
                 px = None
         if px is None:
-            strip_group = dist.new_group(backend="nccl") if args.backend == "nccl" else None   # (RCCL communicators only exist on this path)
-            xdev = dev if args.backend == "nccl" else torch.device("cpu")
-            ex = StripExchange(dist, rank, world, W, H, dev, via_host=args.backend != "nccl", group=strip_group)
+            backend = args.backend
+            if backend == "nccl":                      # (RCCL communicators only exist on this path)
+                # the last resort must not be able to fail: if RCCL cannot be brought up on EVERY rank (one warm-up all_reduce
+                # each, the verdicts gathered over gloo), the strips travel over gloo, staged through the host
+                err = ""
+                try:
+                    strip_group = dist.new_group(backend="nccl")
+                    probe = torch.ones(1, device=dev)
+                    dist.all_reduce(probe, group=strip_group)
+                    torch.cuda.synchronize()
+                    if int(probe.item()) != world:
+                        err = f"rank {rank}: RCCL warm-up all_reduce returned {probe.item()}, expected {world}"
+                except Exception as e:
+                    err = f"rank {rank}: {e}"
+                errs = [None] * world
+                dist.all_gather_object(errs, err)
+                if any(errs):
+                    if rank == 0:
+                        print(f"bench.py: RCCL is not usable for the strips ({next(e for e in errs if e)[:200]}); using gloo through the host", file=sys.stderr)
+                    backend, strip_group = "gloo", None
+            xdev = dev if backend == "nccl" else torch.device("cpu")
+            ex = StripExchange(dist, rank, world, W, H, dev, via_host=backend != "nccl", group=strip_group)
             fb = SchedulerFeedback(dist, rank, world, H, xdev, kind=args.scheduler, group=strip_group)
-            exchange = (exchange if args.exchange == "ipc" else "") + f"{args.backend} point-to-point transfers of the row-block strips to rank 0, one frame behind the tracing"
+            exchange = (exchange if args.exchange == "ipc" else "") + f"{backend} point-to-point transfers of the row-block strips to rank 0, one frame behind the tracing"
     totals = {k: 0 for k in ("primary_rays", "indirect_rays", "occlusion_rays", "shaded_hits", "shaded_misses", "emitter_hits", "unoccluded")}
     pending = []
     rows_log = []
@@ -360,10 +386,10 @@ def main() -> None:
 
     def finish_frame(ticket):
         if px is not None:
-            t = time.perf_counter()
-            px.finish(ticket)                      # rank 0: Reset stage, one peer-read merge per block, tone-map (default.go:159-161)
-            if rank == 0:
-                own_work[0] += time.perf_counter() - t
+            # rank 0: Reset stage, one peer-read merge per block, tone-map (default.go:159-161).  Only those seconds are this
+            # rank's work; the wait for the slowest rank's message inside finish() is not (as with ex.wait() below): billed to
+            # the primary it would make the perfect scheduler shrink rank 0's block frame after frame
+            own_work[0] += px.finish(ticket)
             return
         parts = ex.wait(ticket)                    # (waiting for the others' strips is not this rank's work)
         if rank == 0:
@@ -379,6 +405,10 @@ def main() -> None:
             finish_frame(pending.pop(0))
 
     frame_no = [0]
+    delay_rank, delay_s = -1, 0.0
+    if args.test_delay_rank:
+        dr, dms = args.test_delay_rank.split(":")
+        delay_rank, delay_s = int(dr), float(dms) * 1e-3
 
     def frame(count: bool):
         nonlocal rows, block_y, block_h
@@ -392,6 +422,8 @@ def main() -> None:
             frame_no[0] += 1
         t_own = time.perf_counter()
         tr.Trace(req, fseeds)                      # Trace (tracer.go:194-247)
+        if delay_rank == rank:
+            time.sleep(delay_s)
         if count:
             st = tr.last_trace_stats
             for k in totals:

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define POLARIS_HIP_ABI_VERSION 3 /* 2: + reset_epoch / wait_reset, kernel_symbol, shade_counts; 3: + ipc_export / ipc_open / ipc_close / merge_ipc / merge_slot / trace_slot (additions only: older callers keep working) */
+#define POLARIS_HIP_ABI_VERSION 4 /* 2: + reset_epoch / wait_reset, kernel_symbol, shade_counts; 3: + ipc_export / ipc_open / ipc_close / merge_ipc / merge_slot / trace_slot (additions only: older callers keep working); 4: PolarisIpcExport carries one event handle PER RING SLOT (the blob grows from 352 to 544 bytes; ipc_open refuses a blob of another version) */
 
 /* status codes (0 = ok).  The first three mirror tracer/opencl/errors.go sentinels. */
 #define POLARIS_OK                0
@@ -159,8 +159,11 @@ int polaris_hip_merge_device(polaris_hip_tracer *dst, const void *device_rows, c
  * frame f + 1 -- no copy, no staging strip.  The caller's protocol must guarantee that the primary has finished reading a
  * slot (its merge completed: sync_framebuffer) before the secondary's Trace comes round to it again; with the exchange one
  * frame behind the tracing that needs depth 3 (polaris_amd/distributed.py: PeerExchange states the argument).  The blob
- * also carries an inter-process event recorded at the end of every Trace; merge_ipc makes the merge stream wait for it
- * (device-side ordering on top of the host message; has_event = 0 if the runtime could not export one).  A resize
+ * also carries one inter-process event PER RING SLOT, recorded at the end of the Trace that wrote the slot; merge_ipc(slot)
+ * makes the merge stream wait for that slot's event (device-side ordering on top of the host message; has_event = 0 if the
+ * runtime could not export them).  Because a slot's event is only re-recorded when a Trace comes round to the slot again --
+ * which the protocol above rules out while the slot may still be read -- the wait names exactly the Trace whose rows are
+ * read, however far the secondary has run ahead (ABI 3 had one event for the whole ring, re-recorded by every Trace).  A resize
  * invalidates the export: peers close, the tracer exports again.  hipIpcOpenMemHandle cannot open a handle in the process
  * that created it: tracers of ONE process use polaris_hip_merge / polaris_hip_merge_slot.
  */
@@ -169,10 +172,10 @@ typedef struct PolarisIpcExport {
 	uint32_t abi_version, depth, frame_w, frame_h;
 	int32_t device;     /* HIP device index in the exporting process */
 	uint32_t pid;       /* exporting process (diagnostics; opening in the same process is refused) */
-	uint32_t has_event; /* 1: `event` holds a hipIpcEventHandle_t */
+	uint32_t has_event; /* 1: `event[i]` holds a hipIpcEventHandle_t for every slot i < depth */
 	uint32_t reserved;
-	uint8_t mem[POLARIS_IPC_MAX_DEPTH][64]; /* hipIpcMemHandle_t per ring slot */
-	uint8_t event[64];                      /* hipIpcEventHandle_t: recorded at the end of every Trace */
+	uint8_t mem[POLARIS_IPC_MAX_DEPTH][64];   /* hipIpcMemHandle_t per ring slot */
+	uint8_t event[POLARIS_IPC_MAX_DEPTH][64]; /* hipIpcEventHandle_t per ring slot: recorded at the end of the Trace that wrote the slot */
 } PolarisIpcExport;
 typedef struct polaris_hip_peer polaris_hip_peer; /* opaque: another process's trace accumulator ring, mapped here */
 
@@ -182,8 +185,10 @@ int polaris_hip_ipc_close(polaris_hip_tracer *dst, polaris_hip_peer *peer); /* w
 /* dst.frameAccumulator[rows of req] += peer.traceAccumulator ring[slot][rows of req]; asynchronous on dst's merge stream
  * like polaris_hip_merge, completed by polaris_hip_sync_framebuffer(dst). */
 int polaris_hip_merge_ipc(polaris_hip_tracer *dst, polaris_hip_peer *peer, uint32_t slot, const PolarisBlockRequest *req);
-/* The ring slot the last Trace wrote (0 without a ring), and polaris_hip_merge from a given slot of a tracer of THIS
- * process (a primary that merges its own block one frame late reads the slot of that frame, not the newest). */
+/* The ring slot the last Trace wrote (0 without a ring; a Trace that fails before it has queued anything leaves it alone),
+ * and polaris_hip_merge from a given slot of a tracer of THIS process (a primary that merges its own block one frame late
+ * reads the slot of that frame, not the newest).  Like polaris_hip_merge, a merge_slot with src != dst is fenced on the
+ * device against src's next Trace. */
 int polaris_hip_trace_slot(polaris_hip_tracer *h, uint32_t *slot);
 int polaris_hip_merge_slot(polaris_hip_tracer *dst, polaris_hip_tracer *src, uint32_t slot, const PolarisBlockRequest *req);
 

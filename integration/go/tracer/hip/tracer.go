@@ -260,7 +260,7 @@ func (tr *Tracer) ReadFrameBuffer(pix []uint8) error {
 // ---- one tracer per PROCESS (INTEGRATION.md section 3b): the merge as a peer read through HIP IPC --------------------------
 
 // IpcExport turns the trace accumulator into a ring of `depth` buffers (every Trace writes the next; TraceSlot says which) and
-// returns the 352-byte blob another process opens with IpcOpen.  Plain bytes: send them over any channel.
+// returns the 544-byte blob another process opens with IpcOpen.  Plain bytes: send them over any channel.
 func (tr *Tracer) IpcExport(depth uint32) ([]byte, error) {
 	var x C.PolarisIpcExport
 	if err := tr.check(C.polaris_hip_ipc_export(tr.handle, C.uint32_t(depth), &x)); err != nil {

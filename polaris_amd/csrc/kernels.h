@@ -108,6 +108,12 @@ struct Streams {
 	// one of them (camera rays, camera.cl; bounce rays, pt_integrator.cl:209), so it is neither stored nor loaded.  (Shadow rays
 	// carry a real distance in occ_o.w; the probes and taps pass arbitrary ones: 16 bytes there.)
 	uint32_t o12;
+#ifdef POLARIS_EXP_REORDER
+	// experiment build (scripts/wave_lines.sh; EXPERIMENTS.md "coherence reorder"): k_trace takes its rays in the order of
+	// perm[0 .. *perm_n) -- absolute slots, produced by a sort of per-ray keys between the shade step and the launch -- instead of
+	// chunk by chunk.  Hits still go to the ray's own slot, so results are unchanged bit for bit; what changes is which rays share a wave.
+	const uint32_t *perm, *perm_n;
+#endif
 };
 __device__ __forceinline__ float4 load_ray_o(const Streams &st, size_t slot) {
 	if (st.o12) { const float *p = reinterpret_cast<const float *>(st.ray_o) + 3 * slot; return make_float4(p[0], p[1], p[2], 3.402823466e+38f); }
@@ -131,7 +137,7 @@ __device__ __forceinline__ float4 load_hit(const Streams &st, size_t slot) {
 // every shade launch -- i.e. every kernel symbol -- with its own counts, polaris_hip_shade_counts)
 enum StatSlot { ST_UNOCCLUDED = 0, ST_RAYS_BOUNCE, ST_OCCL_BOUNCE = ST_RAYS_BOUNCE + POLARIS_MAX_BOUNCES, ST_HITS_BOUNCE = ST_OCCL_BOUNCE + POLARIS_MAX_BOUNCES,
                 ST_MISSES_BOUNCE = ST_HITS_BOUNCE + POLARIS_MAX_BOUNCES, ST_EMITTERS_BOUNCE = ST_MISSES_BOUNCE + POLARIS_MAX_BOUNCES,
-                ST_DEBUG = ST_EMITTERS_BOUNCE + POLARIS_MAX_BOUNCES, ST_COUNT = ST_DEBUG + 16 };
+                ST_DEBUG = ST_EMITTERS_BOUNCE + POLARIS_MAX_BOUNCES, ST_COUNT = ST_DEBUG + 32 };
 
 __device__ __forceinline__ int fbits(float f) { return __float_as_int(f); }
 __device__ __forceinline__ float ibits(int i) { return __int_as_float(i); }
@@ -584,6 +590,9 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 		if (ONE) { boxDist = __builtin_fminf(maxDist, kFltMax); best_cull = best_t * kCullMargin; }
 	};
 	// the next rays of the workgroup's chunks go to the lanes for which wants() holds (take(slot) must make it false)
+#ifdef POLARIS_EXP_REORDER
+	const uint32_t perm_total = st.perm ? *st.perm_n : 0u;
+#endif
 	auto draw = [&](auto wants, auto take) {
 		for (;;) {
 			if (off >= cnt) {
@@ -593,6 +602,9 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 				if (c >= num_chunks) { drained = true; break; }
 				chunk = c;
 				off = 0;
+#ifdef POLARIS_EXP_REORDER
+				if (st.perm) { cnt = chunk * WG < perm_total ? min((uint32_t)WG, perm_total - chunk * WG) : 0u; continue; }
+#endif
 				cnt = cnts[chunk];
 				continue;
 			}
@@ -601,16 +613,34 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 			if (n == 0) break;
 			const uint32_t share = min(cnt - off, n);
 			const uint32_t rank = __popcll(m & below);
+#ifdef POLARIS_EXP_REORDER
+			if (st.perm) { if (wants() && rank < share) take(st.perm[chunk * WG + off + rank]); }
+			else
+#endif
 			if (wants() && rank < share) take(chunk * WG + off + rank);
 			off += share;
 		}
 	};
 #ifdef POLARIS_PROFILE_LOOPS
 	// profiling build (scripts/loop_profile.sh): wave-level iteration counts and the lanes that were live in them -- closest hit in
-	// ST_DEBUG + 0..7, any hit in + 8..15: [0] outer iterations [1] lanes holding a ray in them [2] node steps [3] lanes descending
+	// ST_DEBUG + 0..15, any hit in + 16..31: [0] outer iterations [1] lanes holding a ray in them [2] node steps [3] lanes descending
 	// [4] triangle rounds [5] lanes testing [6] refills [7] rays started
-	unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	// [8] distinct 128-byte lines the live lanes of a node step fetch their pair records from [9] the same for the triangle records of a
+	// triangle round (a 48-byte record may straddle two lines: both count) [10] lanes entering an instance [11] distinct instance records they fetch
+	unsigned long long pc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define PROF(i, v) pc[i] += (unsigned long long)(v)
+	// number of distinct values of a (and, where has_b, of b) over the lanes for which `active` holds
+	auto wave_distinct = [&](bool active, uint32_t a, bool has_b, uint32_t b) -> uint32_t {
+		unsigned long long ma = __ballot(active), mb = __ballot(active && has_b && b != a);
+		uint32_t n = 0;
+		while (ma | mb) {
+			const uint32_t x = ma ? __builtin_amdgcn_readlane(a, __ffsll((long long)ma) - 1) : __builtin_amdgcn_readlane(b, __ffsll((long long)mb) - 1);
+			ma &= ~__ballot(active && a == x);
+			mb &= ~__ballot(active && has_b && b == x);
+			n++;
+		}
+		return n;
+	};
 #else
 #define PROF(i, v) ((void)0)
 #endif
@@ -642,6 +672,9 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 		// (one step always if anybody descends, further steps while at least kStragglers lanes still do)
 		if (__ballot(cur >= 0) != 0ull) do {
 			PROF(2, 1); PROF(3, __popcll(__ballot(cur >= 0)));
+#ifdef POLARIS_PROFILE_LOOPS
+			if (!TINY) PROF(8, wave_distinct(cur >= 0 && !(LDS_TOP && cur < kLdsTopNodes), (uint32_t)cur >> 1, false, 0u)); // 64-byte records, two per line
+#endif
 			if (cur >= 0) {
 				PairNode P;
 				if (TINY || (LDS_TOP && cur < kLdsTopNodes)) { P.lo0 = top[4 * cur]; P.hi0 = top[4 * cur + 1]; P.lo1 = top[4 * cur + 2]; P.hi1 = top[4 * cur + 3]; }
@@ -693,6 +726,12 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 			rcp_dir(d.x, d.y, d.z, inv.x, inv.y, inv.z);
 			pop();
 		}
+#ifdef POLARIS_PROFILE_LOOPS
+		if (!ONE) { // [10] lanes entering an instance [11] distinct instance records those lanes fetch (64 bytes each)
+			const bool enters = cur < 0 && cur >= kFirstLeafRef && (((uint32_t)~cur) & 15u) == 0u && !(((uint32_t)~cur) & kBigLeafFlag);
+			PROF(10, __popcll(__ballot(enters))); PROF(11, wave_distinct(enters, ((uint32_t)~cur) >> 4, false, 0u));
+		}
+#endif
 		if (!ONE && cur < 0 && cur >= kFirstLeafRef && (((uint32_t)~cur) & 15u) == 0u) { // a top-level leaf, or a leaf of more than 15 triangles
 			const uint32_t code = (uint32_t)~cur;
 			if (!(code & kBigLeafFlag)) { // top-level leaf: enter the mesh instance (intersect.cl:239-252); its id is in the reference
@@ -781,6 +820,9 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 				// profiles/r04_tri_variants_ab.txt)
 				do {
 					PROF(4, 1); PROF(5, __popcll(__ballot(i < ntri && !occluded)));
+#ifdef POLARIS_PROFILE_LOOPS
+					if (!TINY) PROF(9, wave_distinct(i < ntri && !occluded, ((first + i) * 48u) >> 7, true, ((first + i) * 48u + 47u) >> 7));
+#endif
 					if (i < ntri && !occluded) {
 						const uint32_t s = first + i;
 						if (TINY && s < B.lds_tris) { // (two explicit paths: one fetch through a selected pointer would be a FLAT load)
@@ -807,7 +849,7 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 		}
 	}
 #ifdef POLARIS_PROFILE_LOOPS
-	if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&stats[ST_DEBUG + (ANY_HIT ? 8 : 0) + i], pc[i]);
+	if (lane == 0) for (int i = 0; i < 16; i++) atomicAdd(&stats[ST_DEBUG + (ANY_HIT ? 16 : 0) + i], pc[i]);
 #endif
 	if (ANY_HIT) {
 		// wave sum -> workgroup sum in LDS -> ONE global atomic per workgroup (contended atomics on a single address run

@@ -78,7 +78,11 @@ struct polaris_hip_tracer {
 	// process may still read frame f's rows while frame f + 1 is traced.  Depth 1 = the reference's single buffer.
 	float4 *ring[POLARIS_IPC_MAX_DEPTH] = {};
 	uint32_t ring_depth = 1, ring_pos = 0;
-	hipEvent_t ev_ipc_done = nullptr; // inter-process event, recorded at the end of every Trace once exported
+	// One inter-process event PER RING SLOT, recorded at the end of the Trace that wrote the slot (once exported).  A slot's event
+	// is re-recorded only when a Trace comes round to the slot again -- which the caller's protocol forbids while a peer may still
+	// read it -- so a peer's wait on slot s's event names exactly the Trace whose rows it is about to read (round 4 had ONE event
+	// re-recorded by every Trace: a primary merging frame f while the peer was already in Trace f + 1 waited for whichever it got).
+	hipEvent_t ev_ipc_done[POLARIS_IPC_MAX_DEPTH] = {};
 	// Events recorded by OTHER handles' merge streams behind their reads of this handle's trace accumulator
 	// (polaris_hip_merge with dst != src): this handle's next Trace waits for them before it clears the rows.
 	struct Reader { hipEvent_t ev; int device; };
@@ -150,6 +154,17 @@ struct polaris_hip_tracer {
 	int opt_hit12 = 1;     // 12-byte hit records inside a Trace (A/B aid: 0 = 16)
 	int opt_o12 = 1;       // 12-byte origins of the closest-hit rays inside a Trace (A/B aid: 0 = 16)
 	int opt_traversal = 1; // 1 = persistent waves with lane refill (k_trace), 0 = one ray per lane (k_intersect/k_occlusion)
+#ifdef POLARIS_EXP_REORDER
+	int opt_reorder = 0, opt_reorder_any = 0;
+	uint32_t opt_reorder_win = 256;
+	float3 exp_lo = {0, 0, 0}, exp_scale = {1, 1, 1};
+	unsigned long long *exp_keys[2] = {nullptr, nullptr};
+	uint32_t *exp_vals[2] = {nullptr, nullptr}, *exp_total = nullptr;
+	void *exp_temp = nullptr;
+	size_t exp_slots = 0, exp_temp_bytes = 0;
+	uint32_t exp_npad = 256;
+	double exp_ms[2] = {0, 0};
+#endif
 
 	// per-kernel timing (option time_kernels)
 	struct Pending { const char *name; hipEvent_t a, b; };
@@ -168,8 +183,59 @@ struct polaris_hip_peer {
 	polaris_hip_tracer *owner = nullptr;
 	uint32_t depth = 0, W = 0, H = 0;
 	void *mem[POLARIS_IPC_MAX_DEPTH] = {};
-	hipEvent_t ev = nullptr; // the peer's "Trace done" event (null: the exporter had none)
+	hipEvent_t ev[POLARIS_IPC_MAX_DEPTH] = {}; // per slot: the peer's "the Trace that wrote this slot is done" event (null: the exporter had none)
 };
+
+#ifdef POLARIS_EXP_REORDER
+// ---- experiment build only (scripts/wave_lines.sh; not compiled into the product library) ----------------------------------------
+// "Would a coherence reorder of the bounce rays pay?"  Between a shade step and the traversal launch that consumes its rays a key
+// is computed per live ray, the (key, slot) pairs are sorted (hipCUB: an experiment, not the product) and k_trace deals its rays
+// in that order (kernels.h, Streams::perm).  Options: reorder = 0 off | 1 identity (control: same waves as today, through the
+// indirection) | 2 direction octant, then Morton code of the origin's cell (10 bits per axis of the scene box) | 3 Morton code, then
+// octant | 4 Morton code alone | 5 16 x 16 pixel tiles of the path's pixel, Z-order inside | 6 direction octant alone;
+// reorder_win = slots per sort window (256 = within a chunk, 1024, 0 = the whole batch).
+#include <hipcub/hipcub.hpp>
+namespace pol {
+__device__ __forceinline__ uint32_t exp_spread3(uint32_t v) { // 10 bits -> every third bit
+	v &= 0x3FFu;
+	v = (v | (v << 16)) & 0x030000FFu; v = (v | (v << 8)) & 0x0300F00Fu; v = (v | (v << 4)) & 0x030C30C3u; v = (v | (v << 2)) & 0x09249249u;
+	return v;
+}
+__global__ void k_exp_keys(Streams st, int any, uint32_t n_slots, int mode, uint32_t win, float3 lo, float3 scale, uint32_t Npad, uint32_t W,
+                           unsigned long long *keys, uint32_t *vals, uint32_t *total) {
+	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+	if (slot >= n_slots) return;
+	const uint32_t chunk = slot >> 8;
+	const uint32_t cnt = (any ? st.cnt_occ : st.cnt_ray)[chunk];
+	if ((slot & 255u) == 0u && cnt) atomicAdd(total, cnt);
+	const bool live = (slot & 255u) < cnt;
+	unsigned long long key = ~0ull;
+	if (live) {
+		const float4 o4 = any ? st.occ_o[slot] : load_ray_o(st, slot), d4 = (any ? st.occ_d : st.ray_d)[slot];
+		const uint32_t oct = (d4.x < 0.0f ? 1u : 0u) | (d4.y < 0.0f ? 2u : 0u) | (d4.z < 0.0f ? 4u : 0u);
+		const uint32_t cx = (uint32_t)fminf(fmaxf((o4.x - lo.x) * scale.x, 0.0f), 1023.0f), cy = (uint32_t)fminf(fmaxf((o4.y - lo.y) * scale.y, 0.0f), 1023.0f),
+		               cz = (uint32_t)fminf(fmaxf((o4.z - lo.z) * scale.z, 0.0f), 1023.0f);
+		const unsigned long long morton = exp_spread3(cx) | (exp_spread3(cy) << 1) | (exp_spread3(cz) << 2);
+		unsigned long long sub = slot;
+		if (mode == 2) sub = ((unsigned long long)oct << 30) | morton;
+		else if (mode == 3) sub = (morton << 3) | oct;
+		else if (mode == 4) sub = morton;
+		else if (mode == 5) {
+			const uint32_t pix = (uint32_t)__float_as_int(d4.w) & 0xFFFFFFu, x = pix % W, y = pix / W; // (closest-hit rays: the path word's low 24 bits are the path index in the block)
+			const uint32_t tile = (y >> 4) * ((W + 15u) >> 4) + (x >> 4);
+			uint32_t z = 0;
+			for (int b = 0; b < 4; b++) z |= ((x >> b & 1u) << (2 * b)) | ((y >> b & 1u) << (2 * b + 1));
+			sub = ((unsigned long long)(slot / Npad) << 32) | ((unsigned long long)tile << 8) | z;
+		} else if (mode == 6) sub = oct;
+		const unsigned long long window = win ? slot / win : 0u;
+		key = mode == 5 ? sub : ((window << 34) | sub);
+		key = (key << 0); // (ties keep slot order: the radix sort is stable)
+	}
+	keys[slot] = key;
+	vals[slot] = slot;
+}
+} // namespace pol
+#endif
 
 namespace {
 
@@ -408,6 +474,41 @@ hipError_t launch_trace(polaris_hip_tracer *h, polaris_hip_tracer::Pipe &P, cons
 	Streams st = st_in;
 	uint32_t o_mask = ~0u;
 	if (camera && !ANY_HIT) { st.ray_o = h->d_cam_o; o_mask = 0u; }
+#ifdef POLARIS_EXP_REORDER
+	st.perm = nullptr; st.perm_n = nullptr;
+	if (h->opt_reorder && !camera && (ANY_HIT ? h->opt_reorder_any != 0 : true) && h->opt_overlap == 1) { // (one batch at a time: the sort buffers are the handle's)
+		const size_t n = (size_t)chunks * WG;
+		if (n > h->exp_slots) {
+			for (int i = 0; i < 2; i++) { if (h->exp_keys[i]) (void)hipFree(h->exp_keys[i]); if (h->exp_vals[i]) (void)hipFree(h->exp_vals[i]); h->exp_keys[i] = nullptr; h->exp_vals[i] = nullptr; }
+			if (h->exp_temp) (void)hipFree(h->exp_temp);
+			h->exp_temp = nullptr;
+			for (int i = 0; i < 2; i++) { if (hipMalloc((void **)&h->exp_keys[i], n * 8) != hipSuccess || hipMalloc((void **)&h->exp_vals[i], n * 4) != hipSuccess) return hipErrorOutOfMemory; }
+			if (!h->exp_total && hipMalloc((void **)&h->exp_total, 4) != hipSuccess) return hipErrorOutOfMemory;
+			size_t tb = 0;
+			(void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, h->exp_keys[0], h->exp_keys[1], h->exp_vals[0], h->exp_vals[1], (int)n, 0, 64, P.q);
+			if (hipMalloc(&h->exp_temp, tb) != hipSuccess) return hipErrorOutOfMemory;
+			h->exp_temp_bytes = tb;
+			h->exp_slots = n;
+		}
+		(void)hipMemsetAsync(h->exp_total, 0, 4, P.q);
+		hipLaunchKernelGGL(k_exp_keys, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, P.q, st, ANY_HIT ? 1 : 0, (uint32_t)n, h->opt_reorder, h->opt_reorder_win, h->exp_lo, h->exp_scale,
+		                   h->exp_npad, h->W, h->exp_keys[0], h->exp_vals[0], h->exp_total);
+		size_t tb = h->exp_temp_bytes;
+		(void)hipcub::DeviceRadixSort::SortPairs(h->exp_temp, tb, h->exp_keys[0], h->exp_keys[1], h->exp_vals[0], h->exp_vals[1], (int)n, 0, 64, P.q);
+		st.perm = h->exp_vals[1]; st.perm_n = h->exp_total;
+	}
+	hipEvent_t ea = nullptr, eb = nullptr;
+	if (h->opt_reorder && getenv("POLARIS_DEBUG")) { (void)hipEventCreate(&ea); (void)hipEventCreate(&eb); (void)hipEventRecord(ea, P.q); }
+	void *args_x[] = {(void *)&st, (void *)&h->bvh, (void *)&chunks, (void *)&acc, (void *)&h->d_stats, (void *)&o_mask};
+	hipError_t rc_x = hipLaunchKernel(fn, dim3(grid), dim3(block), args_x, h->node_mode == kNodesLdsAll ? h->tiny_lds_bytes : 0, P.q);
+	if (ea) { // the launch alone (the "intersect" timer of this build includes the key + sort pass)
+		(void)hipEventRecord(eb, P.q); (void)hipEventSynchronize(eb);
+		float ms = 0; (void)hipEventElapsedTime(&ms, ea, eb);
+		h->exp_ms[ANY_HIT ? 1 : 0] += camera ? 0.0 : ms;
+		(void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
+	}
+	return rc_x;
+#endif
 	void *args[] = {(void *)&st, (void *)&h->bvh, (void *)&chunks, (void *)&acc, (void *)&h->d_stats, (void *)&o_mask};
 	return hipLaunchKernel(fn, dim3(grid), dim3(block), args, h->node_mode == kNodesLdsAll ? h->tiny_lds_bytes : 0, P.q);
 }
@@ -478,6 +579,10 @@ hipError_t launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest 
 	hipStream_t q = P.q;
 	P.st.hit12 = h->opt_hit12 ? 1u : 0u; // (a Trace never reads a hit's distance: kernels.h Streams::hit12)
 	P.st.o12 = h->opt_o12 ? 1u : 0u;     // (... and its closest-hit rays all have the max distance FLT_MAX: Streams::o12)
+#ifdef POLARIS_EXP_REORDER
+	h->exp_npad = Npad;
+	P.st.perm = nullptr; P.st.perm_n = nullptr;
+#endif
 	{
 		Timed t(h, "generate", q);
 		if (h->opt_time_kernels) h->timer_symbol["generate"] = "pol::k_generate";
@@ -687,7 +792,8 @@ void polaris_hip_destroy(polaris_hip_tracer *h) {
 			if (h->pipe[p].q) (void)hipStreamDestroy(h->pipe[p].q);
 		free_pool(h->scene_bufs);
 		free_ring(h);
-		if (h->ev_ipc_done) (void)hipEventDestroy(h->ev_ipc_done);
+		for (auto &e : h->ev_ipc_done)
+			if (e) { (void)hipEventDestroy(e); e = nullptr; }
 		{
 			std::lock_guard<std::mutex> lk_r(h->readers_mu);
 			for (auto &r : h->readers) (void)hipEventDestroy(r.ev);
@@ -767,6 +873,13 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 		err = build_layout(*sc, L, 0);
 	}
 	if (!err.empty()) return fail(h, POLARIS_E_BAD_SCENE, "%s", err.c_str());
+#ifdef POLARIS_EXP_REORDER
+	if (sc->num_bvh_nodes) { // the scene box: node 0 is the root of the top-level tree
+		const PolarisBvhNode &R = sc->bvh_nodes[0];
+		h->exp_lo = make_float3(R.min[0], R.min[1], R.min[2]);
+		h->exp_scale = make_float3(1024.0f / std::max(1e-20f, R.max[0] - R.min[0]), 1024.0f / std::max(1e-20f, R.max[1] - R.min[1]), 1024.0f / std::max(1e-20f, R.max[2] - R.min[2]));
+	}
+#endif
 	HIP_TRY(h, hipSetDevice(h->device));
 	HIP_TRY(h, sync_all(h));
 	free_pool(h->scene_bufs);
@@ -904,6 +1017,11 @@ int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value
 	else if (k == "trace_grid") h->opt_trace_grid = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20));
 	else if (k == "trace_wgs_per_cu") h->opt_trace_wgs_per_cu = (int)std::max<int64_t>(0, std::min<int64_t>(value, 64));
 	else if (k == "tiny_one") h->opt_tiny_one = value != 0; // next upload
+#ifdef POLARIS_EXP_REORDER
+	else if (k == "reorder") h->opt_reorder = (int)value;
+	else if (k == "reorder_any") h->opt_reorder_any = (int)value;
+	else if (k == "reorder_win") h->opt_reorder_win = (uint32_t)value;
+#endif
 	else if (k == "hit12") h->opt_hit12 = value != 0;
 	else if (k == "o12") h->opt_o12 = value != 0;
 	else if (k == "lds_tris") h->opt_lds_tris = (int)std::max<int64_t>(-1, std::min<int64_t>(value, 1 << 20)); // next upload
@@ -937,10 +1055,6 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 	const uint32_t N = (uint32_t)N64, Npad = (N + WG - 1) / WG * WG;
 
 	HIP_TRY(h, hipSetDevice(h->device));
-	if (h->ring_depth > 1) { // the next slot of the ring: a peer may still be reading the previous frame's rows (polaris_hip_ipc_export)
-		h->ring_pos = (h->ring_pos + 1) % h->ring_depth;
-		h->trace_acc = h->ring[h->ring_pos];
-	}
 	const bool exact = h->opt_exact != 0;
 	uint32_t K = 1;
 	if (!exact) {
@@ -994,6 +1108,13 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 	h->cam.texel = make_float2(1.0f / (float)h->W, 1.0f / (float)h->H); // resources.go:130-133
 	const size_t F = (size_t)h->W * h->H;
 	hipStream_t q = h->stream;
+	// The next slot of the ring: a peer may still be reading the previous frame's rows (polaris_hip_ipc_export).  Advanced only
+	// HERE, behind the last step that can fail for want of memory (the batch buffers, the seed list): after a Trace that failed
+	// before it queued anything, trace_slot() / merge_slot / export_block still name the slot of the last frame that was traced.
+	if (h->ring_depth > 1) {
+		h->ring_pos = (h->ring_pos + 1) % h->ring_depth;
+		h->trace_acc = h->ring[h->ring_pos];
+	}
 	HIP_TRY(h, hipEventRecord(h->ev_start, q));
 	if (r->accumulated_samples == 0) { // pipeline Reset stage (tracer.go:208-213): the frame accumulator lives on the merge stream
 		{
@@ -1030,7 +1151,7 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 	HIP_TRY(h, hipGetLastError());
 	unsigned long long hs[ST_COUNT];
 	HIP_TRY(h, hipMemcpyAsync(hs, h->d_stats, sizeof hs, hipMemcpyDeviceToHost, q));
-	if (h->ev_ipc_done) HIP_TRY(h, hipEventRecord(h->ev_ipc_done, q)); // what a peer process's merge stream waits for (polaris_hip_merge_ipc)
+	if (h->ev_ipc_done[h->ring_pos]) HIP_TRY(h, hipEventRecord(h->ev_ipc_done[h->ring_pos], q)); // what a peer process's merge of THIS slot waits for (polaris_hip_merge_ipc)
 	HIP_TRY(h, hipEventRecord(h->ev_stop, q));
 	HIP_TRY(h, hipStreamSynchronize(q));
 	drain.armed = false; // the join above made q wait for every pipeline
@@ -1038,12 +1159,23 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 #ifdef POLARIS_PROFILE_LOOPS
 	if (getenv("POLARIS_DEBUG")) { // kernels.h, PROF
 		for (int a = 0; a < 2; a++) {
-			const unsigned long long *c = hs + ST_DEBUG + 8 * a;
+			const unsigned long long *c = hs + ST_DEBUG + 16 * a;
 			fprintf(stderr, "[polaris] %s: %llu rays; per ray: %.2f outer iterations, %.2f node steps, %.2f triangle rounds | live lanes: outer %.1f, node step %.1f, triangle round %.1f | "
 			        "wave-level: %llu outer, %llu node, %llu triangle, %llu refills (%.1f rays each)\n", a ? "any hit" : "closest hit", c[7],
 			        (double)c[1] / std::max(1ull, c[7]), (double)c[3] / std::max(1ull, c[7]), (double)c[5] / std::max(1ull, c[7]),
 			        (double)c[1] / std::max(1ull, c[0]), (double)c[3] / std::max(1ull, c[2]), (double)c[5] / std::max(1ull, c[4]), c[0], c[2], c[4], c[6], (double)c[7] / std::max(1ull, c[6]));
+			// distinct 128-byte lines (global-memory node / triangle records only; camera rays included in the closest-hit row)
+			fprintf(stderr, "[polaris] %s lines: per wave-level node step %.2f distinct lines for %.1f live lanes; per triangle round %.2f for %.1f; per ray %.2f node lines + %.2f triangle lines; "
+			        "instance entries per ray %.2f, distinct instance records per entering lane %.2f\n", a ? "any hit" : "closest hit",
+			        (double)c[8] / std::max(1ull, c[2]), (double)c[3] / std::max(1ull, c[2]), (double)c[9] / std::max(1ull, c[4]), (double)c[5] / std::max(1ull, c[4]),
+			        (double)c[8] / std::max(1ull, c[7]), (double)c[9] / std::max(1ull, c[7]), (double)c[10] / std::max(1ull, c[7]), (double)c[11] / std::max(1ull, c[10]));
 		}
+	}
+#endif
+#ifdef POLARIS_EXP_REORDER
+	if (getenv("POLARIS_DEBUG")) {
+		fprintf(stderr, "[polaris] reorder %d window %u (any hit too: %d): k_trace launches of the bounce rays alone %.3f ms closest hit, %.3f ms any hit\n", h->opt_reorder, h->opt_reorder_win, h->opt_reorder_any, h->exp_ms[0], h->exp_ms[1]);
+		h->exp_ms[0] = h->exp_ms[1] = 0;
 	}
 #endif
 	for (uint32_t b = 0; b < POLARIS_MAX_BOUNCES; b++) {
@@ -1118,7 +1250,7 @@ static int merge_rows(polaris_hip_tracer *dst, polaris_hip_tracer *src, polaris_
 	const size_t off = (size_t)r->block_y * dst->W, n = (size_t)r->block_h * dst->W;
 	const float4 *rows = src_acc + off;
 	hipStream_t q = dst->merge_stream;
-	if (peer && peer->ev && hipStreamWaitEvent(q, peer->ev, 0) != hipSuccess) return fail_merge(POLARIS_E_DEVICE, "merge_ipc: waiting for the peer's Trace event failed");
+	if (peer && peer->ev[slot] && hipStreamWaitEvent(q, peer->ev[slot], 0) != hipSuccess) return fail_merge(POLARIS_E_DEVICE, "merge_ipc: waiting for the peer's Trace event of the slot failed");
 	if (!peer && src_device != dst->device) {
 		int can = 0;
 		if (hipDeviceCanAccessPeer(&can, dst->device, src_device) != hipSuccess) return fail_merge(POLARIS_E_DEVICE, "merge: hipDeviceCanAccessPeer failed");
@@ -1147,8 +1279,10 @@ static int merge_rows(polaris_hip_tracer *dst, polaris_hip_tracer *src, polaris_
 	}
 	if (hipGetLastError() != hipSuccess) return fail_merge(POLARIS_E_DEVICE, "merge: kernel launch failed");
 	// src's next Trace clears and rewrites the rows just queued for reading: it waits (on the device) for this event.  With
-	// src == dst the merge stream itself is joined by Trace (join_merges).
-	if (src && src != dst && slot < 0) {
+	// src == dst the merge stream itself is joined by Trace (join_merges).  Recorded for a merge from a named ring slot too
+	// (merge_slot): with a ring of depth 1 that slot IS what the next Trace clears, and with a deeper ring the wait is for a
+	// kernel of microseconds.
+	if (src && src != dst) {
 		hipEvent_t e = reader_event(src, dst->device);
 		if (!e || hipEventRecord(e, q) != hipSuccess) { // cannot fence on the device: finish the read now
 			(void)hipGetLastError();
@@ -1219,24 +1353,30 @@ int polaris_hip_ipc_export(polaris_hip_tracer *h, uint32_t depth, PolarisIpcExpo
 		HIP_TRY(h, hipIpcGetMemHandle(&mh, h->ring[i]));
 		memcpy(out->mem[i], &mh, 64);
 	}
-	// the "Trace done" event: optional (a runtime that cannot export events still has the host-side ordering: Trace is synchronous)
-	if (!h->ev_ipc_done) {
-		hipEvent_t e = nullptr;
-		if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventInterprocess) == hipSuccess) h->ev_ipc_done = e;
-		else (void)hipGetLastError();
-	}
-	if (h->ev_ipc_done) {
-		hipIpcEventHandle_t eh;
-		if (hipEventRecord(h->ev_ipc_done, h->stream) == hipSuccess && hipStreamSynchronize(h->stream) == hipSuccess &&
-		    hipIpcGetEventHandle(&eh, h->ev_ipc_done) == hipSuccess) {
-			memcpy(out->event, &eh, 64);
-			out->has_event = 1;
-		} else {
-			(void)hipGetLastError();
-			(void)hipEventDestroy(h->ev_ipc_done);
-			h->ev_ipc_done = nullptr;
+	// the per-slot "Trace done" events: optional (a runtime that cannot export events still has the host-side ordering: Trace is
+	// synchronous, and a slot is only announced after the Trace that wrote it has returned).  All slots or none.
+	bool events = true;
+	for (uint32_t i = 0; i < POLARIS_IPC_MAX_DEPTH; i++) {
+		if (i >= depth) {
+			if (h->ev_ipc_done[i]) { (void)hipEventDestroy(h->ev_ipc_done[i]); h->ev_ipc_done[i] = nullptr; }
+			continue;
 		}
+		if (!h->ev_ipc_done[i]) {
+			hipEvent_t e = nullptr;
+			if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventInterprocess) == hipSuccess) h->ev_ipc_done[i] = e;
+			else { (void)hipGetLastError(); events = false; break; }
+		}
+		hipIpcEventHandle_t eh;
+		if (hipEventRecord(h->ev_ipc_done[i], h->stream) == hipSuccess && hipStreamSynchronize(h->stream) == hipSuccess &&
+		    hipIpcGetEventHandle(&eh, h->ev_ipc_done[i]) == hipSuccess) memcpy(out->event[i], &eh, 64);
+		else { (void)hipGetLastError(); events = false; break; }
 	}
+	if (!events) {
+		for (auto &e : h->ev_ipc_done)
+			if (e) { (void)hipEventDestroy(e); e = nullptr; }
+		memset(out->event, 0, sizeof out->event);
+	}
+	out->has_event = events ? 1 : 0;
 	return POLARIS_OK;
 }
 
@@ -1255,7 +1395,8 @@ int polaris_hip_ipc_open(polaris_hip_tracer *dst, const PolarisIpcExport *x, pol
 	auto undo = [&]() {
 		for (uint32_t i = 0; i < POLARIS_IPC_MAX_DEPTH; i++)
 			if (p->mem[i]) (void)hipIpcCloseMemHandle(p->mem[i]);
-		if (p->ev) (void)hipEventDestroy(p->ev);
+		for (auto &e : p->ev)
+			if (e) (void)hipEventDestroy(e);
 		delete p;
 		(void)hipGetLastError();
 	};
@@ -1269,10 +1410,17 @@ int polaris_hip_ipc_open(polaris_hip_tracer *dst, const PolarisIpcExport *x, pol
 			return fail(dst, POLARIS_E_UNSUPPORTED, "ipc_open: hipIpcOpenMemHandle (slot %u, peer pid %u device %d): %s", i, x->pid, x->device, hipGetErrorString(e));
 		}
 	}
-	if (x->has_event) { // optional: without it the host message that follows the peer's synchronous Trace is the only ordering
-		hipIpcEventHandle_t eh;
-		memcpy(&eh, x->event, 64);
-		if (hipIpcOpenEventHandle(&p->ev, eh) != hipSuccess) { p->ev = nullptr; (void)hipGetLastError(); }
+	if (x->has_event) { // optional: without them the host message that follows the peer's synchronous Trace is the only ordering
+		for (uint32_t i = 0; i < x->depth; i++) {
+			hipIpcEventHandle_t eh;
+			memcpy(&eh, x->event[i], 64);
+			if (hipIpcOpenEventHandle(&p->ev[i], eh) != hipSuccess) { // all or none
+				(void)hipGetLastError();
+				p->ev[i] = nullptr;
+				for (uint32_t j = 0; j < i; j++) { (void)hipEventDestroy(p->ev[j]); p->ev[j] = nullptr; }
+				break;
+			}
+		}
 	}
 	*out = p;
 	return POLARIS_OK;
@@ -1286,7 +1434,8 @@ int polaris_hip_ipc_close(polaris_hip_tracer *dst, polaris_hip_peer *p) {
 	(void)hipStreamSynchronize(dst->merge_stream); // a merge may still be reading the mapping
 	for (uint32_t i = 0; i < POLARIS_IPC_MAX_DEPTH; i++)
 		if (p->mem[i]) (void)hipIpcCloseMemHandle(p->mem[i]);
-	if (p->ev) (void)hipEventDestroy(p->ev);
+	for (auto &e : p->ev)
+		if (e) (void)hipEventDestroy(e);
 	(void)hipGetLastError();
 	delete p;
 	return POLARIS_OK;

@@ -98,11 +98,11 @@ class IpcExport(C.Structure):
     _fields_ = [
         ("abi_version", C.c_uint32), ("depth", C.c_uint32), ("frame_w", C.c_uint32), ("frame_h", C.c_uint32),
         ("device", C.c_int32), ("pid", C.c_uint32), ("has_event", C.c_uint32), ("reserved", C.c_uint32),
-        ("mem", (C.c_uint8 * 64) * IPC_MAX_DEPTH), ("event", C.c_uint8 * 64),
+        ("mem", (C.c_uint8 * 64) * IPC_MAX_DEPTH), ("event", (C.c_uint8 * 64) * IPC_MAX_DEPTH),
     ]
 
 
-assert C.sizeof(IpcExport) == 32 + 64 * IPC_MAX_DEPTH + 64
+assert C.sizeof(IpcExport) == 32 + 64 * IPC_MAX_DEPTH + 64 * IPC_MAX_DEPTH
 
 
 class BvhBuildInput(C.Structure):

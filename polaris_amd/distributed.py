@@ -35,6 +35,17 @@ def naive_rows(n_tracers: int, frame_h: int, speeds=None) -> list[int]:
     return rows
 
 
+def fit_rows(rows: list[int], frame_h: int) -> list[int]:
+    """The reference's perfect scheduler gives every tracer at least one row AFTER it has floored the shares
+    (scheduler.go:70-76), so with very unequal speeds the blocks can add up to MORE than the frame (it only tops up when they
+    add up to less); the reference's last block then runs off the frame.  Every rank applies the same fix to the same numbers:
+    rows are taken back from the tallest blocks, one at a time.  A no-op for every assignment that fits."""
+    rows = [int(v) for v in rows]
+    while sum(rows) > frame_h and max(rows) > 1:
+        rows[max(range(len(rows)), key=lambda i: (rows[i], -i))] -= 1
+    return rows
+
+
 def block_of(rank: int, rows: list[int]) -> tuple[int, int]:
     """(block_y, block_h) of tracer `rank`: running sum, renderer/default.go:127-136."""
     return sum(rows[:rank]), rows[rank]
@@ -169,7 +180,7 @@ class SchedulerFeedback:
             work, out, _ = self._pending.pop(0)
             work.wait()
             got = out.cpu().tolist() if not isinstance(out, list) else [o.tolist() for o in out]  # (.cpu() orders itself behind the collective on the current stream)
-            self.rows = self._sched.schedule(self.H, block_h=[g[0] for g in got], render_ns=[max(1, g[1]) for g in got])
+            self.rows = fit_rows(self._sched.schedule(self.H, block_h=[g[0] for g in got], render_ns=[max(1, g[1]) for g in got]), self.H)
         return self.rows
 
     def drain(self):
@@ -226,13 +237,20 @@ class PeerExchange:
         self.opened = False
 
     def setup(self) -> bool:
-        """Exchange the rings' IPC blobs (once); the primary maps every peer.  Returns True on every rank iff every mapping
-        opened -- otherwise nothing stays open and the caller falls back to StripExchange (in this process, no re-launch)."""
-        blob = self.port.export(self.depth)
-        blobs = [None] * self.world
-        self.dist.all_gather_object(blobs, blob, group=self.group)
-        ok, why = True, ""
-        if self.rank == self.primary:
+        """Exchange the rings' IPC blobs (once); the primary maps every peer.  Returns True on every rank iff every ring was
+        exported AND every mapping opened -- otherwise nothing stays open and the caller falls back to StripExchange (in this
+        process, no re-launch).  A rank whose export fails (hipIpcGetMemHandle refused, no memory for the ring's extra slots)
+        still takes part in the collective -- it gathers None plus the error text -- so nobody is left waiting in it."""
+        try:
+            mine = (self.port.export(self.depth), "")
+        except Exception as e:
+            mine = (None, f"rank {self.rank}: export failed: {e}")
+        got = [None] * self.world
+        self.dist.all_gather_object(got, mine, group=self.group)
+        blobs = [g[0] for g in got]
+        failed = [g[1] for g in got if g[0] is None]
+        ok, why = not failed, "; ".join(failed)
+        if ok and self.rank == self.primary:
             try:
                 for r in range(self.world):
                     if r != self.primary:
@@ -274,8 +292,9 @@ class PeerExchange:
             out[0].copy_(mine)
         return (f, work, out, list(rows))
 
-    def finish(self, ticket):
-        """Complete frame f's message; the primary merges the frame: every block read where it lies."""
+    def wait(self, ticket):
+        """Complete frame f's message (blocks until the SLOWEST rank has posted frame f: not this rank's work) and feed the
+        block scheduler.  Returns what merge() needs."""
         f, work, out, rows = ticket
         if work is not None:
             work.wait()
@@ -284,9 +303,18 @@ class PeerExchange:
         assert [g[2] for g in got] == rows, f"ranks disagree about the rows of frame {f}: {got} vs {rows}"
         self._finished = f
         if self._sched is not None:
-            self.rows = self._sched.schedule(self.H, block_h=[g[2] for g in got], render_ns=[g[3] for g in got])
+            self.rows = fit_rows(self._sched.schedule(self.H, block_h=[g[2] for g in got], render_ns=[g[3] for g in got]), self.H)
+        return got, rows
+
+    def merge(self, got, rows) -> float:
+        """The primary merges the frame: every block read where it lies (Reset stage, one merge per block, tone-map).  Returns
+        the seconds this took -- the primary's own work on top of its Trace, the part of finish() a caller may bill to the
+        rank's render time (the wait for the other ranks' messages is not); 0.0 on the other ranks."""
         if self.rank != self.primary:
-            return
+            return 0.0
+        import time
+
+        t = time.perf_counter()
         self.port.begin_frame()
         y = 0
         for r in range(self.world):
@@ -296,6 +324,11 @@ class PeerExchange:
                 self.port.merge_peer(self._peers[r], got[r][1], y, rows[r])
             y += rows[r]
         self.port.end_frame()
+        return time.perf_counter() - t
+
+    def finish(self, ticket) -> float:
+        """wait() + merge(); returns merge()'s seconds."""
+        return self.merge(*self.wait(ticket))
 
     def close(self):
         for p in self._peers.values():

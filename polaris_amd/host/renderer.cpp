@@ -108,6 +108,22 @@ Error DefaultRenderer::renderFrame(uint32_t accumulatedSamples) {
 	for (auto &t : tracers_) raw.push_back(t.get());
 	blockAssignments_ = scheduler_->Schedule(raw, blockReq.frame_h);
 	{
+		// scheduler.go:70-76 gives every tracer at least one row AFTER flooring the shares and only tops up when the blocks add up
+		// to LESS than the frame: with very unequal speeds they add up to more ([7, 1, 1, 1] for 8 rows) and the reference's last
+		// block runs off the frame.  The frame loop takes rows back from the tallest blocks (same rule as
+		// polaris_amd/distributed.py::fit_rows); a no-op for every assignment that fits, so scheduler.cpp stays the reference's arithmetic.
+		uint64_t sum = 0;
+		for (uint32_t h : blockAssignments_) sum += h;
+		while (sum > blockReq.frame_h) {
+			size_t tallest = 0;
+			for (size_t i = 1; i < blockAssignments_.size(); i++)
+				if (blockAssignments_[i] > blockAssignments_[tallest]) tallest = i;
+			if (blockAssignments_[tallest] <= 1) break;
+			blockAssignments_[tallest]--;
+			sum--;
+		}
+	}
+	{
 		std::lock_guard<std::mutex> lk(frameMu_);
 		frame_++;
 		frameResets_ = accumulatedSamples == 0;

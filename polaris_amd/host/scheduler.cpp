@@ -1,6 +1,6 @@
 // scheduler.cpp -- tracer/scheduler.go restated.  The arithmetic (float64 scaling, truncation,
 // "at least one row", remainder to tracer 0) is kept operation for operation; the known answers
-// of tracer/scheduler_test.go:16-20,48-55 are pinned in tests/test_host_scheduler.py.
+// of tracer/scheduler_test.go:16-20,48-55 are pinned in tests/test_host_layer.py (test_scheduler_known_answers).
 #include <cmath>
 
 #include "tracer.hpp"

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol(built):
     for name in declared:
         assert hasattr(lib, name), f"libpolaris_hip.so does not export {name}"
     assert sorted(T.C_ABI_SYMBOLS) == declared, "ctypes_api.C_ABI_SYMBOLS is out of sync with polaris_hip.h"
-    assert lib.polaris_hip_abi_version() == 3
+    assert lib.polaris_hip_abi_version() == 4
 
 
 def test_struct_sizes_match_header(built):
@@ -29,7 +29,7 @@ def test_struct_sizes_match_header(built):
     assert C.sizeof(T.TraceStats) == 7 * 8 + 2 * 32 * 8 + 8
     assert T.BVH_NODE.itemsize == 32 and T.MESH_INSTANCE.itemsize == 80
     assert T.MATERIAL_NODE.itemsize == 64 and T.EMISSIVE.itemsize == 80 and T.TEXTURE_META.itemsize == 16
-    assert C.sizeof(T.IpcExport) == 352             # 8 x 4 + 4 x 64 (hipIpcMemHandle_t) + 64 (hipIpcEventHandle_t)
+    assert C.sizeof(T.IpcExport) == 544             # 8 x 4 + 4 x 64 (hipIpcMemHandle_t per slot) + 4 x 64 (hipIpcEventHandle_t per slot)
 
 
 def test_no_device_is_an_error_not_a_crash(built):

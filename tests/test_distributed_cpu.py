@@ -121,6 +121,20 @@ def test_naive_rows_is_the_reference_schedule():
     assert naive_rows(8, 512) == [64] * 8 and naive_rows(8, 1080) == [135] * 8 and naive_rows(2, 97) == [49, 48]
 
 
+def test_fit_rows_repairs_an_over_assigned_frame(built):
+    """scheduler.go:70-76 clamps every share to one row AFTER flooring and only tops up a frame that is short: very unequal
+    speeds over-assign it.  fit_rows takes rows back from the tallest blocks and leaves every assignment that fits alone."""
+    from polaris_amd import host_api
+    from polaris_amd.distributed import fit_rows
+
+    s = host_api.Scheduler(host_api.PERFECT, [1] * 4)
+    s.schedule(8)
+    over = s.schedule(8, block_h=[2, 2, 2, 2], render_ns=[1, 1000, 1000, 1000])
+    assert over == [7, 1, 1, 1]                      # the reference's arithmetic: 10 rows for an 8-row frame
+    assert fit_rows(over, 8) == [5, 1, 1, 1]
+    assert fit_rows([16, 15], 31) == [16, 15] and fit_rows([3, 3, 3], 8) == [2, 3, 3] and fit_rows([1, 1, 1], 2) == [1, 1, 1]
+
+
 # ---- PeerExchange: the default exchange of bench.py (peer reads through IPC mappings) ---------------------------------------
 class ShmPort:
     """PeerExchange's tracer side without a GPU: the ring is `depth` shared-memory segments (the role of the IPC-mapped trace
@@ -186,7 +200,7 @@ class ShmPort:
                 seg.unlink()
 
 
-def _peer_worker(rank, world, port, out_path, scheduler, slow_rank):
+def _peer_worker(rank, world, port, out_path, scheduler, slow_rank, H=H, fail_export_on=-1):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import time
@@ -200,10 +214,23 @@ def _peer_worker(rank, world, port, out_path, scheduler, slow_rank):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sc = scenes.SCENES["cornell-diffuse"](W / H)
     shm = ShmPort(rank, W, H)
+    if rank == fail_export_on:
+        def refuse(depth):
+            raise RuntimeError("hipIpcGetMemHandle: refused (test)")
+        shm.export = refuse
     px = PeerExchange(dist, rank, world, W, H, shm, scheduler=scheduler)
-    assert px.setup()
+    opened = px.setup()
+    if fail_export_on >= 0:  # every rank must learn of the failure (nobody hangs in the collective) and nothing stays open
+        assert not opened and f"rank {fail_export_on}: export failed" in px.why_not and not px._peers, (opened, px.why_not)
+        if rank == 0:
+            np.save(out_path, np.zeros(1))
+        dist.barrier()
+        shm.release(unlink=True)
+        dist.destroy_process_group()
+        return
+    assert opened
     orc = ob.Oracle("oracle")
-    pending, all_rows = [], []
+    pending, all_rows, merge_s = [], [], []
     for f in range(FRAMES + 2):
         rows = px.next_rows()
         all_rows.append(list(rows))
@@ -211,12 +238,17 @@ def _peer_worker(rank, world, port, out_path, scheduler, slow_rank):
         acc, _, _ = orc.trace(sc, ob.make_request(W, H, spp=SPP, bounces=B, block_y=by, block_h=bh), scenes.make_seeds(SPP, B, base=100 + f))
         shm.trace(acc, by, bh)
         if rank == slow_rank:
-            time.sleep(0.15)   # the other rank runs ahead as far as the protocol lets it
+            time.sleep(0.15)   # the other ranks run ahead as far as the protocol lets them
         while pending:
-            px.finish(pending.pop(0))
+            merge_s.append(px.finish(pending.pop(0)))
+        # made-up times: rank 1 takes three times as long per row.  (bench.py bills a rank its Trace + the seconds finish()
+        # RETURNS -- the primary's merges -- never the wait for the slowest rank inside finish().)
         pending.append(px.post(rows, (3.0 if rank == 1 else 1.0) * bh))
     while pending:
-        px.finish(pending.pop(0))
+        merge_s.append(px.finish(pending.pop(0)))
+    # the held-back rank costs everybody 0.15 s per frame in wait(); what finish() returns -- numpy adds of a 40-pixel-wide
+    # frame on the primary, nothing elsewhere -- must not contain it
+    assert all(t == 0.0 for t in merge_s) if rank != 0 else max(merge_s) < 0.1, merge_s
     if rank == 0:
         np.save(out_path, np.stack(shm.frames))
         np.save(out_path + ".rows.npy", np.array(all_rows))
@@ -228,6 +260,35 @@ def _peer_worker(rank, world, port, out_path, scheduler, slow_rank):
     dist.destroy_process_group()
 
 
+def _check_peer_frames(out, world, H, scheduler):
+    from oracle import pybind as ob
+    from polaris_amd import scenes
+    from polaris_amd.distributed import block_of, naive_rows
+
+    frames = np.load(out)
+    all_rows = np.load(out + ".rows.npy").tolist()
+    n = FRAMES + 2
+    assert frames.shape == (n, H, W, 4) and np.isfinite(frames).all()
+    first = naive_rows(world, H)
+    assert all_rows[0] == first and all_rows[1] == first   # frame f + 1 is scheduled from frame f - 1
+    if scheduler == "naive":
+        assert all(r == first for r in all_rows)
+    else:  # rank 1 reported three times the time per row: it ends up with about a third of an equal share (scheduler.go:50-80)
+        assert all(len(r) == world and sum(r) == H and min(r) >= 1 for r in all_rows), all_rows
+        assert all_rows[2][1] < first[1] and all_rows[-1][1] <= max(1, (first[1] * 3) // 5), all_rows
+    sc = scenes.SCENES["cornell-diffuse"](W / H)
+    orc = ob.Oracle("oracle")
+    for f in range(n):
+        seeds = scenes.make_seeds(SPP, B, base=100 + f)
+        expect = np.zeros((H, W, 3), np.float32)
+        for r in range(world):
+            by, bh = block_of(r, all_rows[f])
+            a, _, _ = orc.trace(sc, ob.make_request(W, H, spp=SPP, bounces=B, block_y=by, block_h=bh), seeds)
+            expect[by:by + bh] = a[by:by + bh, :, :3]
+        assert np.array_equal(frames[f][..., :3].view(np.uint32), expect.view(np.uint32)), f
+    return all_rows
+
+
 @pytest.mark.parametrize("scheduler,slow_rank", [("naive", 0), ("naive", 1), ("perfect", 0)])
 def test_two_rank_peer_read_exchange(built, tmp_path, scheduler, slow_rank):
     """Two processes, the primary reads the other's rows out of a shared ring one frame behind the tracing -- with one rank held
@@ -235,31 +296,38 @@ def test_two_rank_peer_read_exchange(built, tmp_path, scheduler, slow_rank):
     put NaNs or another frame's rows into the assembled frame).  Every frame == the per-block oracle, bit for bit."""
     import torch.multiprocessing as mp
 
-    from oracle import pybind as ob
-    from polaris_amd import scenes
-    from polaris_amd.distributed import block_of
-
     out = str(tmp_path / "frames.npy")
     mp.spawn(_peer_worker, args=(2, _free_port(), out, scheduler, slow_rank), nprocs=2, join=True)
-    frames = np.load(out)
-    all_rows = np.load(out + ".rows.npy").tolist()
-    n = FRAMES + 2
-    assert frames.shape == (n, H, W, 4) and np.isfinite(frames).all()
-    assert all_rows[0] == [16, 15] and all_rows[1] == [16, 15]   # frame f + 1 is scheduled from frame f - 1
-    if scheduler == "naive":
-        assert all(r == [16, 15] for r in all_rows)
-    else:
-        assert all(sum(r) == H and min(r) >= 1 for r in all_rows) and all_rows[2][1] < 12 and all_rows[-1][1] <= 9, all_rows
-    sc = scenes.SCENES["cornell-diffuse"](W / H)
-    orc = ob.Oracle("oracle")
-    for f in range(n):
-        seeds = scenes.make_seeds(SPP, B, base=100 + f)
-        expect = np.zeros((H, W, 3), np.float32)
-        for r in range(2):
-            by, bh = block_of(r, all_rows[f])
-            a, _, _ = orc.trace(sc, ob.make_request(W, H, spp=SPP, bounces=B, block_y=by, block_h=bh), seeds)
-            expect[by:by + bh] = a[by:by + bh, :, :3]
-        assert np.array_equal(frames[f][..., :3].view(np.uint32), expect.view(np.uint32)), f
+    all_rows = _check_peer_frames(out, 2, H, scheduler)
+    assert all_rows[0] == [16, 15]
+
+
+@pytest.mark.parametrize("world,height,scheduler,slow_rank", [(8, 61, "naive", 3), (8, 64, "perfect", 0), (4, 31, "perfect", 3)])
+def test_four_and_eight_rank_peer_read_exchange(built, tmp_path, world, height, scheduler, slow_rank):
+    """What the driver's SCALE run launches at N = 4 and N = 8, without a GPU: eight (four) processes, seven (three) peer rings
+    mapped by the primary, eight merges per frame, the all_gather_object of eight blobs, the block scheduler over eight
+    (rows, ns) pairs (renderer/default.go:127-136,188-191; tracer/scheduler.go:50-106) -- a frame height the ranks do not
+    divide (61 rows -> [12, 7, 7, 7, 7, 7, 7, 7]: the remainder goes to tracer 0, scheduler.go:98-104) and one they do, one
+    rank in the MIDDLE held back so that seven peers run ahead of it as far as the ring's depth-3 argument allows.  Every
+    assembled frame == the per-block oracle bit for bit."""
+    import torch.multiprocessing as mp
+
+    out = str(tmp_path / "frames.npy")
+    mp.spawn(_peer_worker, args=(world, _free_port(), out, scheduler, slow_rank, height), nprocs=world, join=True)
+    all_rows = _check_peer_frames(out, world, height, scheduler)
+    if (world, height) == (8, 61):
+        assert all_rows[0] == [12, 7, 7, 7, 7, 7, 7, 7]
+
+
+def test_a_failed_export_on_one_rank_reaches_every_rank(built, tmp_path):
+    """PeerExchange.setup() with the LAST rank's export raising (hipIpcGetMemHandle refused, no memory for the extra ring slots):
+    that rank still takes part in the collective, every rank gets verdict False with the reason, nothing stays mapped -- the
+    caller (bench.py) then falls back to the strip transfers on every rank together."""
+    import torch.multiprocessing as mp
+
+    out = str(tmp_path / "none.npy")
+    mp.spawn(_peer_worker, args=(3, _free_port(), out, "naive", -1, H, 2), nprocs=3, join=True)
+    assert os.path.exists(out)
 
 
 def test_peer_exchange_refuses_a_ring_that_is_too_short():

@@ -225,6 +225,226 @@ def test_bench_two_ranks_with_a_different_frame_every_step(built, tmp_path):
     assert np.array_equal(frame[..., :3].view(np.uint32), expect.view(np.uint32))
 
 
+def _frame_matches_the_oracle_block_by_block(acc_path, W, H, spp, B, rows, seeds):
+    import numpy as np
+
+    from oracle import pybind as ob
+    from polaris_amd import scenes
+
+    frame = np.load(acc_path)
+    assert frame.shape == (H, W, 4) and sum(rows) == H and min(rows) >= 1
+    sc = scenes.SCENES["cornell"](W / H)
+    orc = ob.Oracle("oracle")
+    expect = np.zeros((H, W, 3), np.float32)
+    y = rays = 0
+    for bh in rows:
+        a, st, _ = orc.trace(sc, ob.make_request(W, H, spp=spp, bounces=B, rr=3, block_y=y, block_h=bh), seeds)
+        expect[y:y + bh] = a[y:y + bh, :, :3]
+        y += bh
+        rays += st.total_rays()
+    assert np.array_equal(frame[..., :3].view(np.uint32), expect.view(np.uint32))
+    return rays
+
+
+def test_bench_four_ranks_bare_launch_headline_blocks_one_rank_held_back(built, tmp_path):
+    """`python bench.py --gpus 4`, the first command a multi-GPU node runs (here: four PROCESSES sharing the one GPU -- the box
+    admits six -- through the real HIP-IPC path: three peer rings mapped by rank 0, twelve memory and twelve event handles, four
+    merges per frame).  64 rows per rank, the block an 8-GPU headline frame gives a rank; a different seed list every frame;
+    rank 3 sleeps 60 ms after every Trace so that the three others run as far ahead of it as the ring's depth-3 argument lets
+    them (renderer/default.go:127-136,188-191).  The frame rank 0 assembled last == the per-block oracle of the last frame's
+    seeds, bit for bit; the same run then times the perfect scheduler (tracer/scheduler.go:50-80) over four (rows, ns) pairs."""
+    from polaris_amd import scenes
+
+    acc = str(tmp_path / "frame.npy")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    W, H, spp, B, steps, warmup = 128, 256, 4, 5, 4, 1
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--width", str(W), "--height", str(H), "--spp", str(spp), "--steps", str(steps),
+           "--warmup", str(warmup), "--same-device", "--no-cpu-baseline", "--no-kernel-timers", "--opt", "exact_accumulate=1", "--save-accumulator", acc,
+           "--test-seeds", "--test-delay-rank", "3:60"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 4 and d["config"]["ranks"] == 4 and d["config"]["exchange"].startswith("hip-ipc"), d["config"]["exchange"]
+    assert d["config"]["rows_last_frame"] == [64, 64, 64, 64] and d["config"]["scheduler"] == "naive"
+    ps = d["config"]["perfect_scheduler"]
+    assert ps["scheduler"] == "perfect" and ps["value"] > 0 and sum(ps["rows_last_frame"]) == H and min(ps["rows_last_frame"]) >= 1
+    # the rank that is held back reports the longest frames: the perfect scheduler must have taken rows AWAY from it, and rank 0's
+    # block must not have withered (round 4 billed the primary the wait for the slowest rank: ADVICE r4)
+    assert ps["rows_last_frame"][3] < 64 and ps["rows_last_frame"][0] >= 32, ps
+    _frame_matches_the_oracle_block_by_block(acc, W, H, spp, B, [64] * 4, scenes.make_seeds(spp, B, base=0xC0FFEE + steps + warmup - 1))
+
+
+def test_bench_four_ranks_under_the_drivers_launcher_c4_blocks_perfect_scheduler(built, tmp_path):
+    """The driver's launch line (`python -m torch.distributed.run --nproc-per-node 4 ... bench.py --gpus 4`) on a C4-shaped
+    frame: 541 rows -> [136, 135, 135, 135] (135 rows = a rank's block of the 1080-row frame on 8 GPUs; the odd row goes to
+    tracer 0, scheduler.go:98-104), `--scheduler perfect`: the rows change from frame to frame with the ranks' measured times
+    and every rank must arrive at the same ones.  Last frame == per-block oracle for whatever rows it ended on."""
+    from polaris_amd import scenes
+
+    acc = str(tmp_path / "frame.npy")
+    W, H, spp, B, steps, warmup = 96, 541, 2, 5, 4, 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--width", str(W), "--height", str(H), "--spp", str(spp),
+           "--steps", str(steps), "--warmup", str(warmup), "--same-device", "--no-cpu-baseline", "--no-kernel-timers", "--no-second-scheduler",
+           "--scheduler", "perfect", "--opt", "exact_accumulate=1", "--save-accumulator", acc, "--test-seeds"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 4 and d["config"]["exchange"].startswith("hip-ipc"), d["config"]["exchange"]
+    assert d["config"]["rows_first_timed_frame"] is not None and d["config"]["scheduler"] == "perfect"
+    rows = d["config"]["rows_last_frame"]
+    rays = _frame_matches_the_oracle_block_by_block(acc, W, H, spp, B, rows, scenes.make_seeds(spp, B, base=0xC0FFEE + steps + warmup - 1))
+    assert rays > 0
+
+
+def test_bench_three_ranks_fall_back_together_when_an_export_fails(built, tmp_path):
+    """`--test-ipc-failure export`: the LAST rank's polaris_hip_ipc_export raises.  PeerExchange.setup() must not leave the
+    others hanging in its collective: every rank learns of it and all switch to the strip transfers together (here over gloo)."""
+    from polaris_amd import scenes
+
+    acc = str(tmp_path / "frame.npy")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    W, H, spp, B = 128, 97, 8, 5
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", *SMALL, "--test-ipc-failure", "export", "--backend", "gloo", "--same-device",
+           "--no-cpu-baseline", "--no-kernel-timers", "--no-second-scheduler", "--opt", "exact_accumulate=1", "--save-accumulator", acc]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "falling back to strip transfers" in out.stderr and "rank 2: export failed" in out.stderr
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 3 and d["config"]["exchange"].startswith("fallback after a failed IPC mapping") and "gloo point-to-point" in d["config"]["exchange"]
+    _frame_matches_the_oracle_block_by_block(acc, W, H, spp, B, [33, 32, 32], scenes.make_seeds(spp, B))
+
+
+def _ring_owner(conn, ranks, W, H, spp, B, frames, rows):
+    """Child process of test_primary_maps_seven_peer_rings: owns the tracers of `ranks`, exports their rings, traces every
+    frame's blocks and names the slots.  Before Trace f it waits for the primary's "merged f - 3" (the frame that lived in the
+    slot Trace f overwrites) -- the rule PeerExchange's depth-3 argument guarantees."""
+    sys.path.insert(0, ROOT)
+    from conftest import make_hip_tracer
+    from oracle import pybind as ob
+    from polaris_amd import scenes
+    from polaris_amd.distributed import block_of
+
+    try:
+        sc = scenes.SCENES["cornell"](W / H)
+        trs = {r: make_hip_tracer(sc, W, H, exact_accumulate=1) for r in ranks}
+        conn.send({r: trs[r].ipc_export(3) for r in ranks})
+        merged = -1
+        for f in range(frames):
+            while merged < f - 3:
+                merged = conn.recv()
+            slots = {}
+            for r in ranks:
+                by, bh = block_of(r, rows)
+                trs[r].Trace(ob.make_request(W, H, spp=spp, bounces=B, block_y=by, block_h=bh), scenes.make_seeds(spp, B, base=500 + f))
+                slots[r] = trs[r].trace_slot()
+            conn.send((f, slots))
+        while merged < frames - 1:      # the rings stay mapped until the primary has read the last frame and closed its mappings
+            merged = conn.recv()
+        assert conn.recv() == "closed"
+        for t in trs.values():
+            t.Close()
+        conn.send("bye")
+    except Exception as e:  # noqa: BLE001 -- report instead of leaving the parent in recv()
+        conn.send(("error", repr(e)))
+
+
+def test_primary_maps_seven_peer_rings(built, oracle):
+    """An 8-rank frame's worth of IPC on the one GPU of the box, which admits six processes: the primary (this process) maps the
+    rings of SEVEN tracers living in three other processes (3 + 2 + 2) -- 21 hipIpcOpenMemHandle mappings and 21 inter-process
+    events, one per ring slot -- and assembles every frame from eight blocks (61 rows -> [12, 7, 7, 7, 7, 7, 7, 7]), one frame
+    behind the tracing, a different seed list every frame, the owners running ahead as far as the ring allows.  Every frame ==
+    the per-block oracle bit for bit.  (renderer/default.go:127-136,188-191; what bench.py --gpus 8 does with one tracer per
+    process.)"""
+    import multiprocessing as mp
+
+    import numpy as np
+
+    from conftest import bits, make_hip_tracer
+    from oracle import pybind as ob
+    from polaris_amd import scenes
+    from polaris_amd.distributed import block_of, naive_rows
+
+    W, H, spp, B, frames = 64, 61, 2, 4, 6
+    rows = naive_rows(8, H)
+    assert rows == [12, 7, 7, 7, 7, 7, 7, 7]
+    ctx = mp.get_context("spawn")
+    groups = [(1, 2, 3), (4, 5), (6, 7)]
+    conns, procs = [], []
+    for g in groups:
+        a, b = ctx.Pipe()
+        p = ctx.Process(target=_ring_owner, args=(b, g, W, H, spp, B, frames, rows), daemon=True)
+        p.start()
+        conns.append(a)
+        procs.append(p)
+
+    def recv(c):
+        assert c.poll(300), "a ring owner went silent"
+        m = c.recv()
+        assert not (isinstance(m, tuple) and m[0] == "error"), m
+        return m
+
+    sc = scenes.SCENES["cornell"](W / H)
+    prim = make_hip_tracer(sc, W, H, exact_accumulate=1)
+    peers = {}
+    try:
+        prim.ipc_export(3)
+        for c in conns:
+            for r, blob in recv(c).items():
+                peers[r] = prim.ipc_open(blob)
+        assert sorted(peers) == [1, 2, 3, 4, 5, 6, 7]
+        full = ob.make_request(W, H, spp=spp, bounces=B)
+        own_slots = {}
+
+        def merge(f):
+            slots = {0: own_slots[f]}
+            for c in conns:
+                ff, s = recv(c)
+                assert ff == f
+                slots.update(s)
+            prim.reset_frame()
+            for r in range(8):
+                by, bh = block_of(r, rows)
+                req = ob.make_request(W, H, spp=spp, bounces=B, block_y=by, block_h=bh)
+                if r == 0:
+                    prim.merge_slot(prim, slots[0], req)
+                else:
+                    prim.merge_ipc(peers[r], slots[r], req)
+            prim.SyncFramebuffer(full)
+            got = prim.read_accumulator(1)[..., :3]
+            seeds = scenes.make_seeds(spp, B, base=500 + f)
+            expect = np.zeros((H, W, 3), np.float32)
+            for r in range(8):
+                by, bh = block_of(r, rows)
+                a = oracle.trace(sc, ob.make_request(W, H, spp=spp, bounces=B, block_y=by, block_h=bh), seeds)[0]
+                expect[by:by + bh] = a[by:by + bh, :, :3]
+            assert np.array_equal(bits(got), bits(expect)), f
+            for c in conns:
+                c.send(f)
+
+        for f in range(frames):
+            by, bh = block_of(0, rows)
+            prim.Trace(ob.make_request(W, H, spp=spp, bounces=B, block_y=by, block_h=bh), scenes.make_seeds(spp, B, base=500 + f))
+            own_slots[f] = prim.trace_slot()
+            if f >= 1:
+                merge(f - 1)          # one frame behind the tracing, like PeerExchange
+        merge(frames - 1)
+        for r in list(peers):
+            prim.ipc_close(peers.pop(r))
+        for c in conns:
+            c.send("closed")
+        for c in conns:
+            assert recv(c) == "bye"
+    finally:
+        for r in list(peers):
+            prim.ipc_close(peers.pop(r))
+        prim.Close()
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+
+
 @pytest.mark.parametrize("scheduler", ["naive", "perfect"])
 def test_bench_inproc_three_tracers_on_one_gpu(built, tmp_path, scheduler):
     """`bench.py --gpus 3 --inproc --devices 0,0,0`: ONE process, the C++ frame loop (worker thread per tracer), the blocks
