@@ -98,12 +98,13 @@ def kernel_algorithmic_bytes(st, shade_counts, B: int, packet_camera: bool):
 def committed_counters(symbol: str, workload_is_headline: bool):
     """PMC data cannot be collected inside this run (rocprofv3 --pmc passes: scripts/traffic.sh, scripts/pmc.sh); they are read
     from the newest committed profile of the headline workload, keyed by kernel symbol.  Returns (hbm bytes per launch,
-    lane utilisation, description of the source) -- None where there is no committed number for this symbol."""
+    lane utilisation, wave-level VALU instructions per launch, description of the source) -- None where there is no committed
+    number for this symbol."""
     if not workload_is_headline:
-        return None, None, None
+        return None, None, None, None
     import glob
 
-    traffic = lane_util = None
+    traffic = lane_util = valu = None
     src = []
     for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
         ent = json.load(open(tpath)).get("kernels", {}).get(symbol)
@@ -115,9 +116,31 @@ def committed_counters(symbol: str, workload_is_headline: bool):
         ent = json.load(open(spath)).get("kernels", {}).get(symbol)
         if ent and "lane_util" in ent:
             lane_util = ent["lane_util"]
-            src.append("profiles/" + os.path.basename(spath) + " (SQ_THREAD_CYCLES_VALU / 64 / SQ_ACTIVE_INST_VALU)")
+            if ent.get("launches") and ent.get("SQ_INSTS_VALU"):
+                valu = ent["SQ_INSTS_VALU"] / ent["launches"]
+            src.append("profiles/" + os.path.basename(spath) + " (SQ_INSTS_VALU; SQ_THREAD_CYCLES_VALU / 64 / SQ_ACTIVE_INST_VALU)")
             break
-    return traffic, lane_util, ("; ".join(src) + "; collected on the builder's MI355X lease, not re-measured in this run") if src else None
+    return traffic, lane_util, valu, ("; ".join(src) + "; collected on the builder's MI355X lease, not re-measured in this run") if src else None
+
+
+# The roof these kernels are actually under: vector-instruction ISSUE.  tests/tools/valu_rate.hip measures 0.86-0.93 ns
+# per wave64 VALU instruction per SIMD with 2-8 waves resident (plain v_mul_f32 / v_fma_f32; a packed f32 instruction takes two
+# slots): the chip issues at most CUs x 4 SIMDs / 0.9 ns wave-level vector instructions per second.
+VALU_NS_PER_INST_PER_SIMD = 0.9
+
+
+def issue_roofline(valu_per_launch, launches, ms_per_frame, lane_util, cus: int):
+    """`roofline_issue` of one kernel symbol: wave-level VALU instructions per second (committed SQ_INSTS_VALU per launch x this
+    run's launches / this run's HIP-event time) against the chip's issue rate, and the same weighted by the live lanes per
+    instruction -- the fraction of the vector ALUs' lane-slots doing useful work."""
+    if not valu_per_launch or not launches or ms_per_frame <= 0:
+        return None
+    peak = cus * 4 / (VALU_NS_PER_INST_PER_SIMD * 1e-9) / 1e9     # G wave-instructions / s
+    ach = valu_per_launch * launches / (ms_per_frame * 1e-3) / 1e9
+    return {"bound": "valu-issue", "achieved": ach, "peak": peak, "unit": "G wave64 VALU instructions/s", "frac": ach / peak,
+            "frac_useful_lanes": (ach / peak * lane_util) if lane_util else None, "valu_instructions_per_launch": valu_per_launch,
+            "peak_from": f"{cus} CUs x 4 SIMDs / {VALU_NS_PER_INST_PER_SIMD} ns per wave64 VALU instruction per SIMD (tests/tools/valu_rate.hip: 0.86-0.93 ns with 2-8 waves resident)",
+            "instructions_from": "committed SQ_INSTS_VALU of the same kernel symbol on the same workload (profiles/r*_sq_counters.json); time: this run's HIP events"}
 
 
 def host_cpu() -> str:
@@ -553,7 +576,7 @@ def main() -> None:
                 # credited with bytes its streams do not move (`frac_reference` = the SURVEY price, for comparison across rounds)
                 alg = min(alg_ref[k], alg_lay[k])
                 ach = alg / (kms * 1e-3) / 1e9
-                traffic, lane_util, source = committed_counters(symbols[k], headline)
+                traffic, lane_util, valu, source = committed_counters(symbols[k], headline)
                 per_kernel[symbols[k]] = {"bound": "hbm", "kernel": symbols[k], "timer": k, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                           "frac": ach / HBM_PEAK_GBS, "priced_by": "layout" if alg_lay[k] < alg_ref[k] else "reference",
                                           "frac_reference": alg_ref[k] / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_layout": alg_lay[k] / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -561,10 +584,12 @@ def main() -> None:
                                           "algorithmic_bytes_per_launch": alg / kn_, "algorithmic_bytes_reference": alg_ref[k] / kn_,
                                           "algorithmic_bytes_layout": alg_lay[k] / kn_, "traffic_over_algorithmic": (traffic / (alg / kn_)) if traffic else None,
                                           "avg_launch_ms": kms / kn_, "launches": kn_, "ms_per_frame": kms,
-                                          "measured": "HIP events, one extra frame with overlap=1 after the timed region"}
+                                          "measured": "HIP events, one extra frame with overlap=1 after the timed region",
+                                          "roofline_issue": issue_roofline(valu, kn_, kms, lane_util, tr.device_cus)}
             if per_kernel:
                 dom = max(per_kernel.values(), key=lambda e: e["ms_per_frame"])
                 out["roofline"] = dict(dom)
+                out["roofline_issue"] = dom.get("roofline_issue")   # the roof the dominant kernel is actually under; `roofline` (HBM) stays the headline object
             out["roofline_per_kernel"] = per_kernel
             shade_ms = sum(iso[k][0] for k in SHADE_TIMERS)
             out["kernels_isolated_ms_per_frame"] = {**{k: round(v[0], 3) for k, v in iso.items() if k not in ("aggregate", "tonemap")}, "shade": round(shade_ms, 3)}

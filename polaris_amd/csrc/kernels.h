@@ -497,6 +497,11 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 	constexpr uint32_t kRow = BLOCK * sizeof(StackEntry);
 	__shared__ uint32_t wg_cursor;
 	if (threadIdx.x == 0) wg_cursor = 0;
+#ifdef POLARIS_PROFILE_PROLOGUE
+	// timing build (profiles/r05_small_block_prologue.txt): s_memrealtime (100 MHz) at the start of a workgroup, after the staging
+	// barrier and at its end -- summed per launch class into ST_DEBUG + 12..14 (closest hit) / + 28..30 (any hit)
+	const unsigned long long pp_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
 	__shared__ float4 top_static[LDS_TOP ? kLdsTopNodes * 4 : 1];
 	float4 *const top = TINY ? reinterpret_cast<float4 *>(tiny_lds) : top_static;
 	float *const ltri = TINY ? reinterpret_cast<float *>(tiny_lds + (size_t)B.num_pairs * sizeof(PairNode)) : nullptr; // 9 floats per slot, slots [0, B.lds_tris)
@@ -515,6 +520,9 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 		}
 	}
 	__syncthreads();
+#ifdef POLARIS_PROFILE_PROLOGUE
+	const unsigned long long pp_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
 	// (tiny mode: a lane's stack pointer is its offset in the dynamic block itself -- the block's address is a link-time constant,
 	// so it folds into the instruction's offset field and no access pays an add for the stack's run-time position)
 	char *const stk_bytes = TINY ? tiny_lds : reinterpret_cast<char *>(&stk[0][0]);
@@ -850,6 +858,14 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 	}
 #ifdef POLARIS_PROFILE_LOOPS
 	if (lane == 0) for (int i = 0; i < 16; i++) atomicAdd(&stats[ST_DEBUG + (ANY_HIT ? 16 : 0) + i], pc[i]);
+#endif
+#ifdef POLARIS_PROFILE_PROLOGUE
+	if (threadIdx.x == 0) {
+		const unsigned long long pp_t2 = __builtin_amdgcn_s_memrealtime();
+		atomicAdd(&stats[ST_DEBUG + (ANY_HIT ? 16 : 0) + 12], pp_t1 - pp_t0);
+		atomicAdd(&stats[ST_DEBUG + (ANY_HIT ? 16 : 0) + 13], pp_t2 - pp_t0);
+		atomicAdd(&stats[ST_DEBUG + (ANY_HIT ? 16 : 0) + 14], 1ull);
+	}
 #endif
 	if (ANY_HIT) {
 		// wave sum -> workgroup sum in LDS -> ONE global atomic per workgroup (contended atomics on a single address run
@@ -1267,11 +1283,20 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(POLARIS_SHAD
 	// HBM -- taking the count's scalar round trip out of it, as here, measured +-0.)
 	const size_t base = (size_t)blockIdx.x * WG;
 	const size_t my = base + tid;
-	float4 d4 = st.ray_d[my], t4 = FIRST ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : st.thr[my], h4 = load_hit(st, my); // (camera rays carry no throughput: it is 1)
+#ifndef POLARIS_SHADE_LOAD
+#define POLARIS_SHADE_LOAD 0
+#endif
+	// POLARIS_SHADE_LOAD (A/B, profiles/r05_shade_dead_slots_ab.txt): 0 = every lane requests its slot at once, live or not;
+	// 1 = only live slots are requested (after the chunk's count has arrived: one scalar round trip in front of the ray loads);
+	// 2 = slots 0..127 at once (a chunk's rays sit at its front, so these are nearly always live), slots 128..255 only if live.
+	float4 d4 = make_float4(0, 0, 0, 0), t4 = make_float4(1.0f, 1.0f, 1.0f, 0.0f), h4 = make_float4(0, 0, 0, 0);
+	const bool early = FIRST || POLARIS_SHADE_LOAD == 0 || (POLARIS_SHADE_LOAD == 2 && tid < 128);
+	if (early) { d4 = st.ray_d[my]; if (!FIRST) t4 = st.thr[my]; h4 = load_hit(st, my); } // (camera rays carry no throughput: it is 1)
 	// (the sample's seed and the chunk's position in the reference's buffer: requested with everything else, used by shade_ray)
 	const uint32_t s = blockIdx.x / (A.Npad / WG);
 	const uint32_t seed = A.seeds[(size_t)(A.first_sample + s) * A.seed_stride + 1 + A.bounce], pfx0 = st.pfx[blockIdx.x];
 	const uint32_t cnt = st.cnt_ray[blockIdx.x];
+	if (!early && tid < cnt) { d4 = st.ray_d[my]; t4 = st.thr[my]; h4 = load_hit(st, my); }
 	if (cnt == 0) { // uniform exit: nothing live in this workgroup
 		if (tid == 0) { st.cnt_occ[blockIdx.x] = 0; st.wg_stat[blockIdx.x] = 0; } // (no rays come out of it: its emit mask will not be read)
 		return;

@@ -155,7 +155,7 @@ struct polaris_hip_tracer {
 	int opt_o12 = 1;       // 12-byte origins of the closest-hit rays inside a Trace (A/B aid: 0 = 16)
 	int opt_traversal = 1; // 1 = persistent waves with lane refill (k_trace), 0 = one ray per lane (k_intersect/k_occlusion)
 #ifdef POLARIS_EXP_REORDER
-	int opt_reorder = 0, opt_reorder_any = 0;
+	int opt_reorder = 0, opt_reorder_any = 0, opt_reorder_bits = 30;
 	uint32_t opt_reorder_win = 256;
 	float3 exp_lo = {0, 0, 0}, exp_scale = {1, 1, 1};
 	unsigned long long *exp_keys[2] = {nullptr, nullptr};
@@ -201,7 +201,7 @@ __device__ __forceinline__ uint32_t exp_spread3(uint32_t v) { // 10 bits -> ever
 	v = (v | (v << 16)) & 0x030000FFu; v = (v | (v << 8)) & 0x0300F00Fu; v = (v | (v << 4)) & 0x030C30C3u; v = (v | (v << 2)) & 0x09249249u;
 	return v;
 }
-__global__ void k_exp_keys(Streams st, int any, uint32_t n_slots, int mode, uint32_t win, float3 lo, float3 scale, uint32_t Npad, uint32_t W,
+__global__ void k_exp_keys(Streams st, int any, uint32_t n_slots, int mode, uint32_t win, int bits, float3 lo, float3 scale, uint32_t Npad, uint32_t W,
                            unsigned long long *keys, uint32_t *vals, uint32_t *total) {
 	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
 	if (slot >= n_slots) return;
@@ -209,7 +209,7 @@ __global__ void k_exp_keys(Streams st, int any, uint32_t n_slots, int mode, uint
 	const uint32_t cnt = (any ? st.cnt_occ : st.cnt_ray)[chunk];
 	if ((slot & 255u) == 0u && cnt) atomicAdd(total, cnt);
 	const bool live = (slot & 255u) < cnt;
-	unsigned long long key = ~0ull;
+	unsigned long long key = (win == 0 && mode == 3) ? (1ull << (bits + 3)) : ~0ull; // dead slots sort behind every ray
 	if (live) {
 		const float4 o4 = any ? st.occ_o[slot] : load_ray_o(st, slot), d4 = (any ? st.occ_d : st.ray_d)[slot];
 		const uint32_t oct = (d4.x < 0.0f ? 1u : 0u) | (d4.y < 0.0f ? 2u : 0u) | (d4.z < 0.0f ? 4u : 0u);
@@ -218,7 +218,7 @@ __global__ void k_exp_keys(Streams st, int any, uint32_t n_slots, int mode, uint
 		const unsigned long long morton = exp_spread3(cx) | (exp_spread3(cy) << 1) | (exp_spread3(cz) << 2);
 		unsigned long long sub = slot;
 		if (mode == 2) sub = ((unsigned long long)oct << 30) | morton;
-		else if (mode == 3) sub = (morton << 3) | oct;
+		else if (mode == 3) sub = ((morton >> (30 - bits)) << 3) | oct; // (bits < 30: a coarse binning, rays of a bin stay in slot order)
 		else if (mode == 4) sub = morton;
 		else if (mode == 5) {
 			const uint32_t pix = (uint32_t)__float_as_int(d4.w) & 0xFFFFFFu, x = pix % W, y = pix / W; // (closest-hit rays: the path word's low 24 bits are the path index in the block)
@@ -491,14 +491,15 @@ hipError_t launch_trace(polaris_hip_tracer *h, polaris_hip_tracer::Pipe &P, cons
 			h->exp_slots = n;
 		}
 		(void)hipMemsetAsync(h->exp_total, 0, 4, P.q);
-		hipLaunchKernelGGL(k_exp_keys, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, P.q, st, ANY_HIT ? 1 : 0, (uint32_t)n, h->opt_reorder, h->opt_reorder_win, h->exp_lo, h->exp_scale,
+		hipLaunchKernelGGL(k_exp_keys, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, P.q, st, ANY_HIT ? 1 : 0, (uint32_t)n, h->opt_reorder, h->opt_reorder_win, h->opt_reorder_bits, h->exp_lo, h->exp_scale,
 		                   h->exp_npad, h->W, h->exp_keys[0], h->exp_vals[0], h->exp_total);
 		size_t tb = h->exp_temp_bytes;
-		(void)hipcub::DeviceRadixSort::SortPairs(h->exp_temp, tb, h->exp_keys[0], h->exp_keys[1], h->exp_vals[0], h->exp_vals[1], (int)n, 0, 64, P.q);
+		const int end_bit = (h->opt_reorder_win == 0 && h->opt_reorder == 3) ? h->opt_reorder_bits + 4 : 64; // (coarse bins: fewer radix passes)
+		(void)hipcub::DeviceRadixSort::SortPairs(h->exp_temp, tb, h->exp_keys[0], h->exp_keys[1], h->exp_vals[0], h->exp_vals[1], (int)n, 0, end_bit, P.q);
 		st.perm = h->exp_vals[1]; st.perm_n = h->exp_total;
 	}
 	hipEvent_t ea = nullptr, eb = nullptr;
-	if (h->opt_reorder && getenv("POLARIS_DEBUG")) { (void)hipEventCreate(&ea); (void)hipEventCreate(&eb); (void)hipEventRecord(ea, P.q); }
+	if (getenv("POLARIS_DEBUG")) { (void)hipEventCreate(&ea); (void)hipEventCreate(&eb); (void)hipEventRecord(ea, P.q); }
 	void *args_x[] = {(void *)&st, (void *)&h->bvh, (void *)&chunks, (void *)&acc, (void *)&h->d_stats, (void *)&o_mask};
 	hipError_t rc_x = hipLaunchKernel(fn, dim3(grid), dim3(block), args_x, h->node_mode == kNodesLdsAll ? h->tiny_lds_bytes : 0, P.q);
 	if (ea) { // the launch alone (the "intersect" timer of this build includes the key + sort pass)
@@ -1021,6 +1022,7 @@ int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value
 	else if (k == "reorder") h->opt_reorder = (int)value;
 	else if (k == "reorder_any") h->opt_reorder_any = (int)value;
 	else if (k == "reorder_win") h->opt_reorder_win = (uint32_t)value;
+	else if (k == "reorder_bits") h->opt_reorder_bits = (int)std::max<int64_t>(3, std::min<int64_t>(value, 30)) / 3 * 3;
 #endif
 	else if (k == "hit12") h->opt_hit12 = value != 0;
 	else if (k == "o12") h->opt_o12 = value != 0;
@@ -1169,6 +1171,15 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 			        "instance entries per ray %.2f, distinct instance records per entering lane %.2f\n", a ? "any hit" : "closest hit",
 			        (double)c[8] / std::max(1ull, c[2]), (double)c[3] / std::max(1ull, c[2]), (double)c[9] / std::max(1ull, c[4]), (double)c[5] / std::max(1ull, c[4]),
 			        (double)c[8] / std::max(1ull, c[7]), (double)c[9] / std::max(1ull, c[7]), (double)c[10] / std::max(1ull, c[7]), (double)c[11] / std::max(1ull, c[10]));
+		}
+	}
+#endif
+#ifdef POLARIS_PROFILE_PROLOGUE
+	if (getenv("POLARIS_DEBUG")) { // kernels.h: s_memrealtime ticks (100 MHz) summed over the workgroups of every k_trace launch of this Trace
+		for (int a = 0; a < 2; a++) {
+			const unsigned long long *c = hs + ST_DEBUG + 16 * a + 12;
+			fprintf(stderr, "[polaris] %s prologue: %llu workgroups; staging (tree + triangle records into LDS, to the barrier) %.2f us per workgroup of %.2f us lifetime = %.1f %%\n",
+			        a ? "any hit" : "closest hit", c[2], (double)c[0] / std::max(1ull, c[2]) / 100.0, (double)c[1] / std::max(1ull, c[2]) / 100.0, 100.0 * (double)c[0] / std::max(1ull, c[1]));
 		}
 	}
 #endif

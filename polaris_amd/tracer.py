@@ -88,6 +88,7 @@ class HipTracer:
         self._check(self._lib.polaris_hip_device_info(self._device, name, C.byref(cus), C.byref(mhz), C.byref(mem)), None)
         self._name = name.value.decode()
         self._speed = int(cus.value * mhz.value // 1000)
+        self.device_cus = int(cus.value)   # compute units of the device (bench.py: the issue roofline's peak)
         self._check(self._lib.polaris_hip_create(self._device, C.byref(self._h)), None)
 
     def Close(self) -> None:
