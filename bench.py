@@ -227,8 +227,8 @@ def main() -> None:
     ap.add_argument("--bounces", type=int, default=5)
     ap.add_argument("--rr", type=int, default=3)
     ap.add_argument("--samples-per-batch", type=int, default=0)
-    ap.add_argument("--bvh", default="scene", choices=("scene", "device"), help="`device`: the scene's two-level BVH is rebuilt on the GPU before the upload "
-                    "(polaris_hip_build_bvh: an LBVH; an alternative producer, not the headline's tree)")
+    ap.add_argument("--bvh", default="scene", choices=("scene", "device", "device-lbvh"), help="`device`: the scene's two-level BVH is rebuilt on the GPU before the upload "
+                    "(polaris_hip_build_bvh: binned SAH, level by level; `device-lbvh`: its linear-BVH algorithm -- an alternative producer, not the headline's tree)")
     ap.add_argument("--bvh-max-leaf", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
@@ -313,11 +313,11 @@ def main() -> None:
     W, H, spp, B = args.width, args.height, args.spp, args.bounces
     sc = scenes.SCENES[args.scene](W / H)
     bvh_info = None
-    if args.bvh == "device":
+    if args.bvh != "scene":
         from polaris_amd import bvh_build
 
         t_b = time.perf_counter()
-        sc, bvh_info = bvh_build.rebuild_on_device(sc, max_leaf_tris=args.bvh_max_leaf, device=local_rank)
+        sc, bvh_info = bvh_build.rebuild_on_device(sc, max_leaf_tris=args.bvh_max_leaf, device=local_rank, algorithm="lbvh" if args.bvh == "device-lbvh" else "sah")
         bvh_info["wall_ms_with_permutation"] = (time.perf_counter() - t_b) * 1e3
     seeds = scenes.make_seeds(spp, B)
     rows = naive_rows(world, H)                      # tracer/scheduler.go:83-106, equal speeds

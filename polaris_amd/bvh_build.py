@@ -47,8 +47,9 @@ def mesh_ranges_and_instance_boxes(scene):
     return first.astype(np.uint32), count.astype(np.uint32), boxes, inst_mesh
 
 
-def rebuild_on_device(scene, max_leaf_tris: int = 4, device: int = 0):
-    """Returns (scene with the BVH built by polaris_hip_build_bvh, {"device_ms": .., "num_nodes": ..})."""
+def rebuild_on_device(scene, max_leaf_tris: int = 4, device: int = 0, algorithm: str = "sah"):
+    """Returns (scene with the BVH built by polaris_hip_build_bvh, {"device_ms": .., "num_nodes": ..}).  algorithm: "sah" (binned
+    surface-area heuristic, level by level: the default) or "lbvh" (linear BVH: faster to build, slower to trace)."""
     lib = T.load_library()
     first, count, boxes, inst_mesh = mesh_ranges_and_instance_boxes(scene)
     nt, ni = len(scene.material_index), len(scene.mesh_instances)
@@ -58,6 +59,7 @@ def rebuild_on_device(scene, max_leaf_tris: int = 4, device: int = 0):
     inp.mesh_first_tri, inp.mesh_num_tris, inp.num_meshes = first.ctypes.data, count.ctypes.data, len(first)
     inp.instance_boxes, inp.instance_mesh, inp.num_instances = boxes.ctypes.data, inst_mesh.ctypes.data, ni
     inp.max_leaf_tris = max_leaf_tris
+    inp.algorithm = {"sah": T.BVH_SAH, "lbvh": T.BVH_LBVH}[algorithm]
     cap = 2 * (nt + ni)
     nodes = np.zeros(cap, T.BVH_NODE)
     order = np.zeros(nt, np.uint32)
@@ -80,4 +82,4 @@ def rebuild_on_device(scene, max_leaf_tris: int = 4, device: int = 0):
                               vertices=np.ascontiguousarray(scene.vertices[v3]), normals=np.ascontiguousarray(scene.normals[v3]),
                               uvs=np.ascontiguousarray(scene.uvs[v3]), material_index=np.ascontiguousarray(scene.material_index[o]),
                               name=scene.name + "-gpubvh")
-    return out, {"device_ms": ms.value, "num_nodes": int(n_nodes.value)}
+    return out, {"device_ms": ms.value, "num_nodes": int(n_nodes.value), "algorithm": algorithm}

@@ -3,21 +3,34 @@
 // The reference's builder (asset/compiler/bvh/bvh_builder.go:100-308) scores ~1024 / (depth + 1) candidate planes per axis with
 // one goroutine each, every one an O(n) pass over the node's items: fine for a few thousand triangles, minutes for a million.
 // polaris_amd/host/scene_compiler.cpp restates it for the CPU.  This file is an ALTERNATIVE producer for the same arrays
-// (PolarisBvhNode in the reference's encoding, optimized_scene.go:14-64) shaped for the GPU: a linear BVH (Morton order of the
-// centroids on a grid whose cells stay near-cubic, one radix sort, the hierarchy of Karras 2012 built for all inner nodes at
-// once, boxes fitted bottom-up), with subtrees of up to max_leaf_tris items collapsed into the reference's kind of leaf (first
-// item, count).  (Round 4 also built PLOC -- bottom-up clustering of mutual nearest neighbours, Meister & Bittner 2018 -- on the
-// same infrastructure: better on the Cornell box (14.5 vs 16.7 ms per frame), level elsewhere, and too DEEP for the 32-entry
-// traversal stack on the 58 K-triangle ball; removed again, profiles/r04_bvh_build_lbvh_vs_ploc.json.)  One tree per mesh
-// over its triangles, one over the instances' world boxes (one instance per leaf, compiler.go:88-103).
+// (PolarisBvhNode in the reference's encoding, optimized_scene.go:14-64) shaped for the GPU, with two algorithms:
 //
-// It cannot reproduce the reference's tree (a different algorithm, and the reference breaks equal-score ties by goroutine
-// arrival), and need not: the traversal is correct for ANY tree whose boxes contain their items, and parity is
-// defined on the uploaded arrays.  What is checked instead (tests/test_gpu_bvh_build.py): the tree is valid under
-// scene_layout.h's rules, every item sits in exactly one leaf, every box contains what is below it, and the HIP trace of a scene
-// on the tree built here equals the CPU oracle's trace of the same arrays bit for bit.
+//   POLARIS_BVH_SAH (the default, round 5): a surface-area-heuristic tree built LEVEL BY LEVEL -- every node of a level is split at
+//   once: centroid bounds and 16 bins per axis by atomics (aggregated per wave / per workgroup in LDS while a node still spans
+//   whole workgroups), the cheapest of the 3 x 15 planes per node, a STABLE partition of the item array by one prefix sum over the
+//   whole level.  The same criterion as polaris_amd/scenes.py's CPU producer (and, plane count aside, as bvh_builder.go:162-211),
+//   so the trees trace like the CPU-built ones; no sort anywhere; leaves of <= max_leaf_tris items, so the upload-time leaf
+//   subdivision (scene_layout.h) finds nothing left to do; depth is O(log n) whatever the geometry (a node whose centroids no
+//   plane separates is halved by position), so a mesh that packs thousands of triangles into one cell of a Morton grid -- which
+//   the linear builder turns into a chain deeper than the traversal stack -- builds like any other.
+//
+//   POLARIS_BVH_LBVH (round 4): a linear BVH (Morton order of the centroids on a grid whose cells stay near-cubic, one radix sort,
+//   the hierarchy of Karras 2012 for all inner nodes at once, boxes fitted bottom-up, subtrees of up to max_leaf_tris items
+//   collapsed into leaves).  2-4 x faster to build, 28-44 % slower to trace (profiles/r04_bvh_build.json): for trees that must
+//   exist in a fraction of a frame.  (Round 4 also built PLOC -- Meister & Bittner 2018 -- on the same infrastructure: better on
+//   the Cornell box, level elsewhere, too DEEP for the 32-entry traversal stack on the 58 K-triangle ball; removed again,
+//   profiles/r04_bvh_build_lbvh_vs_ploc.json.)
+//
+// One tree per mesh over its triangles, one over the instances' world boxes (one instance per leaf, compiler.go:88-103).  The
+// two library primitives used -- an exclusive prefix sum, and the radix sort of the linear builder -- are rocPRIM's (ROCm's own
+// primitives, called directly: no CUB layer).
+//
+// Neither algorithm can reproduce the reference's tree (the reference breaks equal-score ties by goroutine arrival, SURVEY.md
+// 5.2), and need not: the traversal is correct for ANY tree whose boxes contain their items, and parity is defined on the
+// uploaded arrays.  What is checked instead (tests/test_gpu_bvh_build.py): the tree is valid under
+// scene_layout.h's rules, every item sits in exactly one leaf, every box contains what is below it, two builds are byte-identical,
+// and the HIP trace of a scene on the tree built here equals the CPU oracle's trace of the same arrays bit for bit.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <chrono>
@@ -25,6 +38,8 @@
 #include <cstring>
 #include <string>
 #include <vector>
+
+#include <rocprim/rocprim.hpp> // (after <cstring>: its texture iterator calls memset unqualified)
 
 #include "polaris_hip.h"
 
@@ -294,7 +309,7 @@ int build_tree(Scratch &S, hipStream_t q, uint32_t n, uint32_t max_leaf, uint32_
 	hipLaunchKernelGGL(k_box_bounds, dim3(grid(n)), dim3(BT), 0, q, S.boxes, n, S.bounds);
 	hipLaunchKernelGGL(k_morton, dim3(grid(n)), dim3(BT), 0, q, S.boxes, n, S.bounds, S.keys_alt);
 	size_t tb = S.temp_bytes;
-	BUILD_TRY(hipcub::DeviceRadixSort::SortKeys(S.temp, tb, S.keys_alt, S.keys, (int)n, 0, 62, q));
+	BUILD_TRY(rocprim::radix_sort_keys(S.temp, tb, S.keys_alt, S.keys, (size_t)n, 0u, 62u, q));
 	const bool single = n <= max_leaf || n < 2;
 	if (d_order) hipLaunchKernelGGL(k_order, dim3(grid(n)), dim3(BT), 0, q, S.keys, n, item_base, d_order);
 	if (single) {
@@ -309,7 +324,7 @@ int build_tree(Scratch &S, hipStream_t q, uint32_t n, uint32_t max_leaf, uint32_
 	hipLaunchKernelGGL(k_fit, dim3(grid(n)), dim3(BT), 0, q, S.keys, S.boxes, n, S.left, S.right, S.parent_inner, S.parent_leaf, S.inner_box, S.arrived);
 	hipLaunchKernelGGL(k_need, dim3(grid(n - 1)), dim3(BT), 0, q, n, max_leaf, S.left, S.right, S.range, S.parent_inner, S.need);
 	tb = S.temp_bytes;
-	BUILD_TRY(hipcub::DeviceScan::ExclusiveSum(S.temp, tb, S.need, S.place, (int)(n - 1), q));
+	BUILD_TRY(rocprim::exclusive_scan(S.temp, tb, S.need, S.place, 0u, (size_t)(n - 1), rocprim::plus<uint32_t>(), q));
 	hipLaunchKernelGGL(k_emit, dim3(grid(n - 1)), dim3(BT), 0, q, n, max_leaf, S.keys, S.boxes, S.left, S.right, S.range, S.inner_box, S.place, node_base,
 	                   item_base, instances, d_out);
 	BUILD_TRY(hipGetLastError());
@@ -318,6 +333,398 @@ int build_tree(Scratch &S, hipStream_t q, uint32_t n, uint32_t max_leaf, uint32_
 	BUILD_TRY(hipMemcpyAsync(&last_need, S.need + (n - 2), 4, hipMemcpyDeviceToHost, q));
 	BUILD_TRY(hipStreamSynchronize(q));
 	*emitted = last_place + last_need;
+	return POLARIS_OK;
+}
+
+
+// =============================================================================================
+// Binned SAH, level by level (POLARIS_BVH_SAH)
+// =============================================================================================
+// The items of a tree sit in ONE array of positions; every node owns a contiguous range of it.  A level:
+//   nodes of > 512 items    k_sah_cbounds_big, k_sah_bin_big: centroid bounds, then kBins bins per axis (count + box), by atomics that a
+//                           workgroup aggregates in LDS over its tile of 256 positions; k_sah_split_big: one thread per node
+//   nodes of <= 512 items   k_sah_small: ONE WAVE per node does all of that in registers and LDS, no global atomic (the deep levels
+//                           of a tree are hundreds of thousands of such nodes)
+//   the split               the cheapest of 3 x (kBins - 1) planes (cost = n_l area_l + n_r area_r, as scenes.py / bvh_builder.go); the two
+//                           children get their node ids, their boxes (unions of bins: exact) and, if they hold <= max_leaf items,
+//                           become leaves; a node no plane separates is halved by position
+//   prefix sum      over "this item goes left" flags of the whole level (rocPRIM) -- a STABLE partition, so the build is deterministic
+//   k_sah_scatter   items move to their child's range; every position learns which active node of the next level owns it
+// until no node is left to split.  Node ids are level by level, children adjacent.
+constexpr int kBins = 16;
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+struct SahBin { uint32_t cnt, lo[3], hi[3]; };          // boxes as order-preserving uints (atomicMin / atomicMax)
+struct SahAct { uint32_t node, first, count; };          // an active node: it holds more than max_leaf items and will be split
+struct SahSplit { uint32_t axis, k, nl; float clo, ext; }; // axis kNone = halved by position
+struct SahCb { uint32_t lo[3], hi[3]; };
+
+__device__ __forceinline__ float sah_centroid(const Box &b, int a) { return 0.5f * b.lo[a] + 0.5f * b.hi[a]; }
+__device__ __forceinline__ uint32_t sah_bin_of(float c, float clo, float ext) { // the ONE expression both the binning and the partition use
+	return (uint32_t)fminf(fmaxf((c - clo) / ext * (float)kBins, 0.0f), (float)(kBins - 1));
+}
+
+__global__ __launch_bounds__(BT) void k_sah_init(uint32_t n, uint32_t *item, uint32_t *owner) {
+	const uint32_t p = blockIdx.x * BT + threadIdx.x;
+	if (p < n) { item[p] = p; owner[p] = 0; }
+}
+
+// bounds of the item BOXES (the root's box): per thread over a tile, per wave by shuffles, per workgroup in LDS, six atomics per workgroup
+__global__ __launch_bounds__(BT) void k_sah_root_bounds(const Box *boxes, uint32_t n, uint32_t *bounds) {
+	__shared__ uint32_t l[6];
+	if (threadIdx.x < 6) l[threadIdx.x] = threadIdx.x < 3 ? 0xFFFFFFFFu : 0u;
+	__syncthreads();
+	float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+	const uint32_t base = blockIdx.x * 2048u;
+	for (uint32_t i = base + threadIdx.x; i < min(base + 2048u, n); i += BT)
+		for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], boxes[i].lo[k]); hi[k] = fmaxf(hi[k], boxes[i].hi[k]); }
+	for (int k = 0; k < 3; k++) {
+		for (int s = 32; s > 0; s >>= 1) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], s)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], s)); }
+		if ((threadIdx.x & 63) == 0) { atomicMin(&l[k], f2o(lo[k])); atomicMax(&l[3 + k], f2o(hi[k])); }
+	}
+	__syncthreads();
+	if (threadIdx.x < 3) { atomicMin(&bounds[threadIdx.x], l[threadIdx.x]); atomicMax(&bounds[3 + threadIdx.x], l[3 + threadIdx.x]); }
+}
+__global__ void k_sah_root_node(const uint32_t *bounds, uint32_t n, uint32_t max_leaf, uint32_t node, uint32_t item_base, int instances, PolarisBvhNode *out, SahAct *act, uint32_t *counts) {
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	PolarisBvhNode nd;
+	for (int a = 0; a < 3; a++) { nd.min[a] = o2f(bounds[a]); nd.max[a] = o2f(bounds[3 + a]); }
+	nd.ldata = 0; nd.rdata = 0;
+	if (n <= max_leaf) { nd.ldata = -(int32_t)item_base; nd.rdata = instances ? 0 : (int32_t)n; counts[0] = 0; } // the whole tree is one leaf (instances: position 0, resolved by k_sah_finish)
+	else { act[0] = SahAct{node, 0u, n}; counts[0] = 1; }
+	counts[1] = 0;
+	counts[2] = 0;
+	out[node] = nd;
+}
+
+__global__ __launch_bounds__(BT) void k_sah_clear_cb(uint32_t count, SahCb *cb) {
+	const uint32_t i = blockIdx.x * BT + threadIdx.x;
+	if (i < count) { SahCb c; for (int a = 0; a < 3; a++) { c.lo[a] = 0xFFFFFFFFu; c.hi[a] = 0u; } cb[i] = c; }
+}
+__global__ __launch_bounds__(BT) void k_sah_clear_bins(uint32_t count, SahBin *bins) {
+	const uint32_t i = blockIdx.x * BT + threadIdx.x;
+	if (i < count) { SahBin b; b.cnt = 0; for (int a = 0; a < 3; a++) { b.lo[a] = 0xFFFFFFFFu; b.hi[a] = 0u; } bins[i] = b; }
+}
+
+// ---- nodes of more than kSmallMax items: two passes over their positions, tiles of kTile positions per workgroup.  A tile's atomics go
+// to LDS while its positions belong to the tile's FIRST active node (nodes are contiguous ranges: at the top of the tree that is every
+// position of the tile) and are flushed once per workgroup; positions of another node of the tile use global atomics directly.
+constexpr uint32_t kSmallMax = 512; // a node of at most this many items is split by ONE wave (k_sah_small)
+constexpr uint32_t kTile = 256;
+
+__global__ __launch_bounds__(BT) void k_sah_cbounds_big(uint32_t n, const uint32_t *item, const uint32_t *owner, const SahAct *act, const Box *boxes, SahCb *cb) {
+	__shared__ SahCb l;
+	__shared__ uint32_t s_owner;
+	const uint32_t base = blockIdx.x * kTile;
+	if (threadIdx.x == 0) {
+		s_owner = kNone;
+		for (int a = 0; a < 3; a++) { l.lo[a] = 0xFFFFFFFFu; l.hi[a] = 0u; }
+	}
+	__syncthreads();
+	for (uint32_t p = base + threadIdx.x; p < min(base + kTile, n); p += BT) { // the first big node of the tile (lowest position wins)
+		const uint32_t o = owner[p];
+		if (o != kNone && act[o].count > kSmallMax) { atomicMin(&s_owner, o); break; } // (active indices ascend with position)
+	}
+	__syncthreads();
+	const uint32_t o0 = s_owner;
+	if (o0 == kNone) return;
+	float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+	bool any = false;
+	for (uint32_t p = base + threadIdx.x; p < min(base + kTile, n); p += BT) {
+		const uint32_t o = owner[p];
+		if (o == kNone || act[o].count <= kSmallMax) continue;
+		const Box b = boxes[item[p]];
+		if (o == o0) { any = true; for (int a = 0; a < 3; a++) { const float c = sah_centroid(b, a); lo[a] = fminf(lo[a], c); hi[a] = fmaxf(hi[a], c); } }
+		else for (int a = 0; a < 3; a++) { const float c = sah_centroid(b, a); atomicMin(&cb[o].lo[a], f2o(c)); atomicMax(&cb[o].hi[a], f2o(c)); }
+	}
+	if (any) for (int a = 0; a < 3; a++) { atomicMin(&l.lo[a], f2o(lo[a])); atomicMax(&l.hi[a], f2o(hi[a])); }
+	__syncthreads();
+	if (threadIdx.x < 3) { atomicMin(&cb[o0].lo[threadIdx.x], l.lo[threadIdx.x]); atomicMax(&cb[o0].hi[threadIdx.x], l.hi[threadIdx.x]); }
+}
+
+__global__ __launch_bounds__(BT) void k_sah_bin_big(uint32_t n, const uint32_t *item, const uint32_t *owner, const SahAct *act, const Box *boxes, const SahCb *cb, SahBin *bins) {
+	__shared__ SahBin lb[3 * kBins];
+	__shared__ uint32_t s_owner;
+	const uint32_t base = blockIdx.x * kTile;
+	if (threadIdx.x == 0) s_owner = kNone;
+	if (threadIdx.x < 3 * kBins) { SahBin b; b.cnt = 0; for (int a = 0; a < 3; a++) { b.lo[a] = 0xFFFFFFFFu; b.hi[a] = 0u; } lb[threadIdx.x] = b; }
+	__syncthreads();
+	for (uint32_t p = base + threadIdx.x; p < min(base + kTile, n); p += BT) {
+		const uint32_t o = owner[p];
+		if (o != kNone && act[o].count > kSmallMax) { atomicMin(&s_owner, o); break; }
+	}
+	__syncthreads();
+	const uint32_t o0 = s_owner;
+	if (o0 == kNone) return;
+	for (uint32_t p = base + threadIdx.x; p < min(base + kTile, n); p += BT) {
+		const uint32_t o = owner[p];
+		if (o == kNone || act[o].count <= kSmallMax) continue;
+		const Box b = boxes[item[p]];
+		const SahCb c = cb[o];
+		for (int a = 0; a < 3; a++) {
+			const float clo = o2f(c.lo[a]), ext = o2f(c.hi[a]) - clo;
+			if (!(ext > 1e-12f)) continue; // (scenes.py: an axis along which the centroids coincide offers no plane)
+			const uint32_t k = sah_bin_of(sah_centroid(b, a), clo, ext);
+			SahBin *t = o == o0 ? &lb[a * kBins + k] : &bins[((size_t)o * 3 + a) * kBins + k];
+			atomicAdd(&t->cnt, 1u);
+			for (int d = 0; d < 3; d++) { atomicMin(&t->lo[d], f2o(b.lo[d])); atomicMax(&t->hi[d], f2o(b.hi[d])); }
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x < 3 * kBins && lb[threadIdx.x].cnt) {
+		SahBin *t = &bins[(size_t)o0 * 3 * kBins + threadIdx.x];
+		const SahBin v = lb[threadIdx.x];
+		atomicAdd(&t->cnt, v.cnt);
+		for (int d = 0; d < 3; d++) { atomicMin(&t->lo[d], v.lo[d]); atomicMax(&t->hi[d], v.hi[d]); }
+	}
+}
+
+__device__ __forceinline__ float sah_half_area(const float lo[3], const float hi[3]) {
+	const float dx = fmaxf(hi[0] - lo[0], 0.0f), dy = fmaxf(hi[1] - lo[1], 0.0f), dz = fmaxf(hi[2] - lo[2], 0.0f);
+	return dx * dy + dy * dz + dx * dz;
+}
+
+// The split of ONE node from its bins (B: [3][kBins], global or LDS) and centroid bounds: the cheapest of the 3 x (kBins - 1) planes,
+// the children's ids, boxes and leaf records, flags[2 o + side] = 1 when that child is active in the next level.
+__device__ __forceinline__ void sah_split_node(uint32_t o, const SahAct me, const SahCb c, const SahBin *B3, uint32_t max_leaf, uint32_t next_base, uint32_t item_base,
+                                               int instances, PolarisBvhNode *out, SahSplit *split, uint32_t *flags, uint32_t *counts) {
+	const uint32_t m = me.count;
+	float best = 3.0e38f;
+	uint32_t best_axis = kNone, best_k = 0, best_nl = 0;
+	for (int a = 0; a < 3; a++) {
+		const SahBin *B = B3 + a * kBins;
+		// suffix: area and count of bins [k, kBins)
+		float ra[kBins];
+		uint32_t rc[kBins];
+		{
+			float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+			uint32_t cc = 0;
+#pragma unroll
+			for (int k = kBins - 1; k >= 0; k--) {
+				if (B[k].cnt) { for (int d = 0; d < 3; d++) { lo[d] = fminf(lo[d], o2f(B[k].lo[d])); hi[d] = fmaxf(hi[d], o2f(B[k].hi[d])); } cc += B[k].cnt; }
+				ra[k] = cc ? sah_half_area(lo, hi) : 0.0f;
+				rc[k] = cc;
+			}
+		}
+		if (rc[0] != m) continue; // this axis was not binned (no extent)
+		float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+		uint32_t nl = 0;
+#pragma unroll
+		for (int k = 0; k < kBins - 1; k++) { // left = bins [0, k], right = bins [k + 1, kBins)
+			if (B[k].cnt) { for (int d = 0; d < 3; d++) { lo[d] = fminf(lo[d], o2f(B[k].lo[d])); hi[d] = fmaxf(hi[d], o2f(B[k].hi[d])); } nl += B[k].cnt; }
+			if (nl == 0 || rc[k + 1] == 0) continue;
+			const float cost = (float)nl * sah_half_area(lo, hi) + (float)rc[k + 1] * ra[k + 1];
+			if (cost < best) { best = cost; best_axis = (uint32_t)a; best_k = (uint32_t)k; best_nl = nl; }
+		}
+	}
+	SahSplit sp;
+	sp.axis = best_axis; sp.k = best_k; sp.clo = 0.0f; sp.ext = 1.0f;
+	PolarisBvhNode kid[2];
+	if (best_axis != kNone) {
+		sp.nl = best_nl;
+		sp.clo = o2f(c.lo[best_axis]);
+		sp.ext = o2f(c.hi[best_axis]) - sp.clo;
+		const SahBin *B = B3 + best_axis * kBins;
+		for (int side = 0; side < 2; side++) {
+			float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+			for (uint32_t k = side ? best_k + 1 : 0u; k < (side ? (uint32_t)kBins : best_k + 1); k++)
+				if (B[k].cnt) for (int d = 0; d < 3; d++) { lo[d] = fminf(lo[d], o2f(B[k].lo[d])); hi[d] = fmaxf(hi[d], o2f(B[k].hi[d])); }
+			for (int d = 0; d < 3; d++) { kid[side].min[d] = lo[d]; kid[side].max[d] = hi[d]; }
+		}
+	} else { // no plane separates the centroids: halve the range by position; the halves' boxes are fitted by k_sah_fit_halves
+		sp.nl = m / 2;
+		for (int side = 0; side < 2; side++) for (int d = 0; d < 3; d++) { kid[side].min[d] = out[me.node].min[d]; kid[side].max[d] = out[me.node].max[d]; }
+		atomicAdd(&counts[1], 1u);
+	}
+	split[o] = sp;
+	const uint32_t ids[2] = {next_base + 2 * o, next_base + 2 * o + 1};
+	const uint32_t firsts[2] = {me.first, me.first + sp.nl}, cnts[2] = {sp.nl, m - sp.nl};
+	for (int side = 0; side < 2; side++) {
+		const bool leaf = cnts[side] <= max_leaf;
+		kid[side].ldata = leaf ? -(int32_t)(item_base + firsts[side]) : 0;
+		kid[side].rdata = leaf ? (instances ? 0 : (int32_t)cnts[side]) : 0;
+		out[ids[side]] = kid[side];
+		flags[2 * o + side] = leaf ? 0u : 1u;
+	}
+	out[me.node].ldata = (int32_t)ids[0];
+	out[me.node].rdata = (int32_t)ids[1];
+}
+
+// big nodes: one thread per active node, bins in global memory
+__global__ __launch_bounds__(BT) void k_sah_split_big(uint32_t A, const SahAct *act, const SahCb *cb, const SahBin *bins, uint32_t max_leaf, uint32_t next_base,
+                                                      uint32_t item_base, int instances, PolarisBvhNode *out, SahSplit *split, uint32_t *flags, uint32_t *counts) {
+	const uint32_t o = blockIdx.x * BT + threadIdx.x;
+	if (o >= A || act[o].count <= kSmallMax) return;
+	sah_split_node(o, act[o], cb[o], bins + (size_t)o * 3 * kBins, max_leaf, next_base, item_base, instances, out, split, flags, counts);
+}
+
+// small nodes (<= kSmallMax items): ONE WAVE per node does everything -- centroid bounds by a wave reduction, the bins in LDS, the
+// split by its first lane -- without a global atomic (the deep levels of a tree are hundreds of thousands of such nodes).
+__global__ __launch_bounds__(BT) void k_sah_small(uint32_t A, const SahAct *act, const uint32_t *item, const Box *boxes, uint32_t max_leaf, uint32_t next_base,
+                                                  uint32_t item_base, int instances, PolarisBvhNode *out, SahSplit *split, uint32_t *flags, uint32_t *counts) {
+	__shared__ SahBin lb[BT / 64][3 * kBins];
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const uint32_t o = blockIdx.x * (BT / 64) + wave;
+	if (o >= A) return;
+	const SahAct me = act[o];
+	if (me.count > kSmallMax) return;
+	float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+	for (uint32_t i = lane; i < me.count; i += 64) {
+		const Box b = boxes[item[me.first + i]];
+		for (int a = 0; a < 3; a++) { const float c = sah_centroid(b, a); lo[a] = fminf(lo[a], c); hi[a] = fmaxf(hi[a], c); }
+	}
+	SahCb c;
+	for (int a = 0; a < 3; a++) {
+		for (int sft = 32; sft > 0; sft >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], sft)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], sft)); }
+		c.lo[a] = f2o(lo[a]); c.hi[a] = f2o(hi[a]); // (the same encoding round trip as the big path: sah_bin_of sees identical operands)
+	}
+	if (lane < 3 * kBins) { SahBin b; b.cnt = 0; for (int a = 0; a < 3; a++) { b.lo[a] = 0xFFFFFFFFu; b.hi[a] = 0u; } lb[wave][lane] = b; }
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	for (uint32_t i = lane; i < me.count; i += 64) {
+		const Box b = boxes[item[me.first + i]];
+		for (int a = 0; a < 3; a++) {
+			const float clo = o2f(c.lo[a]), ext = o2f(c.hi[a]) - clo;
+			if (!(ext > 1e-12f)) continue;
+			SahBin *t = &lb[wave][a * kBins + sah_bin_of(sah_centroid(b, a), clo, ext)];
+			atomicAdd(&t->cnt, 1u);
+			for (int d = 0; d < 3; d++) { atomicMin(&t->lo[d], f2o(b.lo[d])); atomicMax(&t->hi[d], f2o(b.hi[d])); }
+		}
+	}
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	if (lane == 0) sah_split_node(o, me, c, lb[wave], max_leaf, next_base, item_base, instances, out, split, flags, counts);
+}
+
+__global__ __launch_bounds__(BT) void k_sah_next(uint32_t A, const SahAct *act, const SahSplit *split, const uint32_t *flags, const uint32_t *nidx, uint32_t next_base,
+                                                 SahAct *act_next, uint32_t *counts) {
+	const uint32_t o = blockIdx.x * BT + threadIdx.x;
+	if (o >= A) return;
+	const SahAct me = act[o];
+	const SahSplit sp = split[o];
+	if (flags[2 * o]) act_next[nidx[2 * o]] = SahAct{next_base + 2 * o, me.first, sp.nl};
+	if (flags[2 * o + 1]) act_next[nidx[2 * o + 1]] = SahAct{next_base + 2 * o + 1, me.first + sp.nl, me.count - sp.nl};
+	if (o == A - 1) counts[0] = nidx[2 * o + 1] + flags[2 * o + 1];
+	const uint32_t big = (flags[2 * o] && sp.nl > kSmallMax ? 1u : 0u) + (flags[2 * o + 1] && me.count - sp.nl > kSmallMax ? 1u : 0u);
+	if (big) atomicAdd(&counts[2], big); // how many nodes of the next level take the three-pass path (0: those kernels are not launched)
+}
+
+__global__ __launch_bounds__(BT) void k_sah_flag(uint32_t n, const uint32_t *item, const uint32_t *owner, const Box *boxes, const SahAct *act, const SahSplit *split, uint32_t *left) {
+	const uint32_t p = blockIdx.x * BT + threadIdx.x;
+	if (p >= n) return;
+	const uint32_t o = owner[p];
+	uint32_t l = 0;
+	if (o != kNone) {
+		const SahSplit sp = split[o];
+		if (sp.axis == kNone) l = (p - act[o].first) < sp.nl ? 1u : 0u;
+		else l = sah_bin_of(sah_centroid(boxes[item[p]], (int)sp.axis), sp.clo, sp.ext) <= sp.k ? 1u : 0u;
+	}
+	left[p] = l;
+}
+
+__global__ __launch_bounds__(BT) void k_sah_scatter(uint32_t n, const uint32_t *item, const uint32_t *owner, const uint32_t *left, const uint32_t *lscan, const SahAct *act,
+                                                    const SahSplit *split, const uint32_t *flags, const uint32_t *nidx, uint32_t *item_next, uint32_t *owner_next) {
+	const uint32_t p = blockIdx.x * BT + threadIdx.x;
+	if (p >= n) return;
+	const uint32_t o = owner[p];
+	if (o == kNone) { item_next[p] = item[p]; owner_next[p] = kNone; return; }
+	const SahAct me = act[o];
+	const uint32_t nl = split[o].nl;
+	const uint32_t rank_l = lscan[p] - lscan[me.first];
+	const uint32_t side = left[p] ? 0u : 1u;
+	const uint32_t q = side == 0 ? me.first + rank_l : me.first + nl + (p - me.first - rank_l);
+	item_next[q] = item[p];
+	owner_next[q] = flags[2 * o + side] ? nidx[2 * o + side] : kNone;
+}
+
+// the boxes of the two halves of a node that was halved by position (rare: coincident centroids): per-item atomics into a scratch box
+__global__ __launch_bounds__(BT) void k_sah_fit_halves(uint32_t n, const uint32_t *item_next, const Box *boxes, const uint32_t *owner, const uint32_t *left, const uint32_t *lscan,
+                                                       const SahAct *act, const SahSplit *split, SahCb *half) {
+	const uint32_t p = blockIdx.x * BT + threadIdx.x;
+	if (p >= n) return;
+	const uint32_t o = owner[p];
+	if (o == kNone || split[o].axis != kNone) return;
+	const uint32_t side = left[p] ? 0u : 1u;
+	const SahAct me = act[o];
+	const uint32_t rank_l = lscan[p] - lscan[me.first];
+	const uint32_t q = side == 0 ? me.first + rank_l : me.first + split[o].nl + (p - me.first - rank_l);
+	const Box b = boxes[item_next[q]];
+	SahCb *t = &half[2 * o + side];
+	for (int d = 0; d < 3; d++) { atomicMin(&t->lo[d], f2o(b.lo[d])); atomicMax(&t->hi[d], f2o(b.hi[d])); }
+}
+__global__ __launch_bounds__(BT) void k_sah_write_halves(uint32_t A, const SahSplit *split, const SahCb *half, uint32_t next_base, PolarisBvhNode *out) {
+	const uint32_t o = blockIdx.x * BT + threadIdx.x;
+	if (o >= A || split[o].axis != kNone) return;
+	for (int side = 0; side < 2; side++)
+		for (int d = 0; d < 3; d++) { out[next_base + 2 * o + side].min[d] = o2f(half[2 * o + side].lo[d]); out[next_base + 2 * o + side].max[d] = o2f(half[2 * o + side].hi[d]); }
+}
+
+// the item order the leaves name; top-level leaves: the instance itself (leaves were written with the POSITION of their one item)
+__global__ __launch_bounds__(BT) void k_sah_finish(uint32_t n, const uint32_t *item, uint32_t item_base, uint32_t *order, int instances, uint32_t node_base, uint32_t num_nodes, PolarisBvhNode *out) {
+	const uint32_t p = blockIdx.x * BT + threadIdx.x;
+	if (order && p < n) order[item_base + p] = item_base + item[p];
+	if (instances && p < num_nodes) {
+		PolarisBvhNode &nd = out[node_base + p];
+		if (nd.ldata <= 0 && nd.rdata == 0) nd.ldata = -(int32_t)item[(uint32_t)(-nd.ldata)];
+	}
+}
+
+struct SahScratch {
+	uint32_t *item[2] = {nullptr, nullptr}, *owner[2] = {nullptr, nullptr}, *left = nullptr, *lscan = nullptr, *flags = nullptr, *nidx = nullptr, *counts = nullptr, *bounds = nullptr;
+	SahBin *bins = nullptr;
+	SahCb *cb = nullptr, *half = nullptr;
+	SahAct *act[2] = {nullptr, nullptr};
+	SahSplit *split = nullptr;
+	void *temp = nullptr;
+	size_t temp_bytes = 0;
+	Box *boxes = nullptr;
+};
+
+// One tree over n items whose boxes are in S.boxes: nodes to out[node_base ...]; *emitted = the number of nodes written.
+int build_tree_sah(SahScratch &S, hipStream_t q, uint32_t n, uint32_t max_leaf, uint32_t node_base, uint32_t item_base, int instances,
+                   PolarisBvhNode *d_out, uint32_t *d_order, uint32_t *emitted) {
+	BUILD_TRY(hipMemsetAsync(S.bounds, 0xFF, 3 * sizeof(uint32_t), q));
+	BUILD_TRY(hipMemsetAsync(S.bounds + 3, 0x00, 3 * sizeof(uint32_t), q));
+	hipLaunchKernelGGL(k_sah_init, dim3(grid(n)), dim3(BT), 0, q, n, S.item[0], S.owner[0]);
+	hipLaunchKernelGGL(k_sah_root_bounds, dim3((n + 2047u) / 2048u), dim3(BT), 0, q, S.boxes, n, S.bounds);
+	hipLaunchKernelGGL(k_sah_root_node, dim3(1), dim3(64), 0, q, S.bounds, n, max_leaf, node_base, instances ? 0u : item_base, instances, d_out, S.act[0], S.counts);
+	uint32_t A = n <= max_leaf ? 0u : 1u, total = 1, n_big = n > kSmallMax ? 1u : 0u;
+	int cur = 0;
+	for (int level = 0; A > 0; level++) {
+		if (level > 96) { g_build_error = "build_bvh: the SAH builder did not terminate (more than 96 levels)"; return POLARIS_E_DEVICE; }
+		const uint32_t next_base = node_base + total;
+		if (n_big) { // nodes of more than kSmallMax items: centroid bounds, bins, split as three passes (atomics aggregated per tile in LDS)
+			hipLaunchKernelGGL(k_sah_clear_cb, dim3(grid(A)), dim3(BT), 0, q, A, S.cb);
+			hipLaunchKernelGGL(k_sah_clear_bins, dim3(grid(A * 3u * kBins)), dim3(BT), 0, q, A * 3u * kBins, S.bins);
+			hipLaunchKernelGGL(k_sah_cbounds_big, dim3((n + kTile - 1) / kTile), dim3(BT), 0, q, n, S.item[cur], S.owner[cur], S.act[cur], S.boxes, S.cb);
+			hipLaunchKernelGGL(k_sah_bin_big, dim3((n + kTile - 1) / kTile), dim3(BT), 0, q, n, S.item[cur], S.owner[cur], S.act[cur], S.boxes, S.cb, S.bins);
+			hipLaunchKernelGGL(k_sah_split_big, dim3(grid(A)), dim3(BT), 0, q, A, S.act[cur], S.cb, S.bins, max_leaf, next_base, instances ? 0u : item_base, instances, d_out, S.split, S.flags, S.counts);
+		}
+		hipLaunchKernelGGL(k_sah_small, dim3((A + BT / 64 - 1) / (BT / 64)), dim3(BT), 0, q, A, S.act[cur], S.item[cur], S.boxes, max_leaf, next_base, instances ? 0u : item_base, instances, d_out, S.split, S.flags, S.counts);
+		size_t tb = S.temp_bytes;
+		BUILD_TRY(rocprim::exclusive_scan(S.temp, tb, S.flags, S.nidx, 0u, (size_t)2 * A, rocprim::plus<uint32_t>(), q));
+		hipLaunchKernelGGL(k_sah_next, dim3(grid(A)), dim3(BT), 0, q, A, S.act[cur], S.split, S.flags, S.nidx, next_base, S.act[cur ^ 1], S.counts);
+		hipLaunchKernelGGL(k_sah_flag, dim3(grid(n)), dim3(BT), 0, q, n, S.item[cur], S.owner[cur], S.boxes, S.act[cur], S.split, S.left);
+		tb = S.temp_bytes;
+		BUILD_TRY(rocprim::exclusive_scan(S.temp, tb, S.left, S.lscan, 0u, (size_t)n, rocprim::plus<uint32_t>(), q));
+		hipLaunchKernelGGL(k_sah_scatter, dim3(grid(n)), dim3(BT), 0, q, n, S.item[cur], S.owner[cur], S.left, S.lscan, S.act[cur], S.split, S.flags, S.nidx, S.item[cur ^ 1], S.owner[cur ^ 1]);
+		uint32_t counts[3] = {0, 0, 0};
+		BUILD_TRY(hipMemcpyAsync(counts, S.counts, sizeof counts, hipMemcpyDeviceToHost, q));
+		BUILD_TRY(hipStreamSynchronize(q));
+		BUILD_TRY(hipMemsetAsync(S.counts + 2, 0, sizeof(uint32_t), q));
+		n_big = counts[2];
+		if (counts[1]) { // some node was halved by position: fit its halves' boxes
+			hipLaunchKernelGGL(k_sah_clear_cb, dim3(grid(2 * A)), dim3(BT), 0, q, 2 * A, S.half);
+			hipLaunchKernelGGL(k_sah_fit_halves, dim3(grid(n)), dim3(BT), 0, q, n, S.item[cur ^ 1], S.boxes, S.owner[cur], S.left, S.lscan, S.act[cur], S.split, S.half);
+			hipLaunchKernelGGL(k_sah_write_halves, dim3(grid(A)), dim3(BT), 0, q, A, S.split, S.half, next_base, d_out);
+			BUILD_TRY(hipMemsetAsync(S.counts + 1, 0, sizeof(uint32_t), q));
+		}
+		total += 2 * A;
+		A = counts[0];
+		cur ^= 1;
+	}
+	hipLaunchKernelGGL(k_sah_finish, dim3(grid(std::max(n, total))), dim3(BT), 0, q, n, S.item[cur], item_base, d_order, instances, node_base, total, d_out);
+	BUILD_TRY(hipGetLastError());
+	*emitted = total;
 	return POLARIS_OK;
 }
 
@@ -336,6 +743,7 @@ int polaris_hip_build_bvh(int device, const PolarisBvhBuildInput *in, PolarisBvh
 	if (!in->mesh_first_tri || !in->mesh_num_tris || in->num_meshes == 0) return bad("build_bvh: no meshes");
 	if (!in->instance_boxes || !in->instance_mesh || in->num_instances == 0 || in->num_instances > (1u << 24)) return bad("build_bvh: no instances (or more than 2^24)");
 	if (in->max_leaf_tris < 1 || in->max_leaf_tris > 15) return bad("build_bvh: max_leaf_tris must be 1..15");
+	if (in->algorithm != POLARIS_BVH_SAH && in->algorithm != POLARIS_BVH_LBVH) return bad("build_bvh: algorithm must be POLARIS_BVH_SAH or POLARIS_BVH_LBVH");
 	uint32_t biggest = in->num_instances;
 	uint64_t covered = 0;
 	for (uint32_t m = 0; m < in->num_meshes; m++) {
@@ -355,23 +763,39 @@ int polaris_hip_build_bvh(int device, const PolarisBvhBuildInput *in, PolarisBvh
 	hipStream_t q = nullptr;
 	BUILD_TRY(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
 	struct StreamGuard { hipStream_t q; ~StreamGuard() { (void)hipStreamDestroy(q); } } guard{q};
+	const bool sah = in->algorithm != POLARIS_BVH_LBVH;
 	Scratch S;
+	SahScratch H;
 	float4 *d_verts = nullptr;
 	PolarisBvhNode *d_nodes = nullptr;
 	uint32_t *d_order = nullptr;
 	BUILD_TRY(S.get(&d_verts, (size_t)in->num_triangles * 3));
 	BUILD_TRY(S.get(&d_nodes, nodes_capacity));
 	BUILD_TRY(S.get(&d_order, in->num_triangles));
-	BUILD_TRY(S.get(&S.keys, biggest)); BUILD_TRY(S.get(&S.keys_alt, biggest));
-	BUILD_TRY(S.get(&S.boxes, biggest)); BUILD_TRY(S.get(&S.inner_box, biggest));
-	BUILD_TRY(S.get(&S.left, biggest)); BUILD_TRY(S.get(&S.right, biggest));
-	BUILD_TRY(S.get(&S.parent_inner, biggest)); BUILD_TRY(S.get(&S.parent_leaf, biggest));
-	BUILD_TRY(S.get(&S.arrived, biggest)); BUILD_TRY(S.get(&S.need, biggest)); BUILD_TRY(S.get(&S.place, biggest));
-	BUILD_TRY(S.get(&S.range, biggest)); BUILD_TRY(S.get(&S.bounds, 8));
-	{
+	BUILD_TRY(S.get(&S.boxes, biggest));
+	if (sah) {
+		H.boxes = S.boxes;
+		const size_t amax = (size_t)biggest / 2 + 1; // active nodes of a level hold >= 2 items each and are disjoint
+		for (int i = 0; i < 2; i++) { BUILD_TRY(S.get(&H.item[i], biggest)); BUILD_TRY(S.get(&H.owner[i], biggest)); BUILD_TRY(S.get(&H.act[i], amax)); }
+		BUILD_TRY(S.get(&H.left, biggest)); BUILD_TRY(S.get(&H.lscan, biggest));
+		BUILD_TRY(S.get(&H.flags, 2 * amax)); BUILD_TRY(S.get(&H.nidx, 2 * amax)); BUILD_TRY(S.get(&H.counts, 4)); BUILD_TRY(S.get(&H.bounds, 8));
+		BUILD_TRY(S.get(&H.bins, amax * 3 * kBins)); BUILD_TRY(S.get(&H.cb, amax)); BUILD_TRY(S.get(&H.half, 2 * amax)); BUILD_TRY(S.get(&H.split, amax));
+		size_t a = 0;
+		BUILD_TRY(rocprim::exclusive_scan(nullptr, a, H.left, H.lscan, 0u, std::max<size_t>(biggest, 2 * amax), rocprim::plus<uint32_t>(), q));
+		H.temp_bytes = a;
+		uint8_t *t = nullptr;
+		BUILD_TRY(S.get(&t, a));
+		H.temp = t;
+	} else {
+		BUILD_TRY(S.get(&S.keys, biggest)); BUILD_TRY(S.get(&S.keys_alt, biggest));
+		BUILD_TRY(S.get(&S.inner_box, biggest));
+		BUILD_TRY(S.get(&S.left, biggest)); BUILD_TRY(S.get(&S.right, biggest));
+		BUILD_TRY(S.get(&S.parent_inner, biggest)); BUILD_TRY(S.get(&S.parent_leaf, biggest));
+		BUILD_TRY(S.get(&S.arrived, biggest)); BUILD_TRY(S.get(&S.need, biggest)); BUILD_TRY(S.get(&S.place, biggest));
+		BUILD_TRY(S.get(&S.range, biggest)); BUILD_TRY(S.get(&S.bounds, 8));
 		size_t a = 0, b = 0;
-		BUILD_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, a, S.keys_alt, S.keys, (int)biggest, 0, 62, q));
-		BUILD_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, b, S.need, S.place, (int)biggest, q));
+		BUILD_TRY(rocprim::radix_sort_keys(nullptr, a, S.keys_alt, S.keys, (size_t)biggest, 0u, 62u, q));
+		BUILD_TRY(rocprim::exclusive_scan(nullptr, b, S.need, S.place, 0u, (size_t)std::max<uint32_t>(biggest, 2u), rocprim::plus<uint32_t>(), q));
 		S.temp_bytes = std::max(a, b);
 		uint8_t *t = nullptr;
 		BUILD_TRY(S.get(&t, S.temp_bytes));
@@ -388,13 +812,13 @@ int polaris_hip_build_bvh(int device, const PolarisBvhBuildInput *in, PolarisBvh
 	static_assert(sizeof(Box) == 24, "instance boxes arrive as 6 floats");
 	BUILD_TRY(hipMemcpyAsync(S.boxes, in->instance_boxes, (size_t)in->num_instances * sizeof(Box), hipMemcpyHostToDevice, q));
 	uint32_t total = 0, emitted = 0;
-	if (int rc = build_tree(S, q, in->num_instances, 1, 0, 0, 1, d_nodes, nullptr, &emitted)) return rc;
+	if (int rc = sah ? build_tree_sah(H, q, in->num_instances, 1, 0, 0, 1, d_nodes, nullptr, &emitted) : build_tree(S, q, in->num_instances, 1, 0, 0, 1, d_nodes, nullptr, &emitted)) return rc;
 	total += emitted;
 	for (uint32_t m = 0; m < in->num_meshes; m++) {
 		const uint32_t first = in->mesh_first_tri[m], n = in->mesh_num_tris[m];
 		hipLaunchKernelGGL(k_tri_boxes, dim3(grid(n)), dim3(BT), 0, q, d_verts, first, n, S.boxes);
 		mesh_root[m] = total;
-		if (int rc = build_tree(S, q, n, in->max_leaf_tris, total, first, 0, d_nodes, d_order, &emitted)) return rc;
+		if (int rc = sah ? build_tree_sah(H, q, n, in->max_leaf_tris, total, first, 0, d_nodes, d_order, &emitted) : build_tree(S, q, n, in->max_leaf_tris, total, first, 0, d_nodes, d_order, &emitted)) return rc;
 		total += emitted;
 	}
 	BUILD_TRY(hipEventRecord(e1, q));

@@ -1284,11 +1284,13 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(POLARIS_SHAD
 	const size_t base = (size_t)blockIdx.x * WG;
 	const size_t my = base + tid;
 #ifndef POLARIS_SHADE_LOAD
-#define POLARIS_SHADE_LOAD 0
+#define POLARIS_SHADE_LOAD 1
 #endif
-	// POLARIS_SHADE_LOAD (A/B, profiles/r05_shade_dead_slots_ab.txt): 0 = every lane requests its slot at once, live or not;
-	// 1 = only live slots are requested (after the chunk's count has arrived: one scalar round trip in front of the ray loads);
-	// 2 = slots 0..127 at once (a chunk's rays sit at its front, so these are nearly always live), slots 128..255 only if live.
+	// Only LIVE slots are requested (POLARIS_SHADE_LOAD = 1, round 5).  Round 4 requested every lane's slot at once, live or not, so that
+	// the ray loads did not wait for the chunk's count -- and read the 44 bytes of every dead slot (10 / 30 / 42 % of a chunk at
+	// bounces 1 / 2 / 3): 1.07 GB per headline frame, the larger part of this kernel's 1.30 x traffic over its algorithmic bytes
+	// (now 1.13 x), for no measurable time either way (profiles/r05_shade_dead_slots_ab.txt; 0 = the round-4 form, 2 = slots 0..127 at
+	// once and the rest only if live: A/B aids).  Camera rays (FIRST) fill every slot: they keep the unconditional form.
 	float4 d4 = make_float4(0, 0, 0, 0), t4 = make_float4(1.0f, 1.0f, 1.0f, 0.0f), h4 = make_float4(0, 0, 0, 0);
 	const bool early = FIRST || POLARIS_SHADE_LOAD == 0 || (POLARIS_SHADE_LOAD == 2 && tid < 128);
 	if (early) { d4 = st.ray_d[my]; if (!FIRST) t4 = st.thr[my]; h4 = load_hit(st, my); } // (camera rays carry no throughput: it is 1)

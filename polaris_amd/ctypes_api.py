@@ -111,8 +111,11 @@ class BvhBuildInput(C.Structure):
         ("vertices", C.c_void_p), ("num_triangles", C.c_uint32),
         ("mesh_first_tri", C.c_void_p), ("mesh_num_tris", C.c_void_p), ("num_meshes", C.c_uint32),
         ("instance_boxes", C.c_void_p), ("instance_mesh", C.c_void_p), ("num_instances", C.c_uint32),
-        ("max_leaf_tris", C.c_uint32),
+        ("max_leaf_tris", C.c_uint32), ("algorithm", C.c_uint32),
     ]
+
+
+BVH_SAH, BVH_LBVH = 0, 1   # PolarisBvhBuildInput.algorithm
 
 
 def _ptr(a):

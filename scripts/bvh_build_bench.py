@@ -39,16 +39,22 @@ def main():
         sc = scenes.SCENES[name]()
         t_scene = time.perf_counter() - t
         builds = []
-        bvh_build.rebuild_on_device(sc, max_leaf_tris=4)   # (first call: the builder's kernels are loaded)
-        for max_leaf in (4, 2):
-            t = time.perf_counter()
-            new, info = bvh_build.rebuild_on_device(sc, max_leaf_tris=max_leaf)
-            builds.append({"max_leaf_tris": max_leaf, "device_ms": round(info["device_ms"], 3), "wall_ms_with_readback_and_permutation": round((time.perf_counter() - t) * 1e3, 1),
-                           "nodes": info["num_nodes"], "nodes_of_the_cpu_tree": int(len(sc.bvh_nodes))})
+        for alg in ("sah", "lbvh"):
+            bvh_build.rebuild_on_device(sc, max_leaf_tris=4, algorithm=alg)   # (first call: the builder's kernels are loaded)
+            for max_leaf in (4, 2):
+                t = time.perf_counter()
+                new, info = bvh_build.rebuild_on_device(sc, max_leaf_tris=max_leaf, algorithm=alg)
+                builds.append({"algorithm": alg, "max_leaf_tris": max_leaf, "device_ms": round(info["device_ms"], 3), "wall_ms_with_readback_and_permutation": round((time.perf_counter() - t) * 1e3, 1),
+                               "nodes": info["num_nodes"], "nodes_of_the_cpu_tree": int(len(sc.bvh_nodes))})
+        cpu = bench(args)
         out[name] = {"triangles": int(sc.num_triangles), "instances": int(len(sc.mesh_instances)),
                      "cpu_producer_s_whole_scene_numpy_binned_sah": round(t_scene, 2), "device_builds": builds,
-                     "frame_on_the_cpu_built_tree": bench(args), "frame_on_the_device_built_tree": bench([*args, "--bvh", "device"]),
-                     "frame_on_the_device_built_tree_leaf2": bench([*args, "--bvh", "device", "--bvh-max-leaf", "2"])}
+                     "frame_on_the_cpu_built_tree": cpu}
+        for key, extra in (("sah_leaf4", ["--bvh", "device"]), ("sah_leaf2", ["--bvh", "device", "--bvh-max-leaf", "2"]), ("lbvh_leaf4", ["--bvh", "device-lbvh"])):
+            r = bench([*args, *extra])
+            if "ms_per_frame" in r and "ms_per_frame" in cpu:
+                r["trace_penalty_vs_cpu_tree"] = round(r["ms_per_frame"] / cpu["ms_per_frame"] - 1.0, 3)
+            out[name]["frame_on_the_device_built_tree_" + key] = r
         print(name, json.dumps(out[name]), flush=True)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"{tag}_bvh_build.json"), "w"), indent=1)
 

@@ -64,14 +64,15 @@ def check_tree(sc, old):
     return top_depth + 1 + max(depths.values())
 
 
+@pytest.mark.parametrize("algorithm", ["sah", "lbvh"])
 @pytest.mark.parametrize("name", SCENES)
-def test_device_built_bvh_is_valid_and_traces_like_the_oracle(built, oracle, name):
+def test_device_built_bvh_is_valid_and_traces_like_the_oracle(built, oracle, name, algorithm):
     from oracle import pybind as ob
     from polaris_amd import bvh_build, scenes
 
     old = scenes.SCENES[name]()
     for max_leaf in (1, 4):
-        sc, info = bvh_build.rebuild_on_device(old, max_leaf_tris=max_leaf)
+        sc, info = bvh_build.rebuild_on_device(old, max_leaf_tris=max_leaf, algorithm=algorithm)
         assert info["num_nodes"] == len(sc.bvh_nodes) <= 2 * (sc.num_triangles + len(sc.mesh_instances))
         leaves = sc.bvh_nodes[(sc.bvh_nodes["ldata"] <= 0) & (sc.bvh_nodes["rdata"] > 0)]
         assert leaves["rdata"].max() <= max_leaf
@@ -88,21 +89,81 @@ def test_device_built_bvh_is_valid_and_traces_like_the_oracle(built, oracle, nam
         finally:
             tr.Close()
         assert list(st.rays_per_bounce[:B]) == list(wst.rays_per_bounce[:B]) and list(st.occl_per_bounce[:B]) == list(wst.occl_per_bounce[:B])
-        assert np.array_equal(bits(got[..., :3]), bits(want[..., :3])), (name, max_leaf)
+        assert np.array_equal(bits(got[..., :3]), bits(want[..., :3])), (name, max_leaf, algorithm)
         # the same picture as on the original tree: a tree decides no hit except exact ties (and, through them, a few paths)
         ref, _, _ = oracle.trace(old, req, seeds)
         diff = np.abs(want[..., :3] - ref[..., :3]).reshape(-1, 3).max(axis=1)
         assert (diff > 1e-6).mean() < 0.02, (name, float((diff > 1e-6).mean()))
 
 
-def test_the_build_is_deterministic(built):
-    """Two builds give the same arrays, byte for byte (the sort keys are unique, node places come from a prefix sum)."""
+@pytest.mark.parametrize("algorithm", ["sah", "lbvh"])
+def test_the_build_is_deterministic(built, algorithm):
+    """Two builds give the same arrays, byte for byte (SAH: bins filled by min / max / integer-add atomics, a stable partition by a
+    prefix sum, node ids by level; LBVH: unique sort keys, node places from a prefix sum)."""
     from polaris_amd import bvh_build, scenes
 
     old = scenes.SCENES["material-ball-small"]()
-    a, _ = bvh_build.rebuild_on_device(old, max_leaf_tris=2)
-    b, _ = bvh_build.rebuild_on_device(old, max_leaf_tris=2)
+    a, _ = bvh_build.rebuild_on_device(old, max_leaf_tris=2, algorithm=algorithm)
+    b, _ = bvh_build.rebuild_on_device(old, max_leaf_tris=2, algorithm=algorithm)
     assert a.bvh_nodes.tobytes() == b.bvh_nodes.tobytes() and np.array_equal(a.material_index, b.material_index) and np.array_equal(a.vertices, b.vertices)
+
+
+def _dense_cell_mesh():
+    """A mesh the linear builder cannot handle: 5 000 triangles whose centroids share ONE cell of the 30-bit Morton grid, behind a
+    "spine" of 33 tiny triangles placed so that every level of the Morton hierarchy splits exactly one of them off (spine triangle
+    i sits at 1024 * 2^-(i // 3) along axis i % 3: it differs from the cluster in one code bit).  The Karras hierarchy is then
+    a chain of ~30 nodes with the cluster's log2(5 000) = 13 levels below it: deeper than the 32-entry traversal stack.  Returns a
+    Scene compiled by the CPU producer (binned SAH: no such problem)."""
+    from polaris_amd import scenes
+
+    rng = np.random.default_rng(5)
+    n = 5000
+    c = rng.uniform(0.0, 0.02, (n, 1, 3))
+    tri = c + rng.uniform(-0.05, 0.05, (n, 3, 3))
+    spine = []
+    for i in range(33):
+        p = np.zeros(3)
+        p[i % 3] = 1024.0 * 2.0 ** -(i // 3)
+        spine.append(p + np.array([[0, 0, 0], [1e-3, 0, 0], [0, 1e-3, 0]]))
+    verts = np.concatenate([tri, np.array(spine)]).astype(np.float32)
+    mt = scenes.MaterialTable()
+    d, e = mt.diffuse((0.7, 0.7, 0.7)), mt.emissive((8, 8, 8))
+    mat = np.full(len(verts), d, np.uint32)
+    mat[:40] = e
+    mesh = scenes.Mesh(verts, scenes._flat_normals(verts), np.zeros((len(verts), 3, 2), np.float32), mat)
+    sc = scenes.compile_scene([mesh], [(0, np.eye(4))], mt, max_leaf=4, name="dense-cell")
+    sc.set_camera(eye=(0.0, 0.0, 1.2), look=(0.0, 0.0, 0.0), fov=0.5, aspect=80 / 60)
+    return sc
+
+
+def test_a_mesh_dense_in_one_morton_cell_builds_with_the_sah_builder(built, oracle):
+    """Round 4's builder (LBVH) turns thousands of triangles that share a 30-bit Morton cell into a tree deeper than the traversal
+    stack, and the upload refuses the scene; the level-by-level SAH builder halves such a node by position and stays O(log n)
+    deep: valid tree, stack need < 32, and the trace equals the oracle bit for bit."""
+    from oracle import pybind as ob
+    from polaris_amd import bvh_build, scenes
+    from polaris_amd.tracer import TracerError
+
+    old = _dense_cell_mesh()
+    sc, _ = bvh_build.rebuild_on_device(old, max_leaf_tris=2, algorithm="sah")
+    assert check_tree(sc, old) < 32
+    W, H, spp, B = 80, 60, 2, 3
+    seeds = scenes.make_seeds(spp, B, base=3)
+    want, wst, _ = oracle.trace(sc, ob.make_request(W, H, spp=spp, bounces=B), seeds)
+    tr = make_hip_tracer(sc, W, H, exact_accumulate=1)
+    try:
+        tr.Trace(ob.make_request(W, H, spp=spp, bounces=B), seeds)
+        got = tr.read_accumulator(0)
+    finally:
+        tr.Close()
+    assert want[..., :3].sum() > 0 and np.array_equal(bits(got[..., :3]), bits(want[..., :3]))
+    # the linear builder on the same mesh: refused at upload (or, should a future key layout split the cell, at least valid)
+    lb, _ = bvh_build.rebuild_on_device(old, max_leaf_tris=2, algorithm="lbvh")
+    try:
+        make_hip_tracer(lb, W, H).Close()
+        assert check_tree(lb, old) < 32
+    except TracerError as e:
+        assert "stack" in str(e) or "deep" in str(e), str(e)
 
 
 def test_build_refuses_malformed_input(built):
@@ -127,6 +188,9 @@ def test_build_refuses_malformed_input(built):
     count[0] = 2
     inp.max_leaf_tris = 99
     assert lib.polaris_hip_build_bvh(0, C.byref(inp), nodes.ctypes.data, 8, C.byref(n), order.ctypes.data, roots.ctypes.data, None) == 2
+    inp.max_leaf_tris, inp.algorithm = 4, 7
+    assert lib.polaris_hip_build_bvh(0, C.byref(inp), nodes.ctypes.data, 8, C.byref(n), order.ctypes.data, roots.ctypes.data, None) == 2 and b"algorithm" in lib.polaris_hip_build_bvh_error()
+    inp.algorithm = 0
     inp.max_leaf_tris = 4
     assert lib.polaris_hip_build_bvh(0, C.byref(inp), nodes.ctypes.data, 2, C.byref(n), order.ctypes.data, roots.ctypes.data, None) == 2   # capacity
     assert lib.polaris_hip_build_bvh(0, C.byref(inp), nodes.ctypes.data, 8, C.byref(n), order.ctypes.data, roots.ctypes.data, None) == 0
