@@ -1261,7 +1261,16 @@ static int merge_rows(polaris_hip_tracer *dst, polaris_hip_tracer *src, polaris_
 	const size_t off = (size_t)r->block_y * dst->W, n = (size_t)r->block_h * dst->W;
 	const float4 *rows = src_acc + off;
 	hipStream_t q = dst->merge_stream;
-	if (peer && peer->ev[slot] && hipStreamWaitEvent(q, peer->ev[slot], 0) != hipSuccess) return fail_merge(POLARIS_E_DEVICE, "merge_ipc: waiting for the peer's Trace event of the slot failed");
+	if (peer && peer->ev[slot] && hipStreamWaitEvent(q, peer->ev[slot], 0) != hipSuccess) {
+		// The device-side wait is belt and braces: the slot was announced by a host message AFTER the peer's synchronous Trace returned, so
+		// its rows are complete.  A runtime that refuses to wait for another process's / another device's event must not cost the frame:
+		// drop the peer's events (the wait is not retried) and go on with the host-side ordering alone.
+		(void)hipGetLastError();
+		for (auto &e : peer->ev)
+			if (e) { (void)hipEventDestroy(e); e = nullptr; }
+		(void)hipGetLastError();
+		if (getenv("POLARIS_DEBUG")) fprintf(stderr, "[polaris] merge_ipc: hipStreamWaitEvent on the peer's inter-process event failed; continuing with the host-side ordering\n");
+	}
 	if (!peer && src_device != dst->device) {
 		int can = 0;
 		if (hipDeviceCanAccessPeer(&can, dst->device, src_device) != hipSuccess) return fail_merge(POLARIS_E_DEVICE, "merge: hipDeviceCanAccessPeer failed");
