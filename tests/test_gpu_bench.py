@@ -272,7 +272,7 @@ def test_bench_four_ranks_bare_launch_headline_blocks_one_rank_held_back(built, 
     assert ps["scheduler"] == "perfect" and ps["value"] > 0 and sum(ps["rows_last_frame"]) == H and min(ps["rows_last_frame"]) >= 1
     # the rank that is held back reports the longest frames: the perfect scheduler must have taken rows AWAY from it, and rank 0's
     # block must not have withered (round 4 billed the primary the wait for the slowest rank: ADVICE r4)
-    assert ps["rows_last_frame"][3] < 64 and ps["rows_last_frame"][0] >= 32, ps
+    assert ps["rows_last_frame"][3] < 64 and ps["rows_last_frame"][0] >= 16, ps
     _frame_matches_the_oracle_block_by_block(acc, W, H, spp, B, [64] * 4, scenes.make_seeds(spp, B, base=0xC0FFEE + steps + warmup - 1))
 
 
