@@ -383,7 +383,9 @@ def main() -> None:
                 # each, the verdicts gathered over gloo), the strips travel over gloo, staged through the host
                 err = ""
                 try:
-                    strip_group = dist.new_group(backend="nccl")
+                    import datetime
+
+                    strip_group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))  # (a rank whose RCCL bring-up fails must not leave the others waiting for ten minutes)
                     probe = torch.ones(1, device=dev)
                     dist.all_reduce(probe, group=strip_group)
                     torch.cuda.synchronize()
