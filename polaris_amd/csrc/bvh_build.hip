@@ -409,9 +409,11 @@ __global__ __launch_bounds__(BT) void k_sah_clear_bins(uint32_t count, SahBin *b
 // to LDS while its positions belong to the tile's FIRST active node (nodes are contiguous ranges: at the top of the tree that is every
 // position of the tile) and are flushed once per workgroup; positions of another node of the tile use global atomics directly.
 constexpr uint32_t kSmallMax = 512; // a node of at most this many items is split by ONE wave (k_sah_small)
-constexpr uint32_t kTile = 256;
+constexpr uint32_t kTile = 256;      // positions per workgroup of the two big-node passes
+constexpr int kBigBlock = 256;        // ... and its threads: one position each (measured: 2048 positions per 256 threads 13.9 ms for 1 M triangles -- too few
+                                      // workgroups --, 1024 per 1024 threads 9.8 ms -- sixteen waves at every barrier --, 256 per 256: 6.9 ms)
 
-__global__ __launch_bounds__(BT) void k_sah_cbounds_big(uint32_t n, const uint32_t *item, const uint32_t *owner, const SahAct *act, const Box *boxes, SahCb *cb) {
+__global__ __launch_bounds__(kBigBlock) void k_sah_cbounds_big(uint32_t n, const uint32_t *item, const uint32_t *owner, const SahAct *act, const Box *boxes, SahCb *cb) {
 	__shared__ SahCb l;
 	__shared__ uint32_t s_owner;
 	const uint32_t base = blockIdx.x * kTile;
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(BT) void k_sah_cbounds_big(uint32_t n, const uint32
 		for (int a = 0; a < 3; a++) { l.lo[a] = 0xFFFFFFFFu; l.hi[a] = 0u; }
 	}
 	__syncthreads();
-	for (uint32_t p = base + threadIdx.x; p < min(base + kTile, n); p += BT) { // the first big node of the tile (lowest position wins)
+	for (uint32_t p = base + threadIdx.x; p < min(base + kTile, n); p += kBigBlock) { // the first big node of the tile (lowest position wins)
 		const uint32_t o = owner[p];
 		if (o != kNone && act[o].count > kSmallMax) { atomicMin(&s_owner, o); break; } // (active indices ascend with position)
 	}
@@ -429,7 +431,7 @@ __global__ __launch_bounds__(BT) void k_sah_cbounds_big(uint32_t n, const uint32
 	if (o0 == kNone) return;
 	float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
 	bool any = false;
-	for (uint32_t p = base + threadIdx.x; p < min(base + kTile, n); p += BT) {
+	for (uint32_t p = base + threadIdx.x; p < min(base + kTile, n); p += kBigBlock) {
 		const uint32_t o = owner[p];
 		if (o == kNone || act[o].count <= kSmallMax) continue;
 		const Box b = boxes[item[p]];
@@ -441,21 +443,21 @@ __global__ __launch_bounds__(BT) void k_sah_cbounds_big(uint32_t n, const uint32
 	if (threadIdx.x < 3) { atomicMin(&cb[o0].lo[threadIdx.x], l.lo[threadIdx.x]); atomicMax(&cb[o0].hi[threadIdx.x], l.hi[threadIdx.x]); }
 }
 
-__global__ __launch_bounds__(BT) void k_sah_bin_big(uint32_t n, const uint32_t *item, const uint32_t *owner, const SahAct *act, const Box *boxes, const SahCb *cb, SahBin *bins) {
+__global__ __launch_bounds__(kBigBlock) void k_sah_bin_big(uint32_t n, const uint32_t *item, const uint32_t *owner, const SahAct *act, const Box *boxes, const SahCb *cb, SahBin *bins) {
 	__shared__ SahBin lb[3 * kBins];
 	__shared__ uint32_t s_owner;
 	const uint32_t base = blockIdx.x * kTile;
 	if (threadIdx.x == 0) s_owner = kNone;
 	if (threadIdx.x < 3 * kBins) { SahBin b; b.cnt = 0; for (int a = 0; a < 3; a++) { b.lo[a] = 0xFFFFFFFFu; b.hi[a] = 0u; } lb[threadIdx.x] = b; }
 	__syncthreads();
-	for (uint32_t p = base + threadIdx.x; p < min(base + kTile, n); p += BT) {
+	for (uint32_t p = base + threadIdx.x; p < min(base + kTile, n); p += kBigBlock) {
 		const uint32_t o = owner[p];
 		if (o != kNone && act[o].count > kSmallMax) { atomicMin(&s_owner, o); break; }
 	}
 	__syncthreads();
 	const uint32_t o0 = s_owner;
 	if (o0 == kNone) return;
-	for (uint32_t p = base + threadIdx.x; p < min(base + kTile, n); p += BT) {
+	for (uint32_t p = base + threadIdx.x; p < min(base + kTile, n); p += kBigBlock) {
 		const uint32_t o = owner[p];
 		if (o == kNone || act[o].count <= kSmallMax) continue;
 		const Box b = boxes[item[p]];
@@ -695,8 +697,8 @@ int build_tree_sah(SahScratch &S, hipStream_t q, uint32_t n, uint32_t max_leaf, 
 		if (n_big) { // nodes of more than kSmallMax items: centroid bounds, bins, split as three passes (atomics aggregated per tile in LDS)
 			hipLaunchKernelGGL(k_sah_clear_cb, dim3(grid(A)), dim3(BT), 0, q, A, S.cb);
 			hipLaunchKernelGGL(k_sah_clear_bins, dim3(grid(A * 3u * kBins)), dim3(BT), 0, q, A * 3u * kBins, S.bins);
-			hipLaunchKernelGGL(k_sah_cbounds_big, dim3((n + kTile - 1) / kTile), dim3(BT), 0, q, n, S.item[cur], S.owner[cur], S.act[cur], S.boxes, S.cb);
-			hipLaunchKernelGGL(k_sah_bin_big, dim3((n + kTile - 1) / kTile), dim3(BT), 0, q, n, S.item[cur], S.owner[cur], S.act[cur], S.boxes, S.cb, S.bins);
+			hipLaunchKernelGGL(k_sah_cbounds_big, dim3((n + kTile - 1) / kTile), dim3(kBigBlock), 0, q, n, S.item[cur], S.owner[cur], S.act[cur], S.boxes, S.cb);
+			hipLaunchKernelGGL(k_sah_bin_big, dim3((n + kTile - 1) / kTile), dim3(kBigBlock), 0, q, n, S.item[cur], S.owner[cur], S.act[cur], S.boxes, S.cb, S.bins);
 			hipLaunchKernelGGL(k_sah_split_big, dim3(grid(A)), dim3(BT), 0, q, A, S.act[cur], S.cb, S.bins, max_leaf, next_base, instances ? 0u : item_base, instances, d_out, S.split, S.flags, S.counts);
 		}
 		hipLaunchKernelGGL(k_sah_small, dim3((A + BT / 64 - 1) / (BT / 64)), dim3(BT), 0, q, A, S.act[cur], S.item[cur], S.boxes, max_leaf, next_base, instances ? 0u : item_base, instances, d_out, S.split, S.flags, S.counts);
