@@ -227,8 +227,13 @@ __global__ void k_exp_keys(Streams st, int any, uint32_t n_slots, int mode, uint
 			for (int b = 0; b < 4; b++) z |= ((x >> b & 1u) << (2 * b)) | ((y >> b & 1u) << (2 * b + 1));
 			sub = ((unsigned long long)(slot / Npad) << 32) | ((unsigned long long)tile << 8) | z;
 		} else if (mode == 6) sub = oct;
+		else if (mode == 7) { // all samples of a pixel side by side (pixel-major over the whole batch): what a "64 samples of one pixel per wave" slot layout would give
+			const uint32_t w = (uint32_t)__float_as_int(d4.w);
+			const uint32_t pix = any ? w % Npad : (w & 0xFFFFFFu); // (shadow rays carry their accumulator cell = sample * Npad + path index)
+			sub = ((unsigned long long)pix << 8) | (slot / Npad);
+		}
 		const unsigned long long window = win ? slot / win : 0u;
-		key = mode == 5 ? sub : ((window << 34) | sub);
+		key = (mode == 5 || mode == 7) ? sub : ((window << 34) | sub);
 		key = (key << 0); // (ties keep slot order: the radix sort is stable)
 	}
 	keys[slot] = key;

@@ -21,6 +21,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SCENES = [("terrain", "terrain", 1024, 1024, 32), ("C4", "material-ball", 1920, 1080, 32), ("C5", "instanced", 2048, 2048, 16)]
+if os.environ.get("WAVE_LINES_SCENES"):   # e.g. "headline:cornell:512:512:128"
+    SCENES = [(a, b, int(c), int(d), int(e)) for a, b, c, d, e in (x.split(":") for x in os.environ["WAVE_LINES_SCENES"].split(","))]
 ORDERS = [  # (label, reorder, window, shadow rays too[, Morton bits kept: 30 = 10 per axis])
     ("a: as emitted today (no indirection)", 0, 256, 0),
     ("control: identity through the indirection", 1, 256, 0),
@@ -39,7 +41,12 @@ ORDERS = [  # (label, reorder, window, shadow rays too[, Morton bits kept: 30 = 
     ("h: whole batch, bins of Morton top 15 bits (32^3 cells) x octant", 3, 0, 0, 15),
     ("h: whole batch, bins of Morton top 18 bits (64^3 cells) x octant", 3, 0, 0, 18),
     ("h + shadow rays: bins of Morton top 15 bits x octant, any-hit launches too", 3, 0, 1, 15),
+    ("i: all samples of a pixel side by side (pixel-major), whole batch", 7, 0, 0),
+    ("i + shadow rays: pixel-major, any-hit launches too", 7, 0, 1),
 ]
+if os.environ.get("WAVE_LINES_ORDERS"):   # comma separated first letters, e.g. "a,control,i"
+    keep = tuple(os.environ["WAVE_LINES_ORDERS"].split(","))
+    ORDERS = [o for o in ORDERS if o[0].startswith(keep)]
 
 
 def child(tag):
@@ -146,12 +153,12 @@ def main():
             out.append(hdr)
         if r["order"].startswith("control"):
             ctl_ms[r["scene"]] = r.get("k_trace_bounce_ms", 0.0)
-        rel = lpr / base_lines.get(r["scene"], lpr)
+        rel = lpr / base_lines[r["scene"]] if base_lines.get(r["scene"]) else float("nan")   # (tiny-mode scenes fetch nothing from global memory in the loops: no lines to count)
         ms = r.get("k_trace_bounce_ms", 0.0)
         relms = ms / ctl_ms[r["scene"]] if ctl_ms.get(r["scene"]) else float("nan")
         out.append(f"{r['scene']:8} {r['order']:74} {r['ch']['node_lines_per_step']:15.2f} {r['ch']['node_lanes']:6.1f} {r['ch']['tri_lines_per_round']:15.2f} {r['ch']['tri_lanes']:6.1f} "
                    f"{lpr:10.2f} {rel:6.2f} {ms:10.3f} {relms:7.2f} {r.get('k_trace_shadow_ms', 0.0):9.3f} {r.get('same', '?'):>5}")
-        if r["order"].startswith("h + shadow"):
+        if r["order"].startswith("i + shadow"):
             out.append("")
     txt = "\n".join(out) + "\n"
     open(os.path.join(ROOT, "gpurun_out", f"{tag}_wave_lines.txt"), "w").write(txt)
