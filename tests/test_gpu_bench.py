@@ -1,9 +1,11 @@
 """bench.py end to end on the GPU box: the single-GPU line carries the contract's fields, and the
 N>1 flow (row blocks, the primary's peer-read merge through HIP IPC mappings, tonemap) completes under
-torch.distributed -- two PROCESSES sharing the one GPU, which exercises the code path the driver runs
-on 8 GPUs (the mapping is then a peer mapping over xGMI instead of a second mapping of local memory).
-The strip-transfer fallback is covered too (over gloo).  Everything runs as subprocesses under a timeout
-so a collective mismatch cannot hang the suite."""
+torch.distributed -- two, three and FOUR processes sharing the one GPU (the box admits six), which exercises
+the code path the driver runs on 8 GPUs (the mapping is then a peer mapping over xGMI instead of a second
+mapping of local memory); the handle / mapping / merge count of an 8-GPU frame is exercised by one primary
+that maps SEVEN peer rings owned by three other processes (test_primary_maps_seven_peer_rings).  The
+strip-transfer fallback is covered too (over gloo), for a failed open and a failed export.  Everything
+runs as subprocesses under a timeout so a collective mismatch cannot hang the suite."""
 import json
 import os
 import socket
