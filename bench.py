@@ -28,8 +28,11 @@ time (max over ranks); rays = primary + indirect + occlusion rays handed to an i
 (BASELINE.md section 3).  `roofline` prices ONE kernel symbol -- the one with the largest isolated
 time -- against HBM: algorithmic bytes (SURVEY.md 8d split per kernel) / its HIP-event
 time; `roofline_per_kernel` holds the same object for every symbol that moves ray streams.
-`cpu_baseline` times the CPU restatement under oracle/ (the checker, never the product) on a bounded
-sample of the same workload on the host cores.
+`roofline.traffic`, `lane_util` and `roofline_issue` come from PMC counters collected LIVE at the end of the
+run (three rocprofv3 child runs of `bench.py --steps 1` on the same workload: FETCH_SIZE, WRITE_SIZE, one SQ pass;
+~10 s; `--no-live-counters` or a failing profiler falls back to the newest committed profile, and
+`counters_source` says which).  `cpu_baseline` times the CPU restatement under oracle/ (the checker, never the
+product) on a bounded sample of the same workload on the host cores.
 
 `--inproc` runs the same frame the way the reference itself does: ONE process, one worker thread per
 GPU (polaris_amd/host/renderer.cpp), blocks merged into the primary by polaris_hip_merge over xGMI
@@ -123,6 +126,58 @@ def committed_counters(symbol: str, workload_is_headline: bool):
     return traffic, lane_util, valu, ("; ".join(src) + "; collected on the builder's MI355X lease, not re-measured in this run") if src else None
 
 
+def live_counters(argv, timeout_s: float = 150.0):
+    """PMC counters of THIS build on THIS machine, collected at the end of the run: three rocprofv3 passes (FETCH_SIZE, WRITE_SIZE, one
+    SQ pass -- separate passes with --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes and the pool
+    requires) over `python3 bench.py --steps 1 --warmup 0` of the same workload, each a CHILD process.  Returns {kernel symbol:
+    {"traffic": HBM bytes per launch (FETCH_SIZE is in KiB and counts 64 B per 128-B request of a wide stream on gfx950: read side
+    doubled), "lane_util": .., "valu": wave-level VALU instructions per launch}} or None if any pass fails (the committed profiles
+    are used then).  Never raises: the bench line must not depend on the profiler."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    passes = (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU"))
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    launches = collections.defaultdict(set)
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        for ctrs in passes:
+            d = tempfile.mkdtemp(prefix="polaris_pmc_", dir="/tmp")
+            try:
+                cmd = [exe, "--kernel-trace", "--pmc", *ctrs, "--output-format", "csv", "-d", d, "--", "python3", os.path.abspath(__file__),
+                       "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-kernel-timers", "--no-live-counters", *argv]
+                p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env, cwd="/tmp")
+                found = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
+                if p.returncode != 0 or not found:
+                    return None, f"rocprofv3 pass {ctrs[0]} failed (exit {p.returncode}): {(p.stderr or '')[-200:]}"
+                for r in csv.DictReader(open(found[0])):
+                    sym = r["Kernel_Name"].split("(")[0].replace("void ", "")
+                    agg[sym][r["Counter_Name"]] += float(r["Counter_Value"])
+                    if r["Counter_Name"] == ctrs[0]:
+                        launches[(sym, ctrs[0])].add(r["Dispatch_Id"])
+            finally:
+                shutil.rmtree(d, ignore_errors=True)
+    except Exception as e:  # a timeout, a missing tool, an unreadable csv: fall back to the committed profiles
+        return None, f"{type(e).__name__}: {e}"
+    out = {}
+    for sym, c in agg.items():
+        n = len(launches.get((sym, "FETCH_SIZE"), ())) or len(launches.get((sym, "SQ_INSTS_VALU"), ()))
+        if "pol::" not in sym or not n:
+            continue
+        out[sym] = {"traffic": (c.get("FETCH_SIZE", 0.0) * 1024 * 2 + c.get("WRITE_SIZE", 0.0) * 1024) / n,
+                    "lane_util": (c["SQ_THREAD_CYCLES_VALU"] / (64 * c["SQ_ACTIVE_INST_VALU"])) if c.get("SQ_ACTIVE_INST_VALU") else None,
+                    "valu": (c["SQ_INSTS_VALU"] / n) if c.get("SQ_INSTS_VALU") else None}
+    return out, "rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE; SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU / 64 / SQ_ACTIVE_INST_VALU) of `bench.py --steps 1` on the same workload, run as child processes at the end of THIS run"
+
+
 # The roof these kernels are actually under (DESIGN.md 3.1): vector-instruction ISSUE.  tests/tools/valu_rate.hip measures 0.86-0.93 ns
 # per wave64 VALU instruction per SIMD with 2-8 waves resident (plain v_mul_f32 / v_fma_f32; a packed f32 instruction takes two
 # slots): the chip issues at most CUs x 4 SIMDs / 0.9 ns wave-level vector instructions per second.
@@ -140,7 +195,7 @@ def issue_roofline(valu_per_launch, launches, ms_per_frame, lane_util, cus: int)
     return {"bound": "valu-issue", "achieved": ach, "peak": peak, "unit": "G wave64 VALU instructions/s", "frac": ach / peak,
             "frac_useful_lanes": (ach / peak * lane_util) if lane_util else None, "valu_instructions_per_launch": valu_per_launch,
             "peak_from": f"{cus} CUs x 4 SIMDs / {VALU_NS_PER_INST_PER_SIMD} ns per wave64 VALU instruction per SIMD (tests/tools/valu_rate.hip: 0.86-0.93 ns with 2-8 waves resident)",
-            "instructions_from": "committed SQ_INSTS_VALU of the same kernel symbol on the same workload (profiles/r*_sq_counters.json); time: this run's HIP events"}
+            "instructions_from": "SQ_INSTS_VALU of the same kernel symbol on the same workload (see counters_source); time: this run's HIP events"}
 
 
 def host_cpu() -> str:
@@ -232,6 +287,8 @@ def main() -> None:
     ap.add_argument("--bvh-max-leaf", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--no-live-counters", action="store_true", help="do not collect the PMC counters (HBM traffic, live lanes, VALU instructions) with rocprofv3 child runs "
+                    "at the end (N = 1 only; ~25 s); `roofline.traffic` then comes from the newest committed profile of the headline workload")
     ap.add_argument("--save-png", default="")
     ap.add_argument("--save-accumulator", default="", help="rank 0 writes its frame accumulator of the last frame as .npy (tests)")
     ap.add_argument("--opt", action="append", default=[], help="tracer option key=value (polaris_hip_set_option)")
@@ -570,6 +627,21 @@ def main() -> None:
             alg_ref, alg_lay = kernel_algorithmic_bytes(fst, tr.shade_counts(B), B, packet_camera=iso["intersect_packet"][1] > 0)
             headline = (W, H, spp, B, args.scene, world, args.opt) == (512, 512, 128, 5, "cornell", 1, [])
             per_kernel = {}
+            live, live_src = (None, None)
+            under_profiler = "rocprof" in (os.environ.get("LD_PRELOAD", "") + os.environ.get("ROCP_TOOL_LIBRARIES", "") + os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD", "")).lower()
+            if world == 1 and not args.no_live_counters and not args.emulate_rank and not under_profiler:   # (never a profiler inside a profiler)
+                workload = [a for a in sys.argv[1:] if a not in ("--no-cpu-baseline",)]
+                # (the child runs repeat the workload's own arguments; --steps / --warmup are overridden by the later occurrence rule of argparse)
+                skip, keep = {"--steps", "--warmup", "--save-png", "--save-accumulator"}, []
+                it = iter(workload)
+                for a in it:
+                    if a in skip:
+                        next(it, None)
+                        continue
+                    keep.append(a)
+                live, live_src = live_counters(keep)
+                if live is None and rank == 0:
+                    print(f"bench.py: live PMC counters unavailable ({live_src}); using the committed profiles", file=sys.stderr)
             for k in PRICED:
                 kms, kn_ = iso[k]
                 if kms <= 0 or not kn_:
@@ -579,6 +651,9 @@ def main() -> None:
                 alg = min(alg_ref[k], alg_lay[k])
                 ach = alg / (kms * 1e-3) / 1e9
                 traffic, lane_util, valu, source = committed_counters(symbols[k], headline)
+                if live and symbols[k] in live:   # measured in this run: preferred over the committed numbers
+                    e = live[symbols[k]]
+                    traffic, lane_util, valu, source = e["traffic"], e["lane_util"], e["valu"], live_src
                 per_kernel[symbols[k]] = {"bound": "hbm", "kernel": symbols[k], "timer": k, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                           "frac": ach / HBM_PEAK_GBS, "priced_by": "layout" if alg_lay[k] < alg_ref[k] else "reference",
                                           "frac_reference": alg_ref[k] / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_layout": alg_lay[k] / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -9,7 +9,7 @@ for rep in 1 2 3; do
 	for o in "$a" "$b"; do
 		opts=""
 		if [ "$o" != "-" ]; then for kv in ${o//,/ }; do opts="$opts --opt $kv"; done; fi
-		line=$(timeout -k 10 300 python3 bench.py --no-cpu-baseline $opts "$@" 2>gpurun_out/${tag}_err.txt | grep '^{') || { echo "[$o] FAILED" >> "$out"; tail -5 gpurun_out/${tag}_err.txt >> "$out"; exit 1; }
+		line=$(timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-live-counters $opts "$@" 2>gpurun_out/${tag}_err.txt | grep '^{') || { echo "[$o] FAILED" >> "$out"; tail -5 gpurun_out/${tag}_err.txt >> "$out"; exit 1; }
 		python3 - "$o" "$line" >> "$out" <<'PY'
 import json, sys
 o, line = sys.argv[1:3]

@@ -7,7 +7,7 @@ names=$1; shift
 for n in $names; do
   lib=polaris_amd/lib/exp/$n.so
   [ "$n" = base ] && lib=polaris_amd/lib/libpolaris_hip.so
-  POLARIS_HIP_LIB=$lib timeout -k 10 240 python bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" 2>/dev/null | python3 -c "
+  POLARIS_HIP_LIB=$lib timeout -k 10 240 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-live-counters "$@" 2>/dev/null | python3 -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

@@ -74,7 +74,7 @@ def main():
         base = ["--steps", "3", "--warmup", "1"]
         if "--steps" in args:
             base = ["--warmup", "1"]
-        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *base, "--no-cpu-baseline", *args], capture_output=True, text=True, cwd=ROOT)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *base, "--no-cpu-baseline", "--no-live-counters", *args], capture_output=True, text=True, cwd=ROOT)
         line = [l for l in p.stdout.splitlines() if l.startswith("{")]
         if p.returncode != 0 or not line:
             out["configs"][key] = {"what": what, "error": p.stderr[-400:]}

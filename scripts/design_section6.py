@@ -56,7 +56,9 @@ new6 = f'''## 6. Measured (MI355X, round 5) — evidence under `profiles/{tag}_*
 time (HIP events of the extra frame `bench.py` traces after its timed region; `{tag}_kernel_stats_overlap1.csv` — rocprofv3
 `--kernel-trace --stats` of the same command — agrees: `k_trace<false, 16, 2, true>` {float(top['AverageNs'])/1e3:.1f} µs average over {top['Calls']} calls against
 {R['avg_launch_ms']*1e3:.1f} µs).  `frac` = HBM roofline on the smaller of the two prices (§3); traffic = FETCH_SIZE × 2 + WRITE_SIZE (`{tag}_traffic.json`);
-issue = `roofline_issue`: share of the chip's vector-issue rate, and the same × live lanes (`{tag}_sq_counters.json`):
+issue = `roofline_issue`: share of the chip's vector-issue rate, and the same × live lanes (`{tag}_sq_counters.json`).  Since round 5
+`bench.py` collects these counters itself at the end of every N = 1 run (three rocprofv3 child passes, ~10 s): the driver's own
+bench line carries the traffic of the build it timed (`counters_source`); the committed files are the fallback:
 
 | kernel symbol (= `roofline_per_kernel` key) | ms / frame | launches | `frac` (priced by) | `frac_reference` | HBM traffic (PMC) vs algorithmic, per launch | live lanes per VALU instr. | issue / × lanes |
 |---|---|---|---|---|---|---|---|

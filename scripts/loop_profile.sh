@@ -5,4 +5,4 @@
 # (kernels.h PROF, polaris_hip.hip).  Evidence of round 4: profiles/r04_loop_profile_*.txt.
 cd "${GRAFT_REPO_ROOT:-.}" || exit 1
 [ -f polaris_amd/lib/exp/prof.so ] || { echo "build polaris_amd/lib/exp/prof.so first: scripts/build_variant.sh prof -DPOLARIS_PROFILE_LOOPS"; exit 1; }
-POLARIS_DEBUG=1 POLARIS_HIP_LIB=polaris_amd/lib/exp/prof.so timeout -k 10 300 python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" 2>&1 | grep "per ray" | tail -2
+POLARIS_DEBUG=1 POLARIS_HIP_LIB=polaris_amd/lib/exp/prof.so timeout -k 10 300 python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-live-counters "$@" 2>&1 | grep "per ray" | tail -2

@@ -12,9 +12,9 @@ CFG[C5]="--scene instanced --width 2048 --height 2048 --spp 16"
 CFG[terrain]="--scene terrain --width 1024 --height 1024 --spp 32"
 for c in ${CONFIGS:-C4 C5 terrain}; do
   args="${CFG[$c]} $EXTRA_BENCH_ARGS"
-  python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline $args > gpurun_out/${tag}_big_${c}_bench.json 2> gpurun_out/${tag}_big_${c}_bench.err || exit 1
+  python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-live-counters $args > gpurun_out/${tag}_big_${c}_bench.json 2> gpurun_out/${tag}_big_${c}_bench.err || exit 1
   rm -rf gpurun_out/bigprof
-  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/bigprof -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --opt overlap=1 $args > /dev/null 2>&1 || exit 1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/bigprof -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-live-counters --opt overlap=1 $args > /dev/null 2>&1 || exit 1
   cp $(ls gpurun_out/bigprof/*/*kernel_stats.csv | head -1) gpurun_out/${tag}_big_${c}_kernel_stats_overlap1.csv
   for pass in sq cache fetch write; do
     case $pass in

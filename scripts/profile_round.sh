@@ -12,7 +12,7 @@ cd $R
 python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 for ov in 1 4; do
   rm -rf gpurun_out/prof_$ov
-  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$ov -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --opt overlap=$ov > gpurun_out/${tag}_bench_under_rocprof_overlap$ov.json 2>/dev/null
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$ov -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-live-counters --opt overlap=$ov > gpurun_out/${tag}_bench_under_rocprof_overlap$ov.json 2>/dev/null
   f=$(ls gpurun_out/prof_$ov/*/*kernel_stats.csv | head -1)
   cp $f gpurun_out/${tag}_kernel_stats_overlap$ov.csv
 done
