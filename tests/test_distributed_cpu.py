@@ -247,8 +247,9 @@ def _peer_worker(rank, world, port, out_path, scheduler, slow_rank, H=H, fail_ex
     while pending:
         merge_s.append(px.finish(pending.pop(0)))
     # the held-back rank costs everybody 0.15 s per frame in wait(); what finish() returns -- numpy adds of a 40-pixel-wide
-    # frame on the primary, nothing elsewhere -- must not contain it
-    assert all(t == 0.0 for t in merge_s) if rank != 0 else max(merge_s) < 0.1, merge_s
+    # frame on the primary, nothing elsewhere -- must not contain it (summed over the frames, so that one scheduling hiccup
+    # of an oversubscribed test machine does not matter: with the wait inside, the sum would be >= 0.15 s x frames)
+    assert all(t == 0.0 for t in merge_s) if rank != 0 else sum(merge_s) < 0.5 * 0.15 * len(merge_s), merge_s
     if rank == 0:
         np.save(out_path, np.stack(shm.frames))
         np.save(out_path + ".rows.npy", np.array(all_rows))
