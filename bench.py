@@ -99,8 +99,9 @@ def kernel_algorithmic_bytes(st, shade_counts, B: int, packet_camera: bool):
 
 
 def committed_counters(symbol: str, workload_is_headline: bool):
-    """PMC data cannot be collected inside this run (rocprofv3 --pmc passes: scripts/traffic.sh, scripts/pmc.sh); they are read
-    from the newest committed profile of the headline workload, keyed by kernel symbol.  Returns (hbm bytes per launch,
+    """The FALLBACK for live_counters() below (which collects the PMC counters of this build on this machine with rocprofv3 child runs
+    at the end of every N = 1 run): the newest committed profile of the headline workload (scripts/traffic.sh, scripts/pmc.sh), keyed by
+    kernel symbol -- used when the profiler is missing, a pass fails, or --no-live-counters is given.  Returns (hbm bytes per launch,
     lane utilisation, wave-level VALU instructions per launch, description of the source) -- None where there is no committed
     number for this symbol."""
     if not workload_is_headline:
@@ -126,13 +127,16 @@ def committed_counters(symbol: str, workload_is_headline: bool):
     return traffic, lane_util, valu, ("; ".join(src) + "; collected on the builder's MI355X lease, not re-measured in this run") if src else None
 
 
-def live_counters(argv, timeout_s: float = 150.0):
+def live_counters(argv, timeout_s: float = 150.0, total_timeout_s: float = 240.0):
     """PMC counters of THIS build on THIS machine, collected at the end of the run: three rocprofv3 passes (FETCH_SIZE, WRITE_SIZE, one
     SQ pass -- separate passes with --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes and the pool
     requires) over `python3 bench.py --steps 1 --warmup 0` of the same workload, each a CHILD process.  Returns {kernel symbol:
     {"traffic": HBM bytes per launch (FETCH_SIZE is in KiB and counts 64 B per 128-B request of a wide stream on gfx950: read side
     doubled), "lane_util": .., "valu": wave-level VALU instructions per launch}} or None if any pass fails (the committed profiles
-    are used then).  Never raises: the bench line must not depend on the profiler."""
+    are used then).  Never raises: the bench line must not depend on the profiler.  The program after `--` is THIS interpreter's
+    resolved binary (os.path.realpath(sys.executable)), never a name looked up on PATH: a shim or wrapper there would be an exec hop
+    behind the profiler's preloaded library, which has already initialised the GPU (the pool forbids that), and a venv's `python3`
+    may be another Python altogether.  timeout_s bounds one pass, total_timeout_s all three."""
     import collections
     import csv
     import glob
@@ -148,13 +152,20 @@ def live_counters(argv, timeout_s: float = 150.0):
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
+    python = os.path.realpath(sys.executable)
+    t_start = time.perf_counter()
     try:
         for ctrs in passes:
+            left = total_timeout_s - (time.perf_counter() - t_start)
+            if left < 5.0:
+                return None, f"the counter passes ran out of their {total_timeout_s:.0f} s budget before {ctrs[0]}"
             d = tempfile.mkdtemp(prefix="polaris_pmc_", dir="/tmp")
             try:
-                cmd = [exe, "--kernel-trace", "--pmc", *ctrs, "--output-format", "csv", "-d", d, "--", "python3", os.path.abspath(__file__),
-                       "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-kernel-timers", "--no-live-counters", *argv]
-                p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env, cwd="/tmp")
+                # (the workload's own arguments first, the overrides LAST: argparse keeps the last occurrence, whatever form -- `--steps N` or
+                # `--steps=N` -- the caller used)
+                cmd = [exe, "--kernel-trace", "--pmc", *ctrs, "--output-format", "csv", "-d", d, "--", python, os.path.abspath(__file__),
+                       *argv, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-kernel-timers", "--no-live-counters"]
+                p = subprocess.run(cmd, capture_output=True, text=True, timeout=min(timeout_s, left), env=env, cwd="/tmp")
                 found = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
                 if p.returncode != 0 or not found:
                     return None, f"rocprofv3 pass {ctrs[0]} failed (exit {p.returncode}): {(p.stderr or '')[-200:]}"
@@ -226,6 +237,8 @@ def run_inproc(args) -> None:
         raise SystemExit(f"bench.py --inproc --gpus {args.gpus}: only {visible} HIP device(s) visible on this host")
     W, H, spp, B = args.width, args.height, args.spp, args.bounces
     sc = scenes.SCENES[args.scene](W / H)
+    identities = [{"tracer": t, **T.device_identity(d)} for t, d in enumerate(devices)]
+    peer_row = {str(d): (T.can_access_peer(devices[0], d) if d != devices[0] else None) for d in sorted(set(devices))}
     r = host_api.Renderer(sc, devices, primary=0, scheduler=host_api.PERFECT if args.scheduler == "perfect" else host_api.NAIVE, width=W, height=H,
                           spp=spp, bounces=B, min_rr=args.rr, exposure=1.2, seed=1)
     try:
@@ -249,6 +262,7 @@ def run_inproc(args) -> None:
             rays += sum(r.tracer_stats(i)[0].total_rays() for i in range(len(devices)))
         elapsed = time.perf_counter() - t0
         trace_ms = [round(r.tracer_stats(i)[1], 3) for i in range(len(devices))]
+        merge_counts = r.merge_counts()
         if args.save_accumulator:
             np.save(args.save_accumulator, r.read()[1])
         if args.save_png:
@@ -262,7 +276,9 @@ def run_inproc(args) -> None:
         "ms_per_step": ms, "ms_per_frame": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{sc.name} {W}x{H} {spp}spp {B} bounces rr>={args.rr}, {sc.num_triangles} tris, row blocks {rows} of the last frame "
                                f"({args.scheduler} scheduler), merge into the primary + tonemap",
-                   "mode": "in-process: one worker thread per tracer, polaris_hip_merge (peer access), no collective", "tracers": len(devices), "devices": devices,
+                   "mode": "in-process: one worker thread per tracer, polaris_hip_merge (peer access), no collective", "tracers": len(devices), "device_indices": devices,
+                   "devices": identities, "distinct_gpus": len({(d["pci_bus_id"], d["uuid"]) for d in identities}),
+                   "exchange_detail": {"mode": "inproc", "primary_device": devices[0], "can_access_peer_from_primary": peer_row, "merge_counts": merge_counts},
                    "scheduler": args.scheduler, "rows_first_timed_frame": all_rows[0] if all_rows else None, "rows_last_frame": rows,
                    "trace_ms_last_frame_per_tracer": trace_ms, "frame": [W, H], "spp": spp, "bounces": B, "rays_per_frame": rays // max(args.steps, 1),
                    "paths_per_s": W * H * spp * args.steps / elapsed},
@@ -303,6 +319,10 @@ def main() -> None:
                     "ahead as the exchange protocol lets them (a ring slot reused too early then shows in the assembled frame)")
     ap.add_argument("--no-second-scheduler", action="store_true", help="N > 1: skip the second timed region (the perfect scheduler when --scheduler naive)")
     ap.add_argument("--same-device", action="store_true", help="testing aid: every rank uses GPU 0 (needs --backend gloo)")
+    ap.add_argument("--control-timeout", type=float, default=120.0, help="N > 1: timeout in seconds of the gloo control group (set-up exchange, 32 bytes per rank "
+                    "and frame): a rank that dies surfaces as an error on the others within this time")
+    ap.add_argument("--test-setup-failure", type=int, default=-1, help="testing aid: rank R fails during set-up (as a tracer that cannot be created would); every "
+                    "rank must learn of it and exit non-zero before any collective can hang")
     ap.add_argument("--emulate-rank", default="", help="R/N: on ONE GPU, trace only the row block rank R of N would own "
                     "(tuning aid for the strong-scaling path; not a valid bench line)")
     ap.add_argument("--rows", default="", help="with --emulate-rank: the N block heights to use instead of the naive scheduler's (comma separated)")
@@ -350,32 +370,78 @@ def main() -> None:
 
     dist = None
     if world > 1:
+        import datetime
+
         import torch.distributed as dist
 
-        if args.same_device:
-            local_rank = 0
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="gloo")  # CONTROL plane only (handles, 32 bytes per rank and frame, the final reductions)
-    if not torch.cuda.is_available():
+        # CONTROL plane only (handles and identities at set-up, 32 bytes per rank and frame, the final reductions).  A BOUNDED timeout: a
+        # rank that dies must surface as an error on the others within two minutes, not after the default thirty.
+        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=args.control_timeout))
+    elif not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the tracer has no CPU fallback")
-    dev = torch.device("cuda", local_rank)
 
     from polaris_amd import ctypes_api as T
     from polaris_amd import scenes
-    from polaris_amd.distributed import SchedulerFeedback, StripExchange, block_of, naive_rows
+    from polaris_amd.distributed import SchedulerFeedback, StripExchange, block_of, device_for_rank, gather_setup_errors, naive_rows
 
     xdev = strip_group = None
     from polaris_amd.tracer import ChangeType, HipTracer, UpdateMode
 
     W, H, spp, B = args.width, args.height, args.spp, args.bounces
-    sc = scenes.SCENES[args.scene](W / H)
-    bvh_info = None
-    if args.bvh != "scene":
-        from polaris_amd import bvh_build
+    # ---- set-up: this rank's device, scene and tracer.  One process per GPU, one tracer per device -- the reference enumerates the
+    # devices inside ONE process and gives each a tracer (renderer/default.go:204-256).  Nothing in here is a collective; whatever fails
+    # is carried to EVERY rank by the gather below, before the first collective that would otherwise wait for the failed rank.
+    tr = sc = bvh_info = identity = None
+    dev_index, dev_why, setup_err = 0, "", ""
+    try:
+        visible = torch.cuda.device_count()
+        # a launcher may hand every rank all GPUs (LOCAL_RANK picks) or mask each rank to one (index 0 everywhere): device_for_rank
+        dev_index, dev_why = (0, "--same-device (testing aid)") if args.same_device else device_for_rank(local_rank, visible)
+        torch.cuda.set_device(dev_index)
+        if not torch.cuda.is_available():
+            raise RuntimeError("no usable HIP device: the tracer has no CPU fallback")
+        if args.test_setup_failure == rank:
+            raise RuntimeError("injected set-up failure (--test-setup-failure)")
+        sc = scenes.SCENES[args.scene](W / H)
+        if args.bvh != "scene":
+            from polaris_amd import bvh_build
 
-        t_b = time.perf_counter()
-        sc, bvh_info = bvh_build.rebuild_on_device(sc, max_leaf_tris=args.bvh_max_leaf, device=local_rank, algorithm="lbvh" if args.bvh == "device-lbvh" else "sah")
-        bvh_info["wall_ms_with_permutation"] = (time.perf_counter() - t_b) * 1e3
+            t_b = time.perf_counter()
+            sc, bvh_info = bvh_build.rebuild_on_device(sc, max_leaf_tris=args.bvh_max_leaf, device=dev_index, algorithm="lbvh" if args.bvh == "device-lbvh" else "sah")
+            bvh_info["wall_ms_with_permutation"] = (time.perf_counter() - t_b) * 1e3
+        tr = HipTracer(f"hip-{rank}", dev_index)
+        tr.Init()
+        if args.samples_per_batch:
+            tr.set_option("samples_per_batch", args.samples_per_batch)
+        tr.set_option("time_kernels", 0)  # no event pairs inside the timed region; per-kernel times come from one extra frame afterwards
+        for kv in args.opt:  # before the upload: some options shape the scene layout
+            k, v = kv.split("=")
+            tr.set_option(k, int(v))
+        tr.UpdateState(UpdateMode.Synchronous, ChangeType.FrameDimensions, (W, H))
+        tr.UpdateState(UpdateMode.Synchronous, ChangeType.SceneData, sc)
+        tr.UpdateState(UpdateMode.Synchronous, ChangeType.CameraData, sc)
+        # which physical GPU this rank traces on: device indices are per process, the PCI bus id and the UUID are not
+        identity = {"rank": rank, "local_rank": local_rank, "pid": os.getpid(), **tr.device_identity(), "visible_devices": visible, "device_chosen_by": dev_why,
+                    "HIP_VISIBLE_DEVICES": os.environ.get("HIP_VISIBLE_DEVICES"), "ROCR_VISIBLE_DEVICES": os.environ.get("ROCR_VISIBLE_DEVICES")}
+    except Exception as e:  # noqa: BLE001 -- reported below, on every rank
+        setup_err = f"{type(e).__name__}: {e}"
+    if world > 1:
+        errs = gather_setup_errors(dist, rank, world, setup_err)
+        if errs:
+            if rank == 0:
+                print("bench.py: set-up failed, no frame was traced -- " + "; ".join(errs), file=sys.stderr)
+            if tr is not None:
+                tr.Close()
+            dist.destroy_process_group()
+            raise SystemExit(1)
+        identities = [None] * world
+        dist.all_gather_object(identities, identity)
+    else:
+        if setup_err:
+            raise SystemExit(f"bench.py: set-up failed: {setup_err}")
+        identities = [identity]
+    distinct_gpus = len({(d["pci_bus_id"], d["uuid"]) for d in identities})
+    dev = torch.device("cuda", dev_index)
     seeds = scenes.make_seeds(spp, B)
     rows = naive_rows(world, H)                      # tracer/scheduler.go:83-106, equal speeds
     block_y, block_h = block_of(rank, rows)
@@ -386,18 +452,6 @@ def main() -> None:
             raise SystemExit(f"bench.py --rows: need {en} positive block heights that add up to {H}")
         block_y, block_h = block_of(er, erows)
         rows = [block_h]
-
-    tr = HipTracer(f"hip-{rank}", local_rank)
-    tr.Init()
-    if args.samples_per_batch:
-        tr.set_option("samples_per_batch", args.samples_per_batch)
-    tr.set_option("time_kernels", 0)  # no event pairs inside the timed region; per-kernel times come from one extra frame afterwards
-    for kv in args.opt:  # before the upload: some options shape the scene layout
-        k, v = kv.split("=")
-        tr.set_option(k, int(v))
-    tr.UpdateState(UpdateMode.Synchronous, ChangeType.FrameDimensions, (W, H))
-    tr.UpdateState(UpdateMode.Synchronous, ChangeType.SceneData, sc)
-    tr.UpdateState(UpdateMode.Synchronous, ChangeType.CameraData, sc)
 
     def make_req(by, bh):
         r = T.BlockRequest()
@@ -411,7 +465,13 @@ def main() -> None:
     # The block scheduler runs identically on every rank from all-gathered (rows, time) pairs, also one frame behind.
     px = ex = fb = None
     exchange = "none (1 GPU)"
+    # config.exchange_detail: what the exchange REALLY was -- per peer the branch its block reaches the primary by, what rank 0 sees of the
+    # other GPUs, and (at the end of the run) how many merges took which branch inside the library.  A fallback shows here, not in a timeout.
+    detail = {"mode": "none (1 GPU)", "peers": []}
     if world > 1:
+        if rank == 0:   # the hipDeviceCanAccessPeer row of the primary's device over the devices THIS process sees (one entry under a per-rank mask)
+            detail["primary_device"] = dev_index
+            detail["can_access_peer_from_primary"] = {str(j): (T.can_access_peer(dev_index, j) if j != dev_index else None) for j in range(torch.cuda.device_count())}
         from polaris_amd.distributed import HipPort, PeerExchange
 
         if args.exchange == "ipc":
@@ -428,6 +488,9 @@ def main() -> None:
             if px.setup():
                 exchange = (f"hip-ipc: rank 0's merge stream reads every rank's rows through an IPC mapping of its trace accumulator ring "
                             f"(depth {px.depth}), one frame behind the tracing; control = 32 B per rank and frame over gloo; no RCCL")
+                detail["mode"] = "hip-ipc"
+                if rank == 0:   # what every mapping really is: the peer's GPU by bus id, local or across xGMI (polaris_hip_peer_info)
+                    detail["peers"] = [{"rank": r, **tr.peer_info(p)} for r, p in sorted(px.peers().items())]
             else:
                 if rank == 0:
                     print(f"bench.py: HIP IPC mapping failed ({px.why_not}); falling back to strip transfers on {args.backend}", file=sys.stderr)
@@ -435,31 +498,51 @@ def main() -> None:
                 px = None
         if px is None:
             backend = args.backend
+            if backend == "nccl" and distinct_gpus < world:
+                # decided over gloo, from the gathered identities, BEFORE any communicator exists: RCCL needs one GPU per rank
+                if rank == 0:
+                    print(f"bench.py: {world} ranks on {distinct_gpus} distinct GPU(s): RCCL needs one device per rank; the strips travel over gloo through the host", file=sys.stderr)
+                detail["rccl"] = f"not tried: {world} ranks share {distinct_gpus} GPU(s)"
+                backend = "gloo"
             if backend == "nccl":                      # (RCCL communicators only exist on this path)
                 # the last resort must not be able to fail: if RCCL cannot be brought up on EVERY rank (one warm-up all_reduce
-                # each, the verdicts gathered over gloo), the strips travel over gloo, staged through the host
+                # each, the verdicts gathered over gloo), the strips travel over gloo, staged through the host.  The probe has to RAISE
+                # on this rank, not end the process: torch's watchdog would abort on a timed-out collective unless asynchronous error
+                # handling is off, and Work.wait(timeout) only blocks (and throws) with blocking wait on -- both are read when the group
+                # is created.
                 err = ""
+                os.environ["TORCH_NCCL_ASYNC_ERROR_HANDLING"] = "0"
+                os.environ["TORCH_NCCL_BLOCKING_WAIT"] = "1"
                 try:
-                    import datetime
-
                     strip_group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))  # (a rank whose RCCL bring-up fails must not leave the others waiting for ten minutes)
                     probe = torch.ones(1, device=dev)
-                    dist.all_reduce(probe, group=strip_group)
+                    work = dist.all_reduce(probe, group=strip_group, async_op=True)
+                    work.wait(timeout=datetime.timedelta(seconds=60))
                     torch.cuda.synchronize()
                     if int(probe.item()) != world:
                         err = f"rank {rank}: RCCL warm-up all_reduce returned {probe.item()}, expected {world}"
-                except Exception as e:
-                    err = f"rank {rank}: {e}"
+                except Exception as e:  # noqa: BLE001
+                    err = f"rank {rank}: {type(e).__name__}: {e}"
                 errs = [None] * world
                 dist.all_gather_object(errs, err)
                 if any(errs):
                     if rank == 0:
                         print(f"bench.py: RCCL is not usable for the strips ({next(e for e in errs if e)[:200]}); using gloo through the host", file=sys.stderr)
+                    detail["rccl"] = "bring-up failed: " + next(e for e in errs if e)[:200]
+                    if strip_group is not None:     # do not keep a half-initialised communicator around: destroy_process_group at exit may block on it
+                        try:
+                            dist.destroy_process_group(strip_group)
+                        except Exception:  # noqa: BLE001
+                            pass
                     backend, strip_group = "gloo", None
+                else:
+                    detail["rccl"] = "warm-up all_reduce succeeded on every rank"
             xdev = dev if backend == "nccl" else torch.device("cpu")
             ex = StripExchange(dist, rank, world, W, H, dev, via_host=backend != "nccl", group=strip_group)
             fb = SchedulerFeedback(dist, rank, world, H, xdev, kind=args.scheduler, group=strip_group)
             exchange = (exchange if args.exchange == "ipc" else "") + f"{backend} point-to-point transfers of the row-block strips to rank 0, one frame behind the tracing"
+            detail["mode"] = "strips-rccl" if backend == "nccl" else "strips-gloo"
+            detail["peers"] = [{"rank": r, "branch": detail["mode"]} for r in range(1, world)]
     totals = {k: 0 for k in ("primary_rays", "indirect_rays", "occlusion_rays", "shaded_hits", "shaded_misses", "emitter_hits", "unoccluded")}
     pending = []
     rows_log = []
@@ -602,6 +685,10 @@ def main() -> None:
                                    f"row blocks {main_rows} ({'naive' if world == 1 else args.scheduler} scheduler{'' if world == 1 else ', rows of the last frame'}), "
                                    f"strips to the primary + tonemap",
                        "ranks": world, "scheduler": "naive" if world == 1 else args.scheduler,
+                       # which physical GPU every rank traced on (PCI bus id + UUID: device indices are per process) and how many DISTINCT ones
+                       # took part: n_gpus is the launch's WORLD_SIZE, distinct_gpus is what the hardware says
+                       "devices": identities, "distinct_gpus": distinct_gpus,
+                       "exchange_detail": {**detail, "merge_counts": tr.merge_counts()},
                        "rows_first_timed_frame": rows_log[0] if rows_log else None, "rows_last_frame": rows_log[-1] if rows_log else None,
                        "bvh": "as compiled with the scene" if bvh_info is None else {"built_on_device": bvh_info}, "exchange": exchange, "perfect_scheduler" if (second or {}).get("scheduler") == "perfect" else "second_scheduler": second,
                        "frame": [W, H], "spp": spp, "bounces": B, "rays_per_frame": rays // args.steps,
@@ -631,15 +718,19 @@ def main() -> None:
             under_profiler = "rocprof" in (os.environ.get("LD_PRELOAD", "") + os.environ.get("ROCP_TOOL_LIBRARIES", "") + os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD", "")).lower()
             if world == 1 and not args.no_live_counters and not args.emulate_rank and not under_profiler:   # (never a profiler inside a profiler)
                 workload = [a for a in sys.argv[1:] if a not in ("--no-cpu-baseline",)]
-                # (the child runs repeat the workload's own arguments; --steps / --warmup are overridden by the later occurrence rule of argparse)
-                skip, keep = {"--steps", "--warmup", "--save-png", "--save-accumulator"}, []
+                # (the child runs repeat the workload's own arguments and append their own --steps 1 --warmup 0: argparse keeps the last
+                # occurrence.  What must not be repeated -- output files -- is dropped here in both spellings, `--opt value` and `--opt=value`)
+                skip, keep = {"--save-png", "--save-accumulator"}, []
                 it = iter(workload)
                 for a in it:
                     if a in skip:
                         next(it, None)
                         continue
+                    if a.split("=", 1)[0] in skip and "=" in a:
+                        continue
                     keep.append(a)
-                live, live_src = live_counters(keep)
+                # a pass traces one frame under the profiler (~6 x slower than plain): bound it by the measured frame time, not by a constant
+                live, live_src = live_counters(keep, timeout_s=max(60.0, min(150.0, 40.0 + 60.0 * ms_per_step * 1e-3)))
                 if live is None and rank == 0:
                     print(f"bench.py: live PMC counters unavailable ({live_src}); using the committed profiles", file=sys.stderr)
             for k in PRICED:

@@ -39,7 +39,14 @@
 extern "C" {
 #endif
 
-#define POLARIS_HIP_ABI_VERSION 4 /* 2: + reset_epoch / wait_reset, kernel_symbol, shade_counts; 3: + ipc_export / ipc_open / ipc_close / merge_ipc / merge_slot / trace_slot (additions only: older callers keep working); 4: PolarisIpcExport carries one event handle PER RING SLOT (the blob grows from 352 to 544 bytes; ipc_open refuses a blob of another version) */
+/* ABI history.  2: + reset_epoch / wait_reset, kernel_symbol, shade_counts.  3: + ipc_export / ipc_open / ipc_close / merge_ipc / merge_slot /
+ * trace_slot (additions only: older callers keep working).  4: PolarisIpcExport carries one event handle PER RING SLOT (the blob grows from 352
+ * to 544 bytes; ipc_open refuses a blob of another version); PolarisBvhBuildInput grew by `algorithm` (64 -> 72 bytes) and polaris_hip_build_bvh's
+ * default for a zero-initialised caller changed from the linear BVH to the binned-SAH builder.  5: + device_identity / can_access_peer /
+ * peer_info / merge_counts (which GPU a tracer really runs on, and which branch every merge took: what a multi-GPU bench line needs to prove
+ * itself); PolarisIpcExport carries the exporting GPU's PCI bus id (544 -> 576 bytes); PolarisBvhBuildInput LEADS with `struct_size`
+ * (72 -> 80 bytes): a caller built against another layout is refused instead of being read past its end. */
+#define POLARIS_HIP_ABI_VERSION 5
 
 /* status codes (0 = ok).  The first three mirror tracer/opencl/errors.go sentinels. */
 #define POLARIS_OK                0
@@ -60,6 +67,28 @@ int polaris_hip_abi_version(void);
 int polaris_hip_device_count(void);
 int polaris_hip_device_info(int index, char name[256], uint32_t *compute_units, uint32_t *clock_mhz,
                             uint64_t *global_mem_bytes);
+
+/* Which physical GPU a HIP device index of THIS process is.  Device indices are per process: a launcher that masks every rank to one
+ * visible device (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank) makes index 0 a different GPU in every rank, and a
+ * misconfigured one makes it the SAME GPU in all of them -- the PCI bus id and the UUID tell which.  The reference names its devices by
+ * the OpenCL device name and has ONE process see them all (tracer/opencl/device/platform.go, renderer/default.go:204-256: one tracer
+ * per enumerated device); with one process per GPU the identity has to travel with the numbers (bench.py: config.devices,
+ * config.distinct_gpus).  The caller sets struct_size = sizeof(PolarisDeviceIdentity). */
+typedef struct PolarisDeviceIdentity {
+	uint32_t struct_size;
+	int32_t hip_index;
+	char pci_bus_id[32];   /* hipDeviceGetPCIBusId, e.g. "0000:05:00.0" */
+	uint8_t uuid[16];      /* hipDeviceGetUuid; all zero if the runtime reports none */
+	uint32_t compute_units, clock_mhz;
+	uint64_t global_mem_bytes;
+	char name[64];         /* hipDeviceProp_t.name, truncated */
+	char gcn_arch[32];     /* hipDeviceProp_t.gcnArchName, e.g. "gfx950:sramecc+:xnack-" */
+} PolarisDeviceIdentity;
+int polaris_hip_device_identity(int index, PolarisDeviceIdentity *out);
+/* hipDeviceCanAccessPeer(device, peer_device) for two device indices of this process: *can = 1 / 0 (0 for device == peer_device, as HIP
+ * answers).  What decides between the direct peer read and the staged copy of polaris_hip_merge (tracer/opencl/tracer.go:279-286: the
+ * reference's devices share one context and the runtime migrates the buffer). */
+int polaris_hip_can_access_peer(int device, int peer_device, int *can);
 
 int polaris_hip_create(int device_index, polaris_hip_tracer **out);
 void polaris_hip_destroy(polaris_hip_tracer *h);
@@ -176,12 +205,28 @@ typedef struct PolarisIpcExport {
 	uint32_t reserved;
 	uint8_t mem[POLARIS_IPC_MAX_DEPTH][64];   /* hipIpcMemHandle_t per ring slot */
 	uint8_t event[POLARIS_IPC_MAX_DEPTH][64]; /* hipIpcEventHandle_t per ring slot: recorded at the end of the Trace that wrote the slot */
+	char pci_bus_id[32];                      /* ABI 5: the exporting GPU (device indices mean nothing across processes; "" if unknown) */
 } PolarisIpcExport;
 typedef struct polaris_hip_peer polaris_hip_peer; /* opaque: another process's trace accumulator ring, mapped here */
 
 int polaris_hip_ipc_export(polaris_hip_tracer *h, uint32_t depth, PolarisIpcExport *out);
 int polaris_hip_ipc_open(polaris_hip_tracer *dst, const PolarisIpcExport *peer_export, polaris_hip_peer **out);
 int polaris_hip_ipc_close(polaris_hip_tracer *dst, polaris_hip_peer *peer); /* waits for dst's merge stream first */
+/* What a mapped ring really is (ABI 5): the exporter's GPU by PCI bus id, whether that is dst's OWN GPU (the mapping is then a second
+ * mapping of local memory: ranks sharing a device, the one-GPU tests) or ANOTHER one (reads cross xGMI / PCIe), the exporter's GPU as a
+ * device index of this process (-1: not visible here, e.g. under a per-rank visibility mask) and hipDeviceCanAccessPeer towards it
+ * (-1: unknown).  The caller sets struct_size. */
+typedef struct PolarisPeerInfo {
+	uint32_t struct_size;
+	uint32_t pid;             /* exporting process */
+	int32_t exporter_device;  /* its HIP device index in THAT process */
+	int32_t local_device;     /* the same GPU as a device index of this process; -1 = not visible here */
+	int32_t same_device;      /* 1: the ring lives on dst's own GPU; 0: on another GPU; -1: unknown (no bus id on either side) */
+	int32_t can_access_peer;  /* hipDeviceCanAccessPeer(dst's device, local_device); -1 = unknown */
+	uint32_t depth, has_events;
+	char pci_bus_id[32];
+} PolarisPeerInfo;
+int polaris_hip_peer_info(polaris_hip_peer *peer, PolarisPeerInfo *out);
 /* dst.frameAccumulator[rows of req] += peer.traceAccumulator ring[slot][rows of req]; asynchronous on dst's merge stream
  * like polaris_hip_merge, completed by polaris_hip_sync_framebuffer(dst). */
 int polaris_hip_merge_ipc(polaris_hip_tracer *dst, polaris_hip_peer *peer, uint32_t slot, const PolarisBlockRequest *req);
@@ -191,6 +236,24 @@ int polaris_hip_merge_ipc(polaris_hip_tracer *dst, polaris_hip_peer *peer, uint3
  * device against src's next Trace. */
 int polaris_hip_trace_slot(polaris_hip_tracer *h, uint32_t *slot);
 int polaris_hip_merge_slot(polaris_hip_tracer *dst, polaris_hip_tracer *src, uint32_t slot, const PolarisBlockRequest *req);
+
+/* Which branch the merges onto `dst` took since it was created (ABI 5), counted per call under dst's merge lock:
+ *   LOCAL         polaris_hip_merge / _merge_slot, source on dst's own device (src == dst included)
+ *   PEER_ACCESS   ... source on another GPU of this process, read directly (hipDeviceEnablePeerAccess: xGMI peer read)
+ *   STAGED        ... source on another GPU, no peer access: hipMemcpyPeerAsync into a staging strip, then added
+ *   IPC_LOCAL     polaris_hip_merge_ipc, the peer's ring lives on dst's own GPU
+ *   IPC_PEER      polaris_hip_merge_ipc, the peer's ring lives on another GPU (IPC_UNKNOWN: the exporter gave no bus id)
+ *   DEVICE_STRIP  polaris_hip_merge_device (a strip some transport delivered: bench.py's fallback)
+ * bench.py reports them in config.exchange_detail: a fallback that ran silently shows in the numbers' own line. */
+#define POLARIS_MERGE_LOCAL 0
+#define POLARIS_MERGE_PEER_ACCESS 1
+#define POLARIS_MERGE_STAGED 2
+#define POLARIS_MERGE_IPC_LOCAL 3
+#define POLARIS_MERGE_IPC_PEER 4
+#define POLARIS_MERGE_IPC_UNKNOWN 5
+#define POLARIS_MERGE_DEVICE_STRIP 6
+#define POLARIS_MERGE_BRANCHES 7
+int polaris_hip_merge_counts(polaris_hip_tracer *dst, uint64_t counts[POLARIS_MERGE_BRANCHES]);
 
 /* The pipeline's Reset stage on its own (tracer/opencl/tracer.go:208-213: clearAccumulator(frameAccumulator)).
  * Trace runs it whenever accumulated_samples == 0.  A host that merges a frame's blocks only after the NEXT
@@ -258,20 +321,28 @@ int polaris_hip_selftest_rcp(polaris_hip_tracer *h, float lo, float hi, uint64_t
 /*
  * BVH construction on the device -- an ALTERNATIVE producer of the scene's two-level BVH (the stretch; the
  * reference's own builder, asset/compiler/bvh/bvh_builder.go:100-308, scores ~1024 / (depth + 1) candidate planes per axis with
- * one goroutine each and is restated for the CPU in polaris_amd/host/scene_compiler.cpp).  A linear BVH: Morton order of the
- * centroids (one radix sort), all inner nodes at once (Karras 2012), boxes fitted bottom-up, subtrees of up to max_leaf_tris
- * triangles collapsed into the reference's kind of leaf.  A linear BVH is deeper and looser than a surface-area-heuristic tree:
- * frames take 20-45 % longer on it, and a mesh that packs many triangles into one cell of the 30-bit grid can
- * exceed the 32-entry traversal stack (upload_scene then refuses the scene: use a CPU producer).  One tree per mesh over its triangles, one over the instances' world
- * boxes with one instance per leaf (compiler.go:88-103).  Output in the reference's encoding (PolarisBvhNode; node 0 = the scene's
- * root), ready for PolarisSceneView once the caller has put the triangle arrays in the new order:
+ * one goroutine each and is restated for the CPU in polaris_amd/host/scene_compiler.cpp).  Two algorithms (`algorithm`):
+ *   POLARIS_BVH_SAH (0, the default)  binned surface-area heuristic, built level by level: 16 bins per axis, the cheapest of the
+ *       3 x 15 planes per node (the criterion of bvh_builder.go:162-211, plane count aside), a node no plane separates is halved by
+ *       position.  Frames trace within 1 % of the CPU-built tree; 1 M triangles build in ~7 ms.  Depth is bounded by
+ *       the float range of the centroid extents plus log2(n) -- not by log2(n) alone: geometrically spaced outliers make a chain --
+ *       and a tree deeper than the 32-entry traversal stack is refused by upload_scene, whoever built it.
+ *   POLARIS_BVH_LBVH (1)  linear BVH: Morton order of the centroids (one radix sort), all inner nodes at once (Karras 2012), boxes
+ *       fitted bottom-up, subtrees of up to max_leaf_tris triangles collapsed into the reference's kind of leaf.  2-6 x faster to
+ *       build, deeper and looser: frames take 26-55 % longer on it, and a mesh that packs many triangles into one cell of the 30-bit
+ *       grid can exceed the traversal stack (upload_scene then refuses the scene: use the SAH builder or a CPU producer).
+ * One tree per mesh over its triangles, one over the instances' world boxes with one instance per leaf (compiler.go:88-103).  Output in
+ * the reference's encoding (PolarisBvhNode; node 0 = the scene's root), ready for PolarisSceneView once the caller has put the
+ * triangle arrays in the new order:
  *   tri_order[new position] = old triangle index (a permutation within every mesh's range; emissive tri_index values follow it);
  *   mesh_root[m] = the node a PolarisMeshInstance.bvh_root of mesh m must name.
  * nodes_capacity >= 2 * (num_instances + num_triangles).  The tree differs from the reference compiler's (another algorithm) --
  * parity is defined on the uploaded arrays, and any tree whose boxes bound their contents is traversed correctly.
  * device_ms (may be NULL) = the build on the device, vertices resident, without the read-back.  No tracer handle is involved.
+ * in->struct_size must be sizeof(PolarisBvhBuildInput) (ABI 5): POLARIS_E_BAD_ARGUMENT otherwise.
  */
 typedef struct PolarisBvhBuildInput {
+	uint32_t struct_size;           /* = sizeof(PolarisBvhBuildInput): a caller built against another layout is refused (ABI 5) */
 	const float *vertices;          /* float4 per vertex, 3 per triangle, as PolarisSceneView.vertices */
 	uint32_t num_triangles;
 	const uint32_t *mesh_first_tri; /* [num_meshes]: mesh m owns triangles [first, first + count); the ranges tile [0, num_triangles) in order */
@@ -281,7 +352,7 @@ typedef struct PolarisBvhBuildInput {
 	const uint32_t *instance_mesh;  /* [num_instances] */
 	uint32_t num_instances;
 	uint32_t max_leaf_tris;         /* 1..15 */
-	uint32_t algorithm;             /* POLARIS_BVH_SAH (0, the default: binned surface-area heuristic, level by level) or POLARIS_BVH_LBVH (1: linear BVH, 2-4 x faster to build, ~30-40 % slower to trace); ABI 4 */
+	uint32_t algorithm;             /* POLARIS_BVH_SAH (0, the default: binned surface-area heuristic, level by level) or POLARIS_BVH_LBVH (1: linear BVH, 2-6 x faster to build, 26-55 % slower to trace); ABI 4 */
 } PolarisBvhBuildInput;
 #define POLARIS_BVH_SAH 0u
 #define POLARIS_BVH_LBVH 1u

@@ -10,9 +10,12 @@
 //   whole workgroups), the cheapest of the 3 x 15 planes per node, a STABLE partition of the item array by one prefix sum over the
 //   whole level.  The same criterion as polaris_amd/scenes.py's CPU producer (and, plane count aside, as bvh_builder.go:162-211),
 //   so the trees trace like the CPU-built ones; no sort anywhere; leaves of <= max_leaf_tris items, so the upload-time leaf
-//   subdivision (scene_layout.h) finds nothing left to do; depth is O(log n) whatever the geometry (a node whose centroids no
-//   plane separates is halved by position), so a mesh that packs thousands of triangles into one cell of a Morton grid -- which
-//   the linear builder turns into a chain deeper than the traversal stack -- builds like any other.
+//   subdivision (scene_layout.h) finds nothing left to do.  Depth: a node whose centroids no plane separates is halved by position, so a
+//   mesh that packs thousands of triangles into one cell of a Morton grid -- which the linear builder turns into a chain deeper than the
+//   traversal stack -- builds like any other; and since a binned split alone only bounds the depth by the float range of the centroid
+//   extents (geometrically spaced outliers peel off one per level), every node carries a DEPTH BUDGET (sah_levels_needed): a split
+//   that would leave a child more items than the remaining levels can finish is replaced by the halving.  The meshes' trees stay within
+//   30 levels minus the top-level tree's share, whatever the geometry.
 //
 //   POLARIS_BVH_LBVH (round 4): a linear BVH (Morton order of the centroids on a grid whose cells stay near-cubic, one radix sort,
 //   the hierarchy of Karras 2012 for all inner nodes at once, boxes fitted bottom-up, subtrees of up to max_leaf_tris items
@@ -354,7 +357,9 @@ int build_tree(Scratch &S, hipStream_t q, uint32_t n, uint32_t max_leaf, uint32_
 constexpr int kBins = 16;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 struct SahBin { uint32_t cnt, lo[3], hi[3]; };          // boxes as order-preserving uints (atomicMin / atomicMax)
-struct SahAct { uint32_t node, first, count; };          // an active node: it holds more than max_leaf items and will be split
+struct SahAct { uint32_t node, first, count, big; };     // an active node: it holds more than max_leaf items and will be split; big = its index among the
+                                                         // level's nodes of more than kSmallMax items (their bins and centroid bounds live in arrays of THAT
+                                                         // length: at most n / 513 such nodes exist per level), kNone for the others
 struct SahSplit { uint32_t axis, k, nl; float clo, ext; }; // axis kNone = halved by position
 struct SahCb { uint32_t lo[3], hi[3]; };
 
@@ -390,7 +395,7 @@ __global__ void k_sah_root_node(const uint32_t *bounds, uint32_t n, uint32_t max
 	for (int a = 0; a < 3; a++) { nd.min[a] = o2f(bounds[a]); nd.max[a] = o2f(bounds[3 + a]); }
 	nd.ldata = 0; nd.rdata = 0;
 	if (n <= max_leaf) { nd.ldata = -(int32_t)item_base; nd.rdata = instances ? 0 : (int32_t)n; counts[0] = 0; } // the whole tree is one leaf (instances: position 0, resolved by k_sah_finish)
-	else { act[0] = SahAct{node, 0u, n}; counts[0] = 1; }
+	else { act[0] = SahAct{node, 0u, n, n > 512u ? 0u : 0xFFFFFFFFu}; counts[0] = 1; } // (512 = kSmallMax, kNone: declared below)
 	counts[1] = 0;
 	counts[2] = 0;
 	out[node] = nd;
@@ -436,11 +441,11 @@ __global__ __launch_bounds__(kBigBlock) void k_sah_cbounds_big(uint32_t n, const
 		if (o == kNone || act[o].count <= kSmallMax) continue;
 		const Box b = boxes[item[p]];
 		if (o == o0) { any = true; for (int a = 0; a < 3; a++) { const float c = sah_centroid(b, a); lo[a] = fminf(lo[a], c); hi[a] = fmaxf(hi[a], c); } }
-		else for (int a = 0; a < 3; a++) { const float c = sah_centroid(b, a); atomicMin(&cb[o].lo[a], f2o(c)); atomicMax(&cb[o].hi[a], f2o(c)); }
+		else for (int a = 0; a < 3; a++) { const float c = sah_centroid(b, a); atomicMin(&cb[act[o].big].lo[a], f2o(c)); atomicMax(&cb[act[o].big].hi[a], f2o(c)); }
 	}
 	if (any) for (int a = 0; a < 3; a++) { atomicMin(&l.lo[a], f2o(lo[a])); atomicMax(&l.hi[a], f2o(hi[a])); }
 	__syncthreads();
-	if (threadIdx.x < 3) { atomicMin(&cb[o0].lo[threadIdx.x], l.lo[threadIdx.x]); atomicMax(&cb[o0].hi[threadIdx.x], l.hi[threadIdx.x]); }
+	if (threadIdx.x < 3) { const uint32_t b0 = act[o0].big; atomicMin(&cb[b0].lo[threadIdx.x], l.lo[threadIdx.x]); atomicMax(&cb[b0].hi[threadIdx.x], l.hi[threadIdx.x]); }
 }
 
 __global__ __launch_bounds__(kBigBlock) void k_sah_bin_big(uint32_t n, const uint32_t *item, const uint32_t *owner, const SahAct *act, const Box *boxes, const SahCb *cb, SahBin *bins) {
@@ -461,19 +466,20 @@ __global__ __launch_bounds__(kBigBlock) void k_sah_bin_big(uint32_t n, const uin
 		const uint32_t o = owner[p];
 		if (o == kNone || act[o].count <= kSmallMax) continue;
 		const Box b = boxes[item[p]];
-		const SahCb c = cb[o];
+		const uint32_t ob = act[o].big; // (bins and centroid bounds are indexed by the node's rank among the level's BIG nodes)
+		const SahCb c = cb[ob];
 		for (int a = 0; a < 3; a++) {
 			const float clo = o2f(c.lo[a]), ext = o2f(c.hi[a]) - clo;
 			if (!(ext > 1e-12f)) continue; // (scenes.py: an axis along which the centroids coincide offers no plane)
 			const uint32_t k = sah_bin_of(sah_centroid(b, a), clo, ext);
-			SahBin *t = o == o0 ? &lb[a * kBins + k] : &bins[((size_t)o * 3 + a) * kBins + k];
+			SahBin *t = o == o0 ? &lb[a * kBins + k] : &bins[((size_t)ob * 3 + a) * kBins + k];
 			atomicAdd(&t->cnt, 1u);
 			for (int d = 0; d < 3; d++) { atomicMin(&t->lo[d], f2o(b.lo[d])); atomicMax(&t->hi[d], f2o(b.hi[d])); }
 		}
 	}
 	__syncthreads();
 	if (threadIdx.x < 3 * kBins && lb[threadIdx.x].cnt) {
-		SahBin *t = &bins[(size_t)o0 * 3 * kBins + threadIdx.x];
+		SahBin *t = &bins[(size_t)act[o0].big * 3 * kBins + threadIdx.x];
 		const SahBin v = lb[threadIdx.x];
 		atomicAdd(&t->cnt, v.cnt);
 		for (int d = 0; d < 3; d++) { atomicMin(&t->lo[d], v.lo[d]); atomicMax(&t->hi[d], v.hi[d]); }
@@ -487,8 +493,21 @@ __device__ __forceinline__ float sah_half_area(const float lo[3], const float hi
 
 // The split of ONE node from its bins (B: [3][kBins], global or LDS) and centroid bounds: the cheapest of the 3 x (kBins - 1) planes,
 // the children's ids, boxes and leaf records, flags[2 o + side] = 1 when that child is active in the next level.
+// The depth budget.  A binned split only shrinks a node's centroid EXTENT: items spaced geometrically (outliers at 16^-k) peel off one
+// per level, a chain as long as the float range allows -- deeper than the 32-entry traversal stack, and upload_scene then refuses the
+// scene.  Every node therefore carries a budget: the levels that may still follow below it.  levels_needed(m) is what the shallowest
+// possible subtree over m items takes (halving all the way); a SAH split is kept only if BOTH children can still be finished within
+// the budget, otherwise the node is halved by position -- which always can (ceil(m / 2) items need one level less than m).  A tree
+// whose natural SAH depth fits the budget never sees the rule.
+__host__ __device__ __forceinline__ uint32_t sah_levels_needed(uint32_t m, uint32_t max_leaf) {
+	const uint32_t q = (m + max_leaf - 1) / max_leaf; // leaves, at best
+	uint32_t l = 0;
+	while ((1u << l) < q) l++;
+	return l;
+}
+
 __device__ __forceinline__ void sah_split_node(uint32_t o, const SahAct me, const SahCb c, const SahBin *B3, uint32_t max_leaf, uint32_t next_base, uint32_t item_base,
-                                               int instances, PolarisBvhNode *out, SahSplit *split, uint32_t *flags, uint32_t *counts) {
+                                               int instances, uint32_t levels_below, PolarisBvhNode *out, SahSplit *split, uint32_t *flags, uint32_t *counts) {
 	const uint32_t m = me.count;
 	float best = 3.0e38f;
 	uint32_t best_axis = kNone, best_k = 0, best_nl = 0;
@@ -518,6 +537,8 @@ __device__ __forceinline__ void sah_split_node(uint32_t o, const SahAct me, cons
 			if (cost < best) { best = cost; best_axis = (uint32_t)a; best_k = (uint32_t)k; best_nl = nl; }
 		}
 	}
+	// (levels_below: what may follow below this node's CHILDREN)
+	if (best_axis != kNone && sah_levels_needed(max(best_nl, m - best_nl), max_leaf) > levels_below) best_axis = kNone;
 	SahSplit sp;
 	sp.axis = best_axis; sp.k = best_k; sp.clo = 0.0f; sp.ext = 1.0f;
 	PolarisBvhNode kid[2];
@@ -553,16 +574,16 @@ __device__ __forceinline__ void sah_split_node(uint32_t o, const SahAct me, cons
 
 // big nodes: one thread per active node, bins in global memory
 __global__ __launch_bounds__(BT) void k_sah_split_big(uint32_t A, const SahAct *act, const SahCb *cb, const SahBin *bins, uint32_t max_leaf, uint32_t next_base,
-                                                      uint32_t item_base, int instances, PolarisBvhNode *out, SahSplit *split, uint32_t *flags, uint32_t *counts) {
+                                                      uint32_t item_base, int instances, uint32_t levels_below, PolarisBvhNode *out, SahSplit *split, uint32_t *flags, uint32_t *counts) {
 	const uint32_t o = blockIdx.x * BT + threadIdx.x;
 	if (o >= A || act[o].count <= kSmallMax) return;
-	sah_split_node(o, act[o], cb[o], bins + (size_t)o * 3 * kBins, max_leaf, next_base, item_base, instances, out, split, flags, counts);
+	sah_split_node(o, act[o], cb[act[o].big], bins + (size_t)act[o].big * 3 * kBins, max_leaf, next_base, item_base, instances, levels_below, out, split, flags, counts);
 }
 
 // small nodes (<= kSmallMax items): ONE WAVE per node does everything -- centroid bounds by a wave reduction, the bins in LDS, the
 // split by its first lane -- without a global atomic (the deep levels of a tree are hundreds of thousands of such nodes).
 __global__ __launch_bounds__(BT) void k_sah_small(uint32_t A, const SahAct *act, const uint32_t *item, const Box *boxes, uint32_t max_leaf, uint32_t next_base,
-                                                  uint32_t item_base, int instances, PolarisBvhNode *out, SahSplit *split, uint32_t *flags, uint32_t *counts) {
+                                                  uint32_t item_base, int instances, uint32_t levels_below, PolarisBvhNode *out, SahSplit *split, uint32_t *flags, uint32_t *counts) {
 	__shared__ SahBin lb[BT / 64][3 * kBins];
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const uint32_t o = blockIdx.x * (BT / 64) + wave;
@@ -594,7 +615,7 @@ __global__ __launch_bounds__(BT) void k_sah_small(uint32_t A, const SahAct *act,
 	}
 	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 	__builtin_amdgcn_wave_barrier();
-	if (lane == 0) sah_split_node(o, me, c, lb[wave], max_leaf, next_base, item_base, instances, out, split, flags, counts);
+	if (lane == 0) sah_split_node(o, me, c, lb[wave], max_leaf, next_base, item_base, instances, levels_below, out, split, flags, counts);
 }
 
 __global__ __launch_bounds__(BT) void k_sah_next(uint32_t A, const SahAct *act, const SahSplit *split, const uint32_t *flags, const uint32_t *nidx, uint32_t next_base,
@@ -603,11 +624,14 @@ __global__ __launch_bounds__(BT) void k_sah_next(uint32_t A, const SahAct *act, 
 	if (o >= A) return;
 	const SahAct me = act[o];
 	const SahSplit sp = split[o];
-	if (flags[2 * o]) act_next[nidx[2 * o]] = SahAct{next_base + 2 * o, me.first, sp.nl};
-	if (flags[2 * o + 1]) act_next[nidx[2 * o + 1]] = SahAct{next_base + 2 * o + 1, me.first + sp.nl, me.count - sp.nl};
+	// the children that take the three-pass path in the next level get their rank among that level's big nodes here: counts[2] ends up as
+	// their number (0: those kernels are not launched).  Which rank a node gets depends on the order of the atomics -- it only names the
+	// node's scratch bins, never anything the tree is made of: two builds stay byte-identical.
+	const uint32_t bigl = flags[2 * o] && sp.nl > kSmallMax ? 1u : 0u, bigr = flags[2 * o + 1] && me.count - sp.nl > kSmallMax ? 1u : 0u;
+	const uint32_t rank = (bigl + bigr) ? atomicAdd(&counts[2], bigl + bigr) : 0u;
+	if (flags[2 * o]) act_next[nidx[2 * o]] = SahAct{next_base + 2 * o, me.first, sp.nl, bigl ? rank : kNone};
+	if (flags[2 * o + 1]) act_next[nidx[2 * o + 1]] = SahAct{next_base + 2 * o + 1, me.first + sp.nl, me.count - sp.nl, bigr ? rank + bigl : kNone};
 	if (o == A - 1) counts[0] = nidx[2 * o + 1] + flags[2 * o + 1];
-	const uint32_t big = (flags[2 * o] && sp.nl > kSmallMax ? 1u : 0u) + (flags[2 * o + 1] && me.count - sp.nl > kSmallMax ? 1u : 0u);
-	if (big) atomicAdd(&counts[2], big); // how many nodes of the next level take the three-pass path (0: those kernels are not launched)
 }
 
 __global__ __launch_bounds__(BT) void k_sah_flag(uint32_t n, const uint32_t *item, const uint32_t *owner, const Box *boxes, const SahAct *act, const SahSplit *split, uint32_t *left) {
@@ -682,8 +706,10 @@ struct SahScratch {
 };
 
 // One tree over n items whose boxes are in S.boxes: nodes to out[node_base ...]; *emitted = the number of nodes written.
-int build_tree_sah(SahScratch &S, hipStream_t q, uint32_t n, uint32_t max_leaf, uint32_t node_base, uint32_t item_base, int instances,
+// max_depth: the levels the tree may have below its root (the depth budget above); raised to what n items need at the least.
+int build_tree_sah(SahScratch &S, hipStream_t q, uint32_t n, uint32_t max_leaf, uint32_t node_base, uint32_t item_base, int instances, uint32_t max_depth,
                    PolarisBvhNode *d_out, uint32_t *d_order, uint32_t *emitted) {
+	max_depth = std::max(max_depth, sah_levels_needed(n, max_leaf));
 	BUILD_TRY(hipMemsetAsync(S.bounds, 0xFF, 3 * sizeof(uint32_t), q));
 	BUILD_TRY(hipMemsetAsync(S.bounds + 3, 0x00, 3 * sizeof(uint32_t), q));
 	hipLaunchKernelGGL(k_sah_init, dim3(grid(n)), dim3(BT), 0, q, n, S.item[0], S.owner[0]);
@@ -694,14 +720,16 @@ int build_tree_sah(SahScratch &S, hipStream_t q, uint32_t n, uint32_t max_leaf, 
 	for (int level = 0; A > 0; level++) {
 		if (level > 96) { g_build_error = "build_bvh: the SAH builder did not terminate (more than 96 levels)"; return POLARIS_E_DEVICE; }
 		const uint32_t next_base = node_base + total;
+		const uint32_t levels_below = max_depth > (uint32_t)level + 1u ? max_depth - (uint32_t)level - 1u : 0u; // below the children of this level's nodes
 		if (n_big) { // nodes of more than kSmallMax items: centroid bounds, bins, split as three passes (atomics aggregated per tile in LDS)
-			hipLaunchKernelGGL(k_sah_clear_cb, dim3(grid(A)), dim3(BT), 0, q, A, S.cb);
-			hipLaunchKernelGGL(k_sah_clear_bins, dim3(grid(A * 3u * kBins)), dim3(BT), 0, q, A * 3u * kBins, S.bins);
+			// (n_big <= n / 513: at most 2^26 / 513 x 48 = 6.3 M bin records, far inside uint32)
+			hipLaunchKernelGGL(k_sah_clear_cb, dim3(grid(n_big)), dim3(BT), 0, q, n_big, S.cb);
+			hipLaunchKernelGGL(k_sah_clear_bins, dim3(grid(n_big * 3u * kBins)), dim3(BT), 0, q, n_big * 3u * kBins, S.bins);
 			hipLaunchKernelGGL(k_sah_cbounds_big, dim3((n + kTile - 1) / kTile), dim3(kBigBlock), 0, q, n, S.item[cur], S.owner[cur], S.act[cur], S.boxes, S.cb);
 			hipLaunchKernelGGL(k_sah_bin_big, dim3((n + kTile - 1) / kTile), dim3(kBigBlock), 0, q, n, S.item[cur], S.owner[cur], S.act[cur], S.boxes, S.cb, S.bins);
-			hipLaunchKernelGGL(k_sah_split_big, dim3(grid(A)), dim3(BT), 0, q, A, S.act[cur], S.cb, S.bins, max_leaf, next_base, instances ? 0u : item_base, instances, d_out, S.split, S.flags, S.counts);
+			hipLaunchKernelGGL(k_sah_split_big, dim3(grid(A)), dim3(BT), 0, q, A, S.act[cur], S.cb, S.bins, max_leaf, next_base, instances ? 0u : item_base, instances, levels_below, d_out, S.split, S.flags, S.counts);
 		}
-		hipLaunchKernelGGL(k_sah_small, dim3((A + BT / 64 - 1) / (BT / 64)), dim3(BT), 0, q, A, S.act[cur], S.item[cur], S.boxes, max_leaf, next_base, instances ? 0u : item_base, instances, d_out, S.split, S.flags, S.counts);
+		hipLaunchKernelGGL(k_sah_small, dim3((A + BT / 64 - 1) / (BT / 64)), dim3(BT), 0, q, A, S.act[cur], S.item[cur], S.boxes, max_leaf, next_base, instances ? 0u : item_base, instances, levels_below, d_out, S.split, S.flags, S.counts);
 		size_t tb = S.temp_bytes;
 		BUILD_TRY(rocprim::exclusive_scan(S.temp, tb, S.flags, S.nidx, 0u, (size_t)2 * A, rocprim::plus<uint32_t>(), q));
 		hipLaunchKernelGGL(k_sah_next, dim3(grid(A)), dim3(BT), 0, q, A, S.act[cur], S.split, S.flags, S.nidx, next_base, S.act[cur ^ 1], S.counts);
@@ -741,6 +769,7 @@ int polaris_hip_build_bvh(int device, const PolarisBvhBuildInput *in, PolarisBvh
 	g_build_error.clear();
 	auto bad = [&](const char *m) { g_build_error = m; return POLARIS_E_BAD_ARGUMENT; };
 	if (!in || !nodes || !num_nodes || !tri_order || !mesh_root) return bad("build_bvh: null argument");
+	if (in->struct_size != sizeof(PolarisBvhBuildInput)) return bad("build_bvh: in->struct_size is not sizeof(PolarisBvhBuildInput): the caller was built against another ABI (polaris_hip.h, ABI history)");
 	if (!in->vertices || in->num_triangles == 0 || in->num_triangles > (1u << 26)) return bad("build_bvh: no triangles (or more than 2^26)");
 	if (!in->mesh_first_tri || !in->mesh_num_tris || in->num_meshes == 0) return bad("build_bvh: no meshes");
 	if (!in->instance_boxes || !in->instance_mesh || in->num_instances == 0 || in->num_instances > (1u << 24)) return bad("build_bvh: no instances (or more than 2^24)");
@@ -781,7 +810,10 @@ int polaris_hip_build_bvh(int device, const PolarisBvhBuildInput *in, PolarisBvh
 		for (int i = 0; i < 2; i++) { BUILD_TRY(S.get(&H.item[i], biggest)); BUILD_TRY(S.get(&H.owner[i], biggest)); BUILD_TRY(S.get(&H.act[i], amax)); }
 		BUILD_TRY(S.get(&H.left, biggest)); BUILD_TRY(S.get(&H.lscan, biggest));
 		BUILD_TRY(S.get(&H.flags, 2 * amax)); BUILD_TRY(S.get(&H.nidx, 2 * amax)); BUILD_TRY(S.get(&H.counts, 4)); BUILD_TRY(S.get(&H.bounds, 8));
-		BUILD_TRY(S.get(&H.bins, amax * 3 * kBins)); BUILD_TRY(S.get(&H.cb, amax)); BUILD_TRY(S.get(&H.half, 2 * amax)); BUILD_TRY(S.get(&H.split, amax));
+		// bins and centroid bounds exist for the nodes of more than kSmallMax items only: disjoint ranges of > 512 items, so at most
+		// biggest / 513 of them per level (round 5 sized them for EVERY active node: 672 bytes per triangle, 6.7 GB for a 10 M-triangle mesh)
+		const size_t bmax = (size_t)biggest / (kSmallMax + 1) + 1;
+		BUILD_TRY(S.get(&H.bins, bmax * 3 * kBins)); BUILD_TRY(S.get(&H.cb, bmax)); BUILD_TRY(S.get(&H.half, 2 * amax)); BUILD_TRY(S.get(&H.split, amax));
 		size_t a = 0;
 		BUILD_TRY(rocprim::exclusive_scan(nullptr, a, H.left, H.lscan, 0u, std::max<size_t>(biggest, 2 * amax), rocprim::plus<uint32_t>(), q));
 		H.temp_bytes = a;
@@ -814,13 +846,18 @@ int polaris_hip_build_bvh(int device, const PolarisBvhBuildInput *in, PolarisBvh
 	static_assert(sizeof(Box) == 24, "instance boxes arrive as 6 floats");
 	BUILD_TRY(hipMemcpyAsync(S.boxes, in->instance_boxes, (size_t)in->num_instances * sizeof(Box), hipMemcpyHostToDevice, q));
 	uint32_t total = 0, emitted = 0;
-	if (int rc = sah ? build_tree_sah(H, q, in->num_instances, 1, 0, 0, 1, d_nodes, nullptr, &emitted) : build_tree(S, q, in->num_instances, 1, 0, 0, 1, d_nodes, nullptr, &emitted)) return rc;
+	// the SAH builder's depth budget: a ray's stack holds at most one entry per level of the top-level tree, the instance's exit marker and
+	// one per level of the mesh's tree -- 32 entries (kernels.h; intersect.cl:4).  The top-level tree gets what a balanced tree over the
+	// instances needs plus four levels of slack for the heuristic, the meshes' trees the rest of 30.
+	const uint32_t top_depth = in->num_instances > 1 ? sah_levels_needed(in->num_instances, 1) + 4u : 0u;
+	const uint32_t mesh_depth = top_depth < 30u ? 30u - top_depth : 0u;
+	if (int rc = sah ? build_tree_sah(H, q, in->num_instances, 1, 0, 0, 1, top_depth, d_nodes, nullptr, &emitted) : build_tree(S, q, in->num_instances, 1, 0, 0, 1, d_nodes, nullptr, &emitted)) return rc;
 	total += emitted;
 	for (uint32_t m = 0; m < in->num_meshes; m++) {
 		const uint32_t first = in->mesh_first_tri[m], n = in->mesh_num_tris[m];
 		hipLaunchKernelGGL(k_tri_boxes, dim3(grid(n)), dim3(BT), 0, q, d_verts, first, n, S.boxes);
 		mesh_root[m] = total;
-		if (int rc = sah ? build_tree_sah(H, q, n, in->max_leaf_tris, total, first, 0, d_nodes, d_order, &emitted) : build_tree(S, q, n, in->max_leaf_tris, total, first, 0, d_nodes, d_order, &emitted)) return rc;
+		if (int rc = sah ? build_tree_sah(H, q, n, in->max_leaf_tris, total, first, 0, mesh_depth, d_nodes, d_order, &emitted) : build_tree(S, q, n, in->max_leaf_tris, total, first, 0, d_nodes, d_order, &emitted)) return rc;
 		total += emitted;
 	}
 	BUILD_TRY(hipEventRecord(e1, q));

@@ -108,12 +108,6 @@ struct Streams {
 	// one of them (camera rays, camera.cl; bounce rays, pt_integrator.cl:209), so it is neither stored nor loaded.  (Shadow rays
 	// carry a real distance in occ_o.w; the probes and taps pass arbitrary ones: 16 bytes there.)
 	uint32_t o12;
-#ifdef POLARIS_EXP_REORDER
-	// experiment build (scripts/wave_lines.sh; EXPERIMENTS.md "coherence reorder"): k_trace takes its rays in the order of
-	// perm[0 .. *perm_n) -- absolute slots, produced by a sort of per-ray keys between the shade step and the launch -- instead of
-	// chunk by chunk.  Hits still go to the ray's own slot, so results are unchanged bit for bit; what changes is which rays share a wave.
-	const uint32_t *perm, *perm_n;
-#endif
 };
 __device__ __forceinline__ float4 load_ray_o(const Streams &st, size_t slot) {
 	if (st.o12) { const float *p = reinterpret_cast<const float *>(st.ray_o) + 3 * slot; return make_float4(p[0], p[1], p[2], 3.402823466e+38f); }
@@ -497,11 +491,6 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 	constexpr uint32_t kRow = BLOCK * sizeof(StackEntry);
 	__shared__ uint32_t wg_cursor;
 	if (threadIdx.x == 0) wg_cursor = 0;
-#ifdef POLARIS_PROFILE_PROLOGUE
-	// timing build (profiles/r05_small_block_prologue.txt): s_memrealtime (100 MHz) at the start of a workgroup, after the staging
-	// barrier and at its end -- summed per launch class into ST_DEBUG + 12..14 (closest hit) / + 28..30 (any hit)
-	const unsigned long long pp_t0 = __builtin_amdgcn_s_memrealtime();
-#endif
 	__shared__ float4 top_static[LDS_TOP ? kLdsTopNodes * 4 : 1];
 	float4 *const top = TINY ? reinterpret_cast<float4 *>(tiny_lds) : top_static;
 	float *const ltri = TINY ? reinterpret_cast<float *>(tiny_lds + (size_t)B.num_pairs * sizeof(PairNode)) : nullptr; // 9 floats per slot, slots [0, B.lds_tris)
@@ -520,9 +509,6 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 		}
 	}
 	__syncthreads();
-#ifdef POLARIS_PROFILE_PROLOGUE
-	const unsigned long long pp_t1 = __builtin_amdgcn_s_memrealtime();
-#endif
 	// (tiny mode: a lane's stack pointer is its offset in the dynamic block itself -- the block's address is a link-time constant,
 	// so it folds into the instruction's offset field and no access pays an add for the stack's run-time position)
 	char *const stk_bytes = TINY ? tiny_lds : reinterpret_cast<char *>(&stk[0][0]);
@@ -598,9 +584,6 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 		if (ONE) { boxDist = __builtin_fminf(maxDist, kFltMax); best_cull = best_t * kCullMargin; }
 	};
 	// the next rays of the workgroup's chunks go to the lanes for which wants() holds (take(slot) must make it false)
-#ifdef POLARIS_EXP_REORDER
-	const uint32_t perm_total = st.perm ? *st.perm_n : 0u;
-#endif
 	auto draw = [&](auto wants, auto take) {
 		for (;;) {
 			if (off >= cnt) {
@@ -610,9 +593,6 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 				if (c >= num_chunks) { drained = true; break; }
 				chunk = c;
 				off = 0;
-#ifdef POLARIS_EXP_REORDER
-				if (st.perm) { cnt = chunk * WG < perm_total ? min((uint32_t)WG, perm_total - chunk * WG) : 0u; continue; }
-#endif
 				cnt = cnts[chunk];
 				continue;
 			}
@@ -621,37 +601,10 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 			if (n == 0) break;
 			const uint32_t share = min(cnt - off, n);
 			const uint32_t rank = __popcll(m & below);
-#ifdef POLARIS_EXP_REORDER
-			if (st.perm) { if (wants() && rank < share) take(st.perm[chunk * WG + off + rank]); }
-			else
-#endif
 			if (wants() && rank < share) take(chunk * WG + off + rank);
 			off += share;
 		}
 	};
-#ifdef POLARIS_PROFILE_LOOPS
-	// profiling build (scripts/loop_profile.sh): wave-level iteration counts and the lanes that were live in them -- closest hit in
-	// ST_DEBUG + 0..15, any hit in + 16..31: [0] outer iterations [1] lanes holding a ray in them [2] node steps [3] lanes descending
-	// [4] triangle rounds [5] lanes testing [6] refills [7] rays started
-	// [8] distinct 128-byte lines the live lanes of a node step fetch their pair records from [9] the same for the triangle records of a
-	// triangle round (a 48-byte record may straddle two lines: both count) [10] lanes entering an instance [11] distinct instance records they fetch
-	unsigned long long pc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define PROF(i, v) pc[i] += (unsigned long long)(v)
-	// number of distinct values of a (and, where has_b, of b) over the lanes for which `active` holds
-	auto wave_distinct = [&](bool active, uint32_t a, bool has_b, uint32_t b) -> uint32_t {
-		unsigned long long ma = __ballot(active), mb = __ballot(active && has_b && b != a);
-		uint32_t n = 0;
-		while (ma | mb) {
-			const uint32_t x = ma ? __builtin_amdgcn_readlane(a, __ffsll((long long)ma) - 1) : __builtin_amdgcn_readlane(b, __ffsll((long long)mb) - 1);
-			ma &= ~__ballot(active && a == x);
-			mb &= ~__ballot(active && has_b && b == x);
-			n++;
-		}
-		return n;
-	};
-#else
-#define PROF(i, v) ((void)0)
-#endif
 	for (;;) {
 		// ---- refill idle lanes from the workgroup's chunks -------------------------------------------
 		// (Round 3 tried the asynchronous version once more, now that the kernel has registers to spare: every lane keeps its
@@ -665,24 +618,17 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 		{
 			const unsigned long long freem = __ballot(cur == kIdle);
 			if (!drained && (freem == ~0ull || __popcll(freem) >= (ANY_HIT ? kRefillMinAny : kRefillMin))) {
-				PROF(6, 1); PROF(7, -(long long)__popcll(__ballot(cur != kIdle)));
 				draw([&]() { return cur == kIdle; }, [&](uint32_t ray_slot) { start_ray(ray_slot, ANY_HIT ? src_o[ray_slot] : load_ray_o(st, ray_slot & o_mask), src_d[ray_slot]); });
-				PROF(7, __popcll(__ballot(cur != kIdle)));
 			}
 			if (__ballot(cur != kIdle) == 0ull) {
 				if (drained) break;
 				continue;
 			}
-			PROF(0, 1); PROF(1, __popcll(__ballot(cur != kIdle)));
 		}
 		// ---- phase 1: descend through inner nodes (intersect.cl:296-328) ---------------------------------
 		// left early once fewer than kStragglers lanes are still descending (they continue next round)
 		// (one step always if anybody descends, further steps while at least kStragglers lanes still do)
 		if (__ballot(cur >= 0) != 0ull) do {
-			PROF(2, 1); PROF(3, __popcll(__ballot(cur >= 0)));
-#ifdef POLARIS_PROFILE_LOOPS
-			if (!TINY) PROF(8, wave_distinct(cur >= 0 && !(LDS_TOP && cur < kLdsTopNodes), (uint32_t)cur >> 1, false, 0u)); // 64-byte records, two per line
-#endif
 			if (cur >= 0) {
 				PairNode P;
 				if (TINY || (LDS_TOP && cur < kLdsTopNodes)) { P.lo0 = top[4 * cur]; P.hi0 = top[4 * cur + 1]; P.lo1 = top[4 * cur + 2]; P.hi1 = top[4 * cur + 3]; }
@@ -734,12 +680,6 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 			rcp_dir(d.x, d.y, d.z, inv.x, inv.y, inv.z);
 			pop();
 		}
-#ifdef POLARIS_PROFILE_LOOPS
-		if (!ONE) { // [10] lanes entering an instance [11] distinct instance records those lanes fetch (64 bytes each)
-			const bool enters = cur < 0 && cur >= kFirstLeafRef && (((uint32_t)~cur) & 15u) == 0u && !(((uint32_t)~cur) & kBigLeafFlag);
-			PROF(10, __popcll(__ballot(enters))); PROF(11, wave_distinct(enters, ((uint32_t)~cur) >> 4, false, 0u));
-		}
-#endif
 		if (!ONE && cur < 0 && cur >= kFirstLeafRef && (((uint32_t)~cur) & 15u) == 0u) { // a top-level leaf, or a leaf of more than 15 triangles
 			const uint32_t code = (uint32_t)~cur;
 			if (!(code & kBigLeafFlag)) { // top-level leaf: enter the mesh instance (intersect.cl:239-252); its id is in the reference
@@ -827,10 +767,6 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 				// memory, and 64-byte triangle records that never straddle a line: both within +-2 % on the terrain, C4 and C5,
 				// profiles/r04_tri_variants_ab.txt)
 				do {
-					PROF(4, 1); PROF(5, __popcll(__ballot(i < ntri && !occluded)));
-#ifdef POLARIS_PROFILE_LOOPS
-					if (!TINY) PROF(9, wave_distinct(i < ntri && !occluded, ((first + i) * 48u) >> 7, true, ((first + i) * 48u + 47u) >> 7));
-#endif
 					if (i < ntri && !occluded) {
 						const uint32_t s = first + i;
 						if (TINY && s < B.lds_tris) { // (two explicit paths: one fetch through a selected pointer would be a FLAT load)
@@ -856,17 +792,6 @@ void k_trace(Streams st, BvhDev B, uint32_t num_chunks, float4 *acc, unsigned lo
 			}
 		}
 	}
-#ifdef POLARIS_PROFILE_LOOPS
-	if (lane == 0) for (int i = 0; i < 16; i++) atomicAdd(&stats[ST_DEBUG + (ANY_HIT ? 16 : 0) + i], pc[i]);
-#endif
-#ifdef POLARIS_PROFILE_PROLOGUE
-	if (threadIdx.x == 0) {
-		const unsigned long long pp_t2 = __builtin_amdgcn_s_memrealtime();
-		atomicAdd(&stats[ST_DEBUG + (ANY_HIT ? 16 : 0) + 12], pp_t1 - pp_t0);
-		atomicAdd(&stats[ST_DEBUG + (ANY_HIT ? 16 : 0) + 13], pp_t2 - pp_t0);
-		atomicAdd(&stats[ST_DEBUG + (ANY_HIT ? 16 : 0) + 14], 1ull);
-	}
-#endif
 	if (ANY_HIT) {
 		// wave sum -> workgroup sum in LDS -> ONE global atomic per workgroup (contended atomics on a single address run
 		// at ~80/us; see k_shade)

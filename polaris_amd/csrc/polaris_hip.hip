@@ -50,6 +50,8 @@ struct DevBuf {
 
 struct polaris_hip_tracer {
 	int device = 0;
+	char pci_bus_id[32] = {}; // which GPU `device` is (device indices are per process); "" if the runtime does not say
+	uint64_t merge_counts[POLARIS_MERGE_BRANCHES] = {}; // which branch every merge onto this tracer took (under merge_mu; polaris_hip_merge_counts)
 	hipStream_t stream = nullptr;
 	std::mutex mu;
 	std::string error;
@@ -154,17 +156,6 @@ struct polaris_hip_tracer {
 	int opt_hit12 = 1;     // 12-byte hit records inside a Trace (A/B aid: 0 = 16)
 	int opt_o12 = 1;       // 12-byte origins of the closest-hit rays inside a Trace (A/B aid: 0 = 16)
 	int opt_traversal = 1; // 1 = persistent waves with lane refill (k_trace), 0 = one ray per lane (k_intersect/k_occlusion)
-#ifdef POLARIS_EXP_REORDER
-	int opt_reorder = 0, opt_reorder_any = 0, opt_reorder_bits = 30;
-	uint32_t opt_reorder_win = 256;
-	float3 exp_lo = {0, 0, 0}, exp_scale = {1, 1, 1};
-	unsigned long long *exp_keys[2] = {nullptr, nullptr};
-	uint32_t *exp_vals[2] = {nullptr, nullptr}, *exp_total = nullptr;
-	void *exp_temp = nullptr;
-	size_t exp_slots = 0, exp_temp_bytes = 0;
-	uint32_t exp_npad = 256;
-	double exp_ms[2] = {0, 0};
-#endif
 
 	// per-kernel timing (option time_kernels)
 	struct Pending { const char *name; hipEvent_t a, b; };
@@ -184,63 +175,9 @@ struct polaris_hip_peer {
 	uint32_t depth = 0, W = 0, H = 0;
 	void *mem[POLARIS_IPC_MAX_DEPTH] = {};
 	hipEvent_t ev[POLARIS_IPC_MAX_DEPTH] = {}; // per slot: the peer's "the Trace that wrote this slot is done" event (null: the exporter had none)
+	PolarisPeerInfo info{};                    // what the mapping is (polaris_hip_peer_info); info.same_device picks the merge branch counted
 };
 
-#ifdef POLARIS_EXP_REORDER
-// ---- experiment build only (scripts/wave_lines.sh; not compiled into the product library) ----------------------------------------
-// "Would a coherence reorder of the bounce rays pay?"  Between a shade step and the traversal launch that consumes its rays a key
-// is computed per live ray, the (key, slot) pairs are sorted (hipCUB: an experiment, not the product) and k_trace deals its rays
-// in that order (kernels.h, Streams::perm).  Options: reorder = 0 off | 1 identity (control: same waves as today, through the
-// indirection) | 2 direction octant, then Morton code of the origin's cell (10 bits per axis of the scene box) | 3 Morton code, then
-// octant | 4 Morton code alone | 5 16 x 16 pixel tiles of the path's pixel, Z-order inside | 6 direction octant alone;
-// reorder_win = slots per sort window (256 = within a chunk, 1024, 0 = the whole batch).
-#include <hipcub/hipcub.hpp>
-namespace pol {
-__device__ __forceinline__ uint32_t exp_spread3(uint32_t v) { // 10 bits -> every third bit
-	v &= 0x3FFu;
-	v = (v | (v << 16)) & 0x030000FFu; v = (v | (v << 8)) & 0x0300F00Fu; v = (v | (v << 4)) & 0x030C30C3u; v = (v | (v << 2)) & 0x09249249u;
-	return v;
-}
-__global__ void k_exp_keys(Streams st, int any, uint32_t n_slots, int mode, uint32_t win, int bits, float3 lo, float3 scale, uint32_t Npad, uint32_t W,
-                           unsigned long long *keys, uint32_t *vals, uint32_t *total) {
-	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-	if (slot >= n_slots) return;
-	const uint32_t chunk = slot >> 8;
-	const uint32_t cnt = (any ? st.cnt_occ : st.cnt_ray)[chunk];
-	if ((slot & 255u) == 0u && cnt) atomicAdd(total, cnt);
-	const bool live = (slot & 255u) < cnt;
-	unsigned long long key = (win == 0 && mode == 3) ? (1ull << (bits + 3)) : ~0ull; // dead slots sort behind every ray
-	if (live) {
-		const float4 o4 = any ? st.occ_o[slot] : load_ray_o(st, slot), d4 = (any ? st.occ_d : st.ray_d)[slot];
-		const uint32_t oct = (d4.x < 0.0f ? 1u : 0u) | (d4.y < 0.0f ? 2u : 0u) | (d4.z < 0.0f ? 4u : 0u);
-		const uint32_t cx = (uint32_t)fminf(fmaxf((o4.x - lo.x) * scale.x, 0.0f), 1023.0f), cy = (uint32_t)fminf(fmaxf((o4.y - lo.y) * scale.y, 0.0f), 1023.0f),
-		               cz = (uint32_t)fminf(fmaxf((o4.z - lo.z) * scale.z, 0.0f), 1023.0f);
-		const unsigned long long morton = exp_spread3(cx) | (exp_spread3(cy) << 1) | (exp_spread3(cz) << 2);
-		unsigned long long sub = slot;
-		if (mode == 2) sub = ((unsigned long long)oct << 30) | morton;
-		else if (mode == 3) sub = ((morton >> (30 - bits)) << 3) | oct; // (bits < 30: a coarse binning, rays of a bin stay in slot order)
-		else if (mode == 4) sub = morton;
-		else if (mode == 5) {
-			const uint32_t pix = (uint32_t)__float_as_int(d4.w) & 0xFFFFFFu, x = pix % W, y = pix / W; // (closest-hit rays: the path word's low 24 bits are the path index in the block)
-			const uint32_t tile = (y >> 4) * ((W + 15u) >> 4) + (x >> 4);
-			uint32_t z = 0;
-			for (int b = 0; b < 4; b++) z |= ((x >> b & 1u) << (2 * b)) | ((y >> b & 1u) << (2 * b + 1));
-			sub = ((unsigned long long)(slot / Npad) << 32) | ((unsigned long long)tile << 8) | z;
-		} else if (mode == 6) sub = oct;
-		else if (mode == 7) { // all samples of a pixel side by side (pixel-major over the whole batch): what a "64 samples of one pixel per wave" slot layout would give
-			const uint32_t w = (uint32_t)__float_as_int(d4.w);
-			const uint32_t pix = any ? w % Npad : (w & 0xFFFFFFu); // (shadow rays carry their accumulator cell = sample * Npad + path index)
-			sub = ((unsigned long long)pix << 8) | (slot / Npad);
-		}
-		const unsigned long long window = win ? slot / win : 0u;
-		key = (mode == 5 || mode == 7) ? sub : ((window << 34) | sub);
-		key = (key << 0); // (ties keep slot order: the radix sort is stable)
-	}
-	keys[slot] = key;
-	vals[slot] = slot;
-}
-} // namespace pol
-#endif
 
 namespace {
 
@@ -479,42 +416,6 @@ hipError_t launch_trace(polaris_hip_tracer *h, polaris_hip_tracer::Pipe &P, cons
 	Streams st = st_in;
 	uint32_t o_mask = ~0u;
 	if (camera && !ANY_HIT) { st.ray_o = h->d_cam_o; o_mask = 0u; }
-#ifdef POLARIS_EXP_REORDER
-	st.perm = nullptr; st.perm_n = nullptr;
-	if (h->opt_reorder && !camera && (ANY_HIT ? h->opt_reorder_any != 0 : true) && h->opt_overlap == 1) { // (one batch at a time: the sort buffers are the handle's)
-		const size_t n = (size_t)chunks * WG;
-		if (n > h->exp_slots) {
-			for (int i = 0; i < 2; i++) { if (h->exp_keys[i]) (void)hipFree(h->exp_keys[i]); if (h->exp_vals[i]) (void)hipFree(h->exp_vals[i]); h->exp_keys[i] = nullptr; h->exp_vals[i] = nullptr; }
-			if (h->exp_temp) (void)hipFree(h->exp_temp);
-			h->exp_temp = nullptr;
-			for (int i = 0; i < 2; i++) { if (hipMalloc((void **)&h->exp_keys[i], n * 8) != hipSuccess || hipMalloc((void **)&h->exp_vals[i], n * 4) != hipSuccess) return hipErrorOutOfMemory; }
-			if (!h->exp_total && hipMalloc((void **)&h->exp_total, 4) != hipSuccess) return hipErrorOutOfMemory;
-			size_t tb = 0;
-			(void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, h->exp_keys[0], h->exp_keys[1], h->exp_vals[0], h->exp_vals[1], (int)n, 0, 64, P.q);
-			if (hipMalloc(&h->exp_temp, tb) != hipSuccess) return hipErrorOutOfMemory;
-			h->exp_temp_bytes = tb;
-			h->exp_slots = n;
-		}
-		(void)hipMemsetAsync(h->exp_total, 0, 4, P.q);
-		hipLaunchKernelGGL(k_exp_keys, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, P.q, st, ANY_HIT ? 1 : 0, (uint32_t)n, h->opt_reorder, h->opt_reorder_win, h->opt_reorder_bits, h->exp_lo, h->exp_scale,
-		                   h->exp_npad, h->W, h->exp_keys[0], h->exp_vals[0], h->exp_total);
-		size_t tb = h->exp_temp_bytes;
-		const int end_bit = (h->opt_reorder_win == 0 && h->opt_reorder == 3) ? h->opt_reorder_bits + 4 : 64; // (coarse bins: fewer radix passes)
-		(void)hipcub::DeviceRadixSort::SortPairs(h->exp_temp, tb, h->exp_keys[0], h->exp_keys[1], h->exp_vals[0], h->exp_vals[1], (int)n, 0, end_bit, P.q);
-		st.perm = h->exp_vals[1]; st.perm_n = h->exp_total;
-	}
-	hipEvent_t ea = nullptr, eb = nullptr;
-	if (getenv("POLARIS_DEBUG")) { (void)hipEventCreate(&ea); (void)hipEventCreate(&eb); (void)hipEventRecord(ea, P.q); }
-	void *args_x[] = {(void *)&st, (void *)&h->bvh, (void *)&chunks, (void *)&acc, (void *)&h->d_stats, (void *)&o_mask};
-	hipError_t rc_x = hipLaunchKernel(fn, dim3(grid), dim3(block), args_x, h->node_mode == kNodesLdsAll ? h->tiny_lds_bytes : 0, P.q);
-	if (ea) { // the launch alone (the "intersect" timer of this build includes the key + sort pass)
-		(void)hipEventRecord(eb, P.q); (void)hipEventSynchronize(eb);
-		float ms = 0; (void)hipEventElapsedTime(&ms, ea, eb);
-		h->exp_ms[ANY_HIT ? 1 : 0] += camera ? 0.0 : ms;
-		(void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
-	}
-	return rc_x;
-#endif
 	void *args[] = {(void *)&st, (void *)&h->bvh, (void *)&chunks, (void *)&acc, (void *)&h->d_stats, (void *)&o_mask};
 	return hipLaunchKernel(fn, dim3(grid), dim3(block), args, h->node_mode == kNodesLdsAll ? h->tiny_lds_bytes : 0, P.q);
 }
@@ -585,10 +486,6 @@ hipError_t launch_batch(polaris_hip_tracer *h, int p, const PolarisBlockRequest 
 	hipStream_t q = P.q;
 	P.st.hit12 = h->opt_hit12 ? 1u : 0u; // (a Trace never reads a hit's distance: kernels.h Streams::hit12)
 	P.st.o12 = h->opt_o12 ? 1u : 0u;     // (... and its closest-hit rays all have the max distance FLT_MAX: Streams::o12)
-#ifdef POLARIS_EXP_REORDER
-	h->exp_npad = Npad;
-	P.st.perm = nullptr; P.st.perm_n = nullptr;
-#endif
 	{
 		Timed t(h, "generate", q);
 		if (h->opt_time_kernels) h->timer_symbol["generate"] = "pol::k_generate";
@@ -742,6 +639,39 @@ int polaris_hip_device_info(int index, char name[256], uint32_t *compute_units, 
 	return POLARIS_OK;
 }
 
+int polaris_hip_device_identity(int index, PolarisDeviceIdentity *out) {
+	if (!out) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "device_identity: out is null");
+	if (out->struct_size != sizeof(PolarisDeviceIdentity))
+		return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "device_identity: struct_size %u, this library's PolarisDeviceIdentity has %zu bytes", out->struct_size, sizeof(PolarisDeviceIdentity));
+	const int n = polaris_hip_device_count();
+	if (index < 0 || index >= n) return fail(nullptr, POLARIS_E_NO_DEVICE, "device %d out of range (%d devices)", index, n);
+	hipDeviceProp_t p;
+	HIP_TRY(nullptr, hipGetDeviceProperties(&p, index));
+	memset(out, 0, sizeof *out);
+	out->struct_size = sizeof *out;
+	out->hip_index = index;
+	if (hipDeviceGetPCIBusId(out->pci_bus_id, (int)sizeof out->pci_bus_id, index) != hipSuccess) { (void)hipGetLastError(); out->pci_bus_id[0] = 0; }
+	hipUUID u;
+	if (hipDeviceGetUuid(&u, index) == hipSuccess) memcpy(out->uuid, u.bytes, 16);
+	else (void)hipGetLastError();
+	out->compute_units = (uint32_t)p.multiProcessorCount;
+	out->clock_mhz = (uint32_t)(p.clockRate / 1000);
+	out->global_mem_bytes = (uint64_t)p.totalGlobalMem;
+	snprintf(out->name, sizeof out->name, "%s", p.name);
+	snprintf(out->gcn_arch, sizeof out->gcn_arch, "%s", p.gcnArchName);
+	return POLARIS_OK;
+}
+
+int polaris_hip_can_access_peer(int device, int peer_device, int *can) {
+	if (!can) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "can_access_peer: out is null");
+	*can = 0;
+	const int n = polaris_hip_device_count();
+	if (device < 0 || device >= n || peer_device < 0 || peer_device >= n) return fail(nullptr, POLARIS_E_NO_DEVICE, "can_access_peer: device %d / %d out of range (%d devices)", device, peer_device, n);
+	if (device == peer_device) return POLARIS_OK;
+	HIP_TRY(nullptr, hipDeviceCanAccessPeer(can, device, peer_device));
+	return POLARIS_OK;
+}
+
 int polaris_hip_create(int device_index, polaris_hip_tracer **out) {
 	if (!out) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "out handle pointer is null");
 	*out = nullptr;
@@ -750,6 +680,7 @@ int polaris_hip_create(int device_index, polaris_hip_tracer **out) {
 		return fail(nullptr, POLARIS_E_NO_DEVICE, "device %d out of range (%d HIP devices visible)", device_index, n);
 	polaris_hip_tracer *h = new polaris_hip_tracer();
 	h->device = device_index;
+	if (hipDeviceGetPCIBusId(h->pci_bus_id, (int)sizeof h->pci_bus_id, device_index) != hipSuccess) { (void)hipGetLastError(); h->pci_bus_id[0] = 0; }
 	hipError_t e = hipSetDevice(device_index);
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
 	h->pipe[0].q = h->stream;
@@ -879,13 +810,6 @@ int polaris_hip_upload_scene(polaris_hip_tracer *h, const PolarisSceneView *sc) 
 		err = build_layout(*sc, L, 0);
 	}
 	if (!err.empty()) return fail(h, POLARIS_E_BAD_SCENE, "%s", err.c_str());
-#ifdef POLARIS_EXP_REORDER
-	if (sc->num_bvh_nodes) { // the scene box: node 0 is the root of the top-level tree
-		const PolarisBvhNode &R = sc->bvh_nodes[0];
-		h->exp_lo = make_float3(R.min[0], R.min[1], R.min[2]);
-		h->exp_scale = make_float3(1024.0f / std::max(1e-20f, R.max[0] - R.min[0]), 1024.0f / std::max(1e-20f, R.max[1] - R.min[1]), 1024.0f / std::max(1e-20f, R.max[2] - R.min[2]));
-	}
-#endif
 	HIP_TRY(h, hipSetDevice(h->device));
 	HIP_TRY(h, sync_all(h));
 	free_pool(h->scene_bufs);
@@ -1023,12 +947,6 @@ int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value
 	else if (k == "trace_grid") h->opt_trace_grid = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20));
 	else if (k == "trace_wgs_per_cu") h->opt_trace_wgs_per_cu = (int)std::max<int64_t>(0, std::min<int64_t>(value, 64));
 	else if (k == "tiny_one") h->opt_tiny_one = value != 0; // next upload
-#ifdef POLARIS_EXP_REORDER
-	else if (k == "reorder") h->opt_reorder = (int)value;
-	else if (k == "reorder_any") h->opt_reorder_any = (int)value;
-	else if (k == "reorder_win") h->opt_reorder_win = (uint32_t)value;
-	else if (k == "reorder_bits") h->opt_reorder_bits = (int)std::max<int64_t>(3, std::min<int64_t>(value, 30)) / 3 * 3;
-#endif
 	else if (k == "hit12") h->opt_hit12 = value != 0;
 	else if (k == "o12") h->opt_o12 = value != 0;
 	else if (k == "lds_tris") h->opt_lds_tris = (int)std::max<int64_t>(-1, std::min<int64_t>(value, 1 << 20)); // next upload
@@ -1163,37 +1081,6 @@ int polaris_hip_trace(polaris_hip_tracer *h, const PolarisBlockRequest *r, const
 	HIP_TRY(h, hipStreamSynchronize(q));
 	drain.armed = false; // the join above made q wait for every pipeline
 	collect_timers(h);
-#ifdef POLARIS_PROFILE_LOOPS
-	if (getenv("POLARIS_DEBUG")) { // kernels.h, PROF
-		for (int a = 0; a < 2; a++) {
-			const unsigned long long *c = hs + ST_DEBUG + 16 * a;
-			fprintf(stderr, "[polaris] %s: %llu rays; per ray: %.2f outer iterations, %.2f node steps, %.2f triangle rounds | live lanes: outer %.1f, node step %.1f, triangle round %.1f | "
-			        "wave-level: %llu outer, %llu node, %llu triangle, %llu refills (%.1f rays each)\n", a ? "any hit" : "closest hit", c[7],
-			        (double)c[1] / std::max(1ull, c[7]), (double)c[3] / std::max(1ull, c[7]), (double)c[5] / std::max(1ull, c[7]),
-			        (double)c[1] / std::max(1ull, c[0]), (double)c[3] / std::max(1ull, c[2]), (double)c[5] / std::max(1ull, c[4]), c[0], c[2], c[4], c[6], (double)c[7] / std::max(1ull, c[6]));
-			// distinct 128-byte lines (global-memory node / triangle records only; camera rays included in the closest-hit row)
-			fprintf(stderr, "[polaris] %s lines: per wave-level node step %.2f distinct lines for %.1f live lanes; per triangle round %.2f for %.1f; per ray %.2f node lines + %.2f triangle lines; "
-			        "instance entries per ray %.2f, distinct instance records per entering lane %.2f\n", a ? "any hit" : "closest hit",
-			        (double)c[8] / std::max(1ull, c[2]), (double)c[3] / std::max(1ull, c[2]), (double)c[9] / std::max(1ull, c[4]), (double)c[5] / std::max(1ull, c[4]),
-			        (double)c[8] / std::max(1ull, c[7]), (double)c[9] / std::max(1ull, c[7]), (double)c[10] / std::max(1ull, c[7]), (double)c[11] / std::max(1ull, c[10]));
-		}
-	}
-#endif
-#ifdef POLARIS_PROFILE_PROLOGUE
-	if (getenv("POLARIS_DEBUG")) { // kernels.h: s_memrealtime ticks (100 MHz) summed over the workgroups of every k_trace launch of this Trace
-		for (int a = 0; a < 2; a++) {
-			const unsigned long long *c = hs + ST_DEBUG + 16 * a + 12;
-			fprintf(stderr, "[polaris] %s prologue: %llu workgroups; staging (tree + triangle records into LDS, to the barrier) %.2f us per workgroup of %.2f us lifetime = %.1f %%\n",
-			        a ? "any hit" : "closest hit", c[2], (double)c[0] / std::max(1ull, c[2]) / 100.0, (double)c[1] / std::max(1ull, c[2]) / 100.0, 100.0 * (double)c[0] / std::max(1ull, c[1]));
-		}
-	}
-#endif
-#ifdef POLARIS_EXP_REORDER
-	if (getenv("POLARIS_DEBUG")) {
-		fprintf(stderr, "[polaris] reorder %d window %u (any hit too: %d): k_trace launches of the bounce rays alone %.3f ms closest hit, %.3f ms any hit\n", h->opt_reorder, h->opt_reorder_win, h->opt_reorder_any, h->exp_ms[0], h->exp_ms[1]);
-		h->exp_ms[0] = h->exp_ms[1] = 0;
-	}
-#endif
 	for (uint32_t b = 0; b < POLARIS_MAX_BOUNCES; b++) {
 		h->last_shade_counts[3 * b] = b < B ? hs[ST_HITS_BOUNCE + b] : 0;
 		h->last_shade_counts[3 * b + 1] = b < B ? hs[ST_MISSES_BOUNCE + b] : 0;
@@ -1276,7 +1163,9 @@ static int merge_rows(polaris_hip_tracer *dst, polaris_hip_tracer *src, polaris_
 		(void)hipGetLastError();
 		if (getenv("POLARIS_DEBUG")) fprintf(stderr, "[polaris] merge_ipc: hipStreamWaitEvent on the peer's inter-process event failed; continuing with the host-side ordering\n");
 	}
+	int branch = peer ? (peer->info.same_device == 1 ? POLARIS_MERGE_IPC_LOCAL : (peer->info.same_device == 0 ? POLARIS_MERGE_IPC_PEER : POLARIS_MERGE_IPC_UNKNOWN)) : POLARIS_MERGE_LOCAL;
 	if (!peer && src_device != dst->device) {
+		branch = POLARIS_MERGE_PEER_ACCESS;
 		int can = 0;
 		if (hipDeviceCanAccessPeer(&can, dst->device, src_device) != hipSuccess) return fail_merge(POLARIS_E_DEVICE, "merge: hipDeviceCanAccessPeer failed");
 		bool direct = false;
@@ -1286,6 +1175,7 @@ static int merge_rows(polaris_hip_tracer *dst, polaris_hip_tracer *src, polaris_
 			(void)hipGetLastError();
 		}
 		if (!direct) { // staged copy over xGMI / PCIe, then add (the staging strip is the merge stream's: merges are serialised on it)
+			branch = POLARIS_MERGE_STAGED;
 			if (dst->staging_bytes < n * sizeof(float4)) {
 				(void)hipStreamSynchronize(q);
 				if (dst->staging) (void)hipFree(dst->staging);
@@ -1303,6 +1193,7 @@ static int merge_rows(polaris_hip_tracer *dst, polaris_hip_tracer *src, polaris_
 		hipLaunchKernelGGL(k_aggregate, dim3(grid_for(n)), dim3(WG), 0, q, rows, dst->frame_acc + off, (uint32_t)n);
 	}
 	if (hipGetLastError() != hipSuccess) return fail_merge(POLARIS_E_DEVICE, "merge: kernel launch failed");
+	dst->merge_counts[branch]++;
 	// src's next Trace clears and rewrites the rows just queued for reading: it waits (on the device) for this event.  With
 	// src == dst the merge stream itself is joined by Trace (join_merges).  Recorded for a merge from a named ring slot too
 	// (merge_slot): with a ring of depth 1 that slot IS what the next Trace clears, and with a deeper ring the wait is for a
@@ -1373,6 +1264,8 @@ int polaris_hip_ipc_export(polaris_hip_tracer *h, uint32_t depth, PolarisIpcExpo
 	memset(out, 0, sizeof *out);
 	out->abi_version = POLARIS_HIP_ABI_VERSION; out->depth = depth; out->frame_w = h->W; out->frame_h = h->H;
 	out->device = h->device; out->pid = (uint32_t)getpid();
+	static_assert(sizeof out->pci_bus_id == sizeof h->pci_bus_id, "the export carries the tracer's bus id as it is");
+	memcpy(out->pci_bus_id, h->pci_bus_id, sizeof out->pci_bus_id);
 	for (uint32_t i = 0; i < depth; i++) {
 		hipIpcMemHandle_t mh;
 		HIP_TRY(h, hipIpcGetMemHandle(&mh, h->ring[i]));
@@ -1417,6 +1310,25 @@ int polaris_hip_ipc_open(polaris_hip_tracer *dst, const PolarisIpcExport *x, pol
 	HIP_TRY(dst, hipSetDevice(dst->device));
 	polaris_hip_peer *p = new polaris_hip_peer();
 	p->owner = dst; p->depth = x->depth; p->W = x->frame_w; p->H = x->frame_h;
+	{ // what the mapping is: the exporter's GPU by bus id, as this process sees it
+		PolarisPeerInfo &I = p->info;
+		I.struct_size = sizeof I; I.pid = x->pid; I.exporter_device = x->device; I.local_device = -1; I.same_device = -1; I.can_access_peer = -1;
+		I.depth = x->depth;
+		memcpy(I.pci_bus_id, x->pci_bus_id, sizeof I.pci_bus_id);
+		I.pci_bus_id[sizeof I.pci_bus_id - 1] = 0;
+		if (I.pci_bus_id[0] && dst->pci_bus_id[0]) {
+			I.same_device = strcmp(I.pci_bus_id, dst->pci_bus_id) == 0 ? 1 : 0;
+			int local = -1;
+			if (hipDeviceGetByPCIBusId(&local, I.pci_bus_id) == hipSuccess) I.local_device = local;
+			else (void)hipGetLastError();
+			if (I.same_device == 1) I.local_device = dst->device;
+			int can = 0;
+			if (I.local_device >= 0 && I.local_device != dst->device) {
+				if (hipDeviceCanAccessPeer(&can, dst->device, I.local_device) == hipSuccess) I.can_access_peer = can;
+				else (void)hipGetLastError();
+			}
+		}
+	}
 	auto undo = [&]() {
 		for (uint32_t i = 0; i < POLARIS_IPC_MAX_DEPTH; i++)
 			if (p->mem[i]) (void)hipIpcCloseMemHandle(p->mem[i]);
@@ -1447,7 +1359,24 @@ int polaris_hip_ipc_open(polaris_hip_tracer *dst, const PolarisIpcExport *x, pol
 			}
 		}
 	}
+	p->info.has_events = p->ev[0] ? 1u : 0u;
 	*out = p;
+	return POLARIS_OK;
+}
+
+int polaris_hip_peer_info(polaris_hip_peer *p, PolarisPeerInfo *out) {
+	if (!p || !out) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "peer_info: null argument");
+	if (out->struct_size != sizeof(PolarisPeerInfo)) return fail(nullptr, POLARIS_E_BAD_ARGUMENT, "peer_info: struct_size %u, this library's PolarisPeerInfo has %zu bytes", out->struct_size, sizeof(PolarisPeerInfo));
+	std::lock_guard<std::mutex> lk(p->owner->merge_mu); // (a merge that finds the peer's events unusable drops them: has_events follows)
+	*out = p->info;
+	out->has_events = p->ev[0] ? 1u : 0u;
+	return POLARIS_OK;
+}
+
+int polaris_hip_merge_counts(polaris_hip_tracer *dst, uint64_t counts[POLARIS_MERGE_BRANCHES]) {
+	if (!dst || !counts) return fail(dst, POLARIS_E_BAD_ARGUMENT, "merge_counts: null argument");
+	std::lock_guard<std::mutex> lk(dst->merge_mu);
+	for (int i = 0; i < POLARIS_MERGE_BRANCHES; i++) counts[i] = dst->merge_counts[i];
 	return POLARIS_OK;
 }
 
@@ -1489,6 +1418,7 @@ int polaris_hip_merge_device(polaris_hip_tracer *dst, const void *device_rows, c
 	hipLaunchKernelGGL(k_aggregate, dim3(grid_for(n)), dim3(WG), 0, dst->merge_stream, (const float4 *)device_rows, dst->frame_acc + off,
 	                   (uint32_t)n);
 	HIP_TRY(dst, hipGetLastError());
+	dst->merge_counts[POLARIS_MERGE_DEVICE_STRIP]++;
 	HIP_TRY(dst, hipStreamSynchronize(dst->merge_stream)); // the caller owns device_rows: do not outlive it
 	return POLARIS_OK;
 }

@@ -99,20 +99,83 @@ class IpcExport(C.Structure):
         ("abi_version", C.c_uint32), ("depth", C.c_uint32), ("frame_w", C.c_uint32), ("frame_h", C.c_uint32),
         ("device", C.c_int32), ("pid", C.c_uint32), ("has_event", C.c_uint32), ("reserved", C.c_uint32),
         ("mem", (C.c_uint8 * 64) * IPC_MAX_DEPTH), ("event", (C.c_uint8 * 64) * IPC_MAX_DEPTH),
+        ("pci_bus_id", C.c_char * 32),
     ]
 
 
-assert C.sizeof(IpcExport) == 32 + 64 * IPC_MAX_DEPTH + 64 * IPC_MAX_DEPTH
+assert C.sizeof(IpcExport) == 32 + 64 * IPC_MAX_DEPTH + 64 * IPC_MAX_DEPTH + 32
+
+
+class DeviceIdentity(C.Structure):
+    """PolarisDeviceIdentity (include/polaris_hip.h): which physical GPU a HIP device index of this process is."""
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("hip_index", C.c_int32), ("pci_bus_id", C.c_char * 32), ("uuid", C.c_uint8 * 16),
+        ("compute_units", C.c_uint32), ("clock_mhz", C.c_uint32), ("global_mem_bytes", C.c_uint64),
+        ("name", C.c_char * 64), ("gcn_arch", C.c_char * 32),
+    ]
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_size = C.sizeof(self)
+
+    def as_dict(self) -> dict:
+        return {"hip_index": int(self.hip_index), "pci_bus_id": self.pci_bus_id.decode(errors="replace"), "uuid": bytes(self.uuid).hex(),
+                "cus": int(self.compute_units), "clock_mhz": int(self.clock_mhz), "global_mem_bytes": int(self.global_mem_bytes),
+                "name": self.name.decode(errors="replace"), "gcn_arch": self.gcn_arch.decode(errors="replace")}
+
+
+class PeerInfo(C.Structure):
+    """PolarisPeerInfo (include/polaris_hip.h): what a mapped peer ring really is."""
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("pid", C.c_uint32), ("exporter_device", C.c_int32), ("local_device", C.c_int32),
+        ("same_device", C.c_int32), ("can_access_peer", C.c_int32), ("depth", C.c_uint32), ("has_events", C.c_uint32),
+        ("pci_bus_id", C.c_char * 32),
+    ]
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_size = C.sizeof(self)
+
+
+assert C.sizeof(DeviceIdentity) == 168 and C.sizeof(PeerInfo) == 64
+MERGE_BRANCHES = ("local", "peer-access", "staged", "ipc-local", "ipc-peer", "ipc-unknown", "device-strip")   # POLARIS_MERGE_* (include/polaris_hip.h)
+
+
+def device_identity(index: int) -> dict:
+    """polaris_hip_device_identity as a dict (hip_index, pci_bus_id, uuid hex, cus, clock_mhz, global_mem_bytes, name, gcn_arch)."""
+    lib = load_library()
+    d = DeviceIdentity()
+    rc = lib.polaris_hip_device_identity(int(index), C.byref(d))
+    if rc:
+        msg = lib.polaris_hip_last_error(None)
+        raise RuntimeError(f"polaris_hip_device_identity({index}) failed with {rc}: {msg.decode() if msg else ''}")
+    return d.as_dict()
+
+
+def can_access_peer(device: int, peer: int) -> int:
+    """hipDeviceCanAccessPeer(device, peer) for two device indices of this process (0 for device == peer)."""
+    lib = load_library()
+    can = C.c_int(0)
+    rc = lib.polaris_hip_can_access_peer(int(device), int(peer), C.byref(can))
+    if rc:
+        msg = lib.polaris_hip_last_error(None)
+        raise RuntimeError(f"polaris_hip_can_access_peer({device}, {peer}) failed with {rc}: {msg.decode() if msg else ''}")
+    return int(can.value)
 
 
 class BvhBuildInput(C.Structure):
     """PolarisBvhBuildInput (include/polaris_hip.h): what polaris_hip_build_bvh builds the two-level BVH from."""
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("vertices", C.c_void_p), ("num_triangles", C.c_uint32),
         ("mesh_first_tri", C.c_void_p), ("mesh_num_tris", C.c_void_p), ("num_meshes", C.c_uint32),
         ("instance_boxes", C.c_void_p), ("instance_mesh", C.c_void_p), ("num_instances", C.c_uint32),
         ("max_leaf_tris", C.c_uint32), ("algorithm", C.c_uint32),
     ]
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_size = C.sizeof(self)   # (the library refuses another layout: ABI 5)
 
 
 BVH_SAH, BVH_LBVH = 0, 1   # PolarisBvhBuildInput.algorithm
@@ -150,6 +213,7 @@ C_ABI_SYMBOLS = [
     "polaris_hip_kernel_symbol", "polaris_hip_shade_counts",
     "polaris_hip_ipc_export", "polaris_hip_ipc_open", "polaris_hip_ipc_close", "polaris_hip_merge_ipc",
     "polaris_hip_trace_slot", "polaris_hip_merge_slot", "polaris_hip_build_bvh", "polaris_hip_build_bvh_error",
+    "polaris_hip_device_identity", "polaris_hip_can_access_peer", "polaris_hip_peer_info", "polaris_hip_merge_counts",
 ]
 
 _lib = None
@@ -241,6 +305,10 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.polaris_hip_merge_slot.argtypes = [vp, vp, u32, C.POINTER(BlockRequest)]
     lib.polaris_hip_build_bvh.argtypes = [i32, C.POINTER(BvhBuildInput), vp, u32, C.POINTER(u32), vp, vp, C.POINTER(C.c_double)]
     lib.polaris_hip_build_bvh_error.restype = C.c_char_p
+    lib.polaris_hip_device_identity.argtypes = [i32, C.POINTER(DeviceIdentity)]
+    lib.polaris_hip_can_access_peer.argtypes = [i32, i32, C.POINTER(i32)]
+    lib.polaris_hip_peer_info.argtypes = [vp, C.POINTER(PeerInfo)]
+    lib.polaris_hip_merge_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
     for name in C_ABI_SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ("polaris_hip_device_count", "polaris_hip_abi_version"):

@@ -25,6 +25,30 @@ asynchronously and returns at once, so every rank goes straight on to trace fram
 from __future__ import annotations
 
 
+def device_for_rank(local_rank: int, visible: int) -> tuple[int, str]:
+    """Which HIP device index a rank of a one-process-per-GPU launch uses, and why.  The reference has ONE process that sees every
+    device and gives each a tracer (renderer/default.go:204-256); a launcher hands every rank either all GPUs -- then LOCAL_RANK
+    names the rank's own -- or, masked per rank (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES), exactly one, which is index 0 in
+    EVERY rank.  Anything else (fewer visible devices than ranks, more than one) is oversubscribed: the ranks wrap around, and
+    bench.py's `config.distinct_gpus` shows it."""
+    if visible < 1:
+        raise RuntimeError("no HIP device is visible to this rank")
+    if local_rank < visible:
+        return local_rank, "LOCAL_RANK"
+    if visible == 1:
+        return 0, "the one visible device (per-rank visibility mask, or ranks sharing a GPU)"
+    return local_rank % visible, f"LOCAL_RANK modulo the {visible} visible devices (more ranks than devices)"
+
+
+def gather_setup_errors(dist, rank: int, world: int, err: str, group=None) -> list[str]:
+    """Every rank's set-up verdict ("" = fine) reaches every rank BEFORE the first collective that would otherwise hang on the
+    rank that failed: one all_gather_object over the (bounded-timeout) control group.  Returns the non-empty messages, prefixed
+    with their rank, in rank order -- the same list on every rank."""
+    got = [None] * world
+    dist.all_gather_object(got, err or "", group=group)
+    return [f"rank {r}: {e}" for r, e in enumerate(got) if e]
+
+
 def naive_rows(n_tracers: int, frame_h: int, speeds=None) -> list[int]:
     """tracer/scheduler.go:83-106 assignBlocksBasedOnSpeed (all speeds equal unless given)."""
     speeds = [1] * n_tracers if speeds is None else list(speeds)
@@ -264,6 +288,10 @@ class PeerExchange:
         self.dist.broadcast_object_list(verdict, src=self.primary, group=self.group)
         self.opened, self.why_not = bool(verdict[0]), verdict[1]
         return self.opened
+
+    def peers(self) -> dict:
+        """(primary) rank -> the peer handle port.open() returned for that rank's ring."""
+        return dict(self._peers)
 
     def set_scheduler(self, kind: str):
         """Start over with another block scheduler (between two timed regions; nothing may be pending).  The mappings stay."""

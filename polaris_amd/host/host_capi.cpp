@@ -149,6 +149,13 @@ int polaris_host_renderer_tracer_stats(void *h, uint32_t tracer_index, PolarisTr
 	if (trace_ms) *trace_ms = std::chrono::duration<double, std::milli>(box->hips[tracer_index]->GetStats()->RenderTime).count();
 	return 0;
 }
+// which branch the merges onto the PRIMARY took so far (polaris_hip_merge_counts: local / peer access / staged copy ...)
+int polaris_host_renderer_merge_counts(void *h, uint64_t counts[POLARIS_MERGE_BRANCHES]) {
+	auto *box = static_cast<RendererBox *>(h);
+	auto *p = dynamic_cast<tracer::hip::HipTracer *>(box->r->Primary());
+	if (!p) return POLARIS_E_UNSUPPORTED;
+	return polaris_hip_merge_counts(p->Handle(), counts);
+}
 int polaris_host_renderer_read(void *h, uint8_t *rgba, size_t n_rgba, float *frame_acc, size_t n_floats) {
 	auto *box = static_cast<RendererBox *>(h);
 	auto *p = dynamic_cast<tracer::hip::HipTracer *>(box->r->Primary());

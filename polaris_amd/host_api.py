@@ -34,6 +34,7 @@ def load() -> C.CDLL:
         lib.polaris_host_renderer_push_seeds.argtypes = [vp, C.c_uint32, vp, C.c_size_t]
         lib.polaris_host_renderer_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
         lib.polaris_host_renderer_read.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t]
+        lib.polaris_host_renderer_merge_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
         lib.polaris_host_renderer_tracer_stats.argtypes = [vp, C.c_uint32, C.POINTER(T.TraceStats), C.POINTER(C.c_double)]
         lib.polaris_host_renderer_save.argtypes = [vp, C.c_char_p]
         lib.polaris_host_write_png.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
@@ -137,6 +138,13 @@ class Renderer:
         if self._lib.polaris_host_renderer_tracer_stats(self._h, tracer_index, C.byref(st), C.byref(ms)):
             raise RuntimeError("tracer_stats: bad tracer index")
         return st, ms.value
+
+    def merge_counts(self) -> dict:
+        """Which branch the merges onto the primary took so far (polaris_hip_merge_counts)."""
+        a = (C.c_uint64 * len(T.MERGE_BRANCHES))()
+        if self._lib.polaris_host_renderer_merge_counts(self._h, a):
+            raise RuntimeError("merge_counts failed")
+        return {name: int(a[k]) for k, name in enumerate(T.MERGE_BRANCHES)}
 
     def read(self):
         fb = np.zeros((self.H, self.W, 4), dtype=np.uint8)

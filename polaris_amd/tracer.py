@@ -245,6 +245,26 @@ class HipTracer:
         """MergeOutput from ring slot `slot` of a tracer of this process (the primary's own block, merged one frame late)."""
         self._check(self._lib.polaris_hip_merge_slot(self._h, other._h, slot, C.byref(req)), self._h)
 
+    def peer_info(self, peer: int) -> dict:
+        """What a mapped peer ring really is (polaris_hip_peer_info): the exporter's GPU by PCI bus id, whether it is this tracer's own
+        GPU, and the merge branch that follows from it ("ipc-local" / "ipc-peer" / "ipc-unknown")."""
+        i = T.PeerInfo()
+        self._check(self._lib.polaris_hip_peer_info(C.c_void_p(peer), C.byref(i)), None)
+        same = int(i.same_device)
+        return {"pid": int(i.pid), "exporter_device": int(i.exporter_device), "pci_bus_id": i.pci_bus_id.decode(errors="replace"),
+                "local_device": int(i.local_device), "same_device": same, "can_access_peer": int(i.can_access_peer), "depth": int(i.depth),
+                "has_events": int(i.has_events), "branch": "ipc-local" if same == 1 else ("ipc-peer" if same == 0 else "ipc-unknown")}
+
+    def merge_counts(self) -> dict:
+        """How many merges onto this tracer took which branch since it was created (polaris_hip_merge_counts)."""
+        a = (C.c_uint64 * len(T.MERGE_BRANCHES))()
+        self._check(self._lib.polaris_hip_merge_counts(self._h, a), self._h)
+        return {name: int(a[k]) for k, name in enumerate(T.MERGE_BRANCHES)}
+
+    def device_identity(self) -> dict:
+        """Which physical GPU this tracer runs on (polaris_hip_device_identity of its device index)."""
+        return T.device_identity(self._device)
+
     def trace_slot(self) -> int:
         s = C.c_uint32()
         self._check(self._lib.polaris_hip_trace_slot(self._h, C.byref(s)), self._h)

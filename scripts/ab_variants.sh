@@ -1,11 +1,11 @@
 #!/bin/bash
 # scripts/ab_variants.sh "<variant names>" "<bench args>" [--opt k=v ...] -- A/B of library builds made by scripts/build_variant.sh
-# (polaris_amd/lib/exp/<name>.so; "base" = the in-tree library) on one bench configuration; prints Mrays/s, ms/frame and the
+# (gpurun_in/variants/<name>.so; "base" = the in-tree library) on one bench configuration; prints Mrays/s, ms/frame and the
 # isolated kernel times per variant.  Run inside gpurun.
 cd $GRAFT_REPO_ROOT
 names=$1; shift
 for n in $names; do
-  lib=polaris_amd/lib/exp/$n.so
+  lib=gpurun_in/variants/$n.so
   [ "$n" = base ] && lib=polaris_amd/lib/libpolaris_hip.so
   POLARIS_HIP_LIB=$lib timeout -k 10 240 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-live-counters "$@" 2>/dev/null | python3 -c "
 import sys, json

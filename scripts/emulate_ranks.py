@@ -65,6 +65,35 @@ def main():
                 frame()
             return (time.perf_counter() - t) / steps * 1e3
 
+        def primary_merge_ms(rows):
+            """What the PRIMARY pays per frame on top of its own Trace: the Reset stage, one MergeOutput (k_aggregate) per block and the
+            tone-map of the whole frame with its synchronisation (renderer/default.go:159-161,191) -- bench.py's `own_work` of rank 0
+            inside PeerExchange.merge().  Every block is read from this tracer's own accumulator here (a peer read over xGMI moves the
+            same bytes: 16 B per pixel of the block)."""
+            full = T.BlockRequest()
+            full.frame_w, full.frame_h, full.block_x, full.block_y, full.block_w, full.block_h = W, H, 0, 0, W, H
+            full.samples_per_pixel, full.num_bounces, full.min_bounces_for_rr, full.exposure = spp, B, rr, 1.2
+            reqs = []
+            for r in range(len(rows)):
+                by, bh = block_of(r, rows)
+                q = T.BlockRequest()
+                q.frame_w, q.frame_h, q.block_x, q.block_y, q.block_w, q.block_h = W, H, 0, by, W, bh
+                q.samples_per_pixel, q.num_bounces, q.min_bounces_for_rr, q.exposure = spp, B, rr, 1.2
+                reqs.append(q)
+
+            def once():
+                tr.reset_frame()
+                for q in reqs:
+                    tr.MergeOutput(tr, q)
+                tr.SyncFramebuffer(full)
+
+            for _ in range(3):
+                once()
+            t = time.perf_counter()
+            for _ in range(20):
+                once()
+            return (time.perf_counter() - t) / 20 * 1e3
+
         one = rank_ms(0, [H])
         out = {"what": f"{sc.name} {W}x{H}x{spp}spp, one rank's block at a time on one MI355X ({steps} timed frames after {warmup})", "one_gpu_ms": round(one, 3), "N": {}}
         print(cfg, "1 GPU", round(one, 3), flush=True)
@@ -75,9 +104,14 @@ def main():
             rounds = []
             for it in range(ROUNDS):
                 ms = [rank_ms(r, rows) for r in range(n)]
+                merge_ms = primary_merge_ms(rows)
                 rounds.append({"scheduler": "naive" if it == 0 else f"perfect, frame {it + 1}", "rows": rows, "ms_per_rank": [round(v, 3) for v in ms],
                                "slowest_ms": round(max(ms), 3), "speedup_vs_1gpu": round(one / max(ms), 2), "efficiency": round(one / max(ms) / n, 3),
-                               "n_times_slowest_over_1gpu": round(n * max(ms) / one, 3), "sum_of_ranks_over_1gpu": round(sum(ms) / one, 3)})
+                               "n_times_slowest_over_1gpu": round(n * max(ms) / one, 3), "sum_of_ranks_over_1gpu": round(sum(ms) / one, 3),
+                               # the primary's per-frame merge work (reset + n k_aggregate + tone-map + sync).  In bench.py it runs one frame behind the
+                               # tracing on rank 0's host thread, i.e. it ADDS to rank 0's frame: the column below is the frame time with it
+                               "primary_merge_ms": round(merge_ms, 3), "slowest_ms_with_primary_merge": round(max([ms[0] + merge_ms] + ms[1:]), 3),
+                               "speedup_vs_1gpu_with_primary_merge": round(one / max([ms[0] + merge_ms] + ms[1:]), 2)})
                 print(cfg, n, rounds[-1], flush=True)
                 rows = sched.schedule(H, block_h=rows, render_ns=[int(v * 1e6) for v in ms])  # the next frame's rows, from this frame's times
             out["N"][str(n)] = rounds

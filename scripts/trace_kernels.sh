@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT
 for mode in "${VARIANTS:-base:}"; do
   lib=${mode%%:*}; opt=${mode#*:}
   rm -rf gpurun_out/kt
-  POLARIS_HIP_LIB=$([ "$lib" = base ] && echo polaris_amd/lib/libpolaris_hip.so || echo polaris_amd/lib/exp/$lib.so) rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/kt -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timers --opt overlap=1 $opt > /dev/null 2>&1
+  POLARIS_HIP_LIB=$([ "$lib" = base ] && echo polaris_amd/lib/libpolaris_hip.so || echo gpurun_in/variants/$lib.so) rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/kt -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timers --opt overlap=1 $opt > /dev/null 2>&1
   echo "== $lib $opt"
   python3 - <<'PY'
 import csv, glob

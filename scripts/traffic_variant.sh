@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
 names=$1; sym=$2; shift 2
 for lib in $names; do
-  L=polaris_amd/lib/libpolaris_hip.so; [ "$lib" != base ] && L=polaris_amd/lib/exp/$lib.so
+  L=polaris_amd/lib/libpolaris_hip.so; [ "$lib" != base ] && L=gpurun_in/variants/$lib.so
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf gpurun_out/tv
     POLARIS_HIP_LIB=$L rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/tv" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timers "$@" > /dev/null 2>&1

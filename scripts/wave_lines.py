@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """scripts/wave_lines.py -- the go / no-go measurement for a coherence reorder of the bounce rays on the scenes whose tree does
 not fit LDS (run inside gpurun; build the variant first on the build machine:
-    scripts/build_variant.sh reorder -DPOLARIS_PROFILE_LOOPS -DPOLARIS_EXP_REORDER).
+    scripts/build_variant.sh reorder --patch reorder --patch profile_loops -DPOLARIS_PROFILE_LOOPS -DPOLARIS_EXP_REORDER).
 
 For terrain / C4 (material-ball) / C5 (instanced), in the kernel's REAL wave assignment (persistent waves, lane refill): distinct
 128-byte lines per wave-level node step and per triangle round, lines per ray, and the time of the k_trace launches themselves,
@@ -104,7 +104,7 @@ def main():
     if len(sys.argv) > 2 and sys.argv[2] == "--child":
         return child(sys.argv[1])
     tag = sys.argv[1] if len(sys.argv) > 1 else "rXX"
-    env = dict(os.environ, POLARIS_DEBUG="1", POLARIS_HIP_LIB=os.path.join(ROOT, "polaris_amd/lib/exp/reorder.so"))
+    env = dict(os.environ, POLARIS_DEBUG="1", POLARIS_HIP_LIB=os.path.join(ROOT, "gpurun_in/variants/reorder.so"))
     p = subprocess.run([sys.executable, os.path.abspath(__file__), tag, "--child"], env=env, stderr=subprocess.PIPE, text=True, cwd=ROOT)
     log = p.stderr
     open(os.path.join(ROOT, "gpurun_out", f"{tag}_wave_lines_raw.log"), "w").write(log)

@@ -200,6 +200,57 @@ class ShmPort:
                 seg.unlink()
 
 
+def _synthetic_frame(f, Hh):
+    """What frame f must look like once assembled (fuzz mode): exact in float32, different in every pixel, channel and frame."""
+    y, x, c = np.meshgrid(np.arange(Hh, dtype=np.float32), np.arange(W, dtype=np.float32), np.arange(4, dtype=np.float32), indexing="ij")
+    return (np.float32(f) * 4096.0 + y * 32.0 + x * 0.25 + c * 0.0625).astype(np.float32)
+
+
+def _fuzz_worker(rank, world, port, out_path, scheduler, Hh, frames):
+    """PeerExchange under a RANDOMISED schedule: every rank sleeps a seeded random time before and after
+    every "Trace" of every frame (0 - 20 ms, most of them short, so that any rank may be the one running ahead or lagging in any
+    frame), the ring is poisoned at the start of every Trace, and with the perfect scheduler the made-up times are random too, so the
+    rows change every frame.  The traced block is a synthetic pattern: the protocol is what is under test, not the tracer."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import datetime
+    import random
+    import time
+
+    import torch.distributed as dist
+
+    from polaris_amd.distributed import PeerExchange, block_of
+
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    shm = ShmPort(rank, W, Hh)
+    px = PeerExchange(dist, rank, world, W, Hh, shm, scheduler=scheduler)
+    assert px.setup()
+    rng = random.Random(20261004 + 7919 * rank)
+    delays = (0.0, 0.0, 0.0, 0.0005, 0.001, 0.002, 0.004, 0.008, 0.02)
+    pending, all_rows = [], []
+    for f in range(frames):
+        rows = px.next_rows()
+        all_rows.append(list(rows))
+        by, bh = block_of(rank, rows)
+        time.sleep(rng.choice(delays))
+        shm.trace(_synthetic_frame(f, Hh), by, bh)
+        time.sleep(rng.choice(delays))
+        while pending:
+            px.finish(pending.pop(0))
+        pending.append(px.post(rows, rng.uniform(0.5, 4.0) * bh))   # made-up times: the perfect scheduler moves rows every frame
+    while pending:
+        px.finish(pending.pop(0))
+    if rank == 0:
+        np.save(out_path, np.stack(shm.frames))
+        np.save(out_path + ".rows.npy", np.array(all_rows))
+    dist.barrier()
+    px.close()
+    shm.release(unlink=False)
+    dist.barrier()
+    shm.release(unlink=True)
+    dist.destroy_process_group()
+
+
 def _peer_worker(rank, world, port, out_path, scheduler, slow_rank, H=H, fail_export_on=-1):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -336,3 +387,66 @@ def test_peer_exchange_refuses_a_ring_that_is_too_short():
 
     with pytest.raises(AssertionError, match="ring"):
         PeerExchange(None, 0, 2, 8, 8, None, depth=2)
+
+
+@pytest.mark.parametrize("scheduler", ["naive", "perfect"])
+def test_eight_rank_exchange_under_random_per_frame_delays(built, tmp_path, scheduler):
+    """100 frames x 8 ranks, a seeded random delay per rank PER FRAME on both sides of every Trace (not one rank held back by a
+    constant): whoever runs ahead or lags changes from frame to frame, so a ring slot reused one frame too early, a merge from the
+    wrong slot, or ranks disagreeing about the rows would show as NaNs (the poisoned slot) or as another frame's pattern.  Every
+    assembled frame must be exactly the frame's pattern (renderer/default.go:127-136,188-191: a worker per tracer, merges as they
+    finish)."""
+    import torch.multiprocessing as mp
+
+    world, Hh, frames = 8, 61, 100
+    out = str(tmp_path / "fuzz.npy")
+    mp.spawn(_fuzz_worker, args=(world, _free_port(), out, scheduler, Hh, frames), nprocs=world, join=True)
+    got = np.load(out)
+    all_rows = np.load(out + ".rows.npy").tolist()
+    assert got.shape == (frames, Hh, W, 4) and np.isfinite(got).all()
+    assert all(len(r) == world and sum(r) == Hh and min(r) >= 1 for r in all_rows)
+    if scheduler == "perfect":
+        assert len({tuple(r) for r in all_rows}) > 10          # the rows really moved
+    for f in range(frames):
+        assert np.array_equal(got[f], _synthetic_frame(f, Hh)), f
+
+
+def test_device_for_rank_covers_the_launch_shapes():
+    """Every rank sees all GPUs (LOCAL_RANK picks), every rank masked to one device (index 0 everywhere), more ranks than
+    devices (wrap around -- bench.py's distinct_gpus then says so), no device at all."""
+    from polaris_amd.distributed import device_for_rank
+
+    assert [device_for_rank(r, 8)[0] for r in range(8)] == list(range(8)) and device_for_rank(5, 8)[1] == "LOCAL_RANK"
+    assert [device_for_rank(r, 1)[0] for r in range(8)] == [0] * 8
+    assert device_for_rank(0, 1)[1] == "LOCAL_RANK" and "one visible device" in device_for_rank(3, 1)[1]
+    assert [device_for_rank(r, 2)[0] for r in range(4)] == [0, 1, 0, 1] and "more ranks than devices" in device_for_rank(3, 2)[1]
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        device_for_rank(0, 0)
+
+
+def _setup_error_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import datetime
+    import json
+
+    import torch.distributed as dist
+
+    from polaris_amd.distributed import gather_setup_errors
+
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    a = gather_setup_errors(dist, rank, world, "")                                                # everybody fine
+    b = gather_setup_errors(dist, rank, world, "hipErrorNoDevice: boom" if rank == 1 else "")       # one rank failed
+    json.dump([a, b], open(os.path.join(out_dir, f"r{rank}.json"), "w"))
+    dist.destroy_process_group()
+
+
+def test_setup_errors_reach_every_rank(tmp_path):
+    import json
+
+    import torch.multiprocessing as mp
+
+    mp.spawn(_setup_error_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    for r in range(3):
+        a, b = json.load(open(tmp_path / f"r{r}.json"))
+        assert a == [] and b == ["rank 1: hipErrorNoDevice: boom"]
