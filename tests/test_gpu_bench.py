@@ -114,7 +114,9 @@ def _one_gpu_shared_by(d, ranks, chosen_by):
     assert d["n_gpus"] == ranks and cfg["distinct_gpus"] == 1 and len(cfg["devices"]) == ranks
     assert [e["rank"] for e in cfg["devices"]] == list(range(ranks))
     assert len({(e["pci_bus_id"], e["uuid"]) for e in cfg["devices"]}) == 1 and len({e["pid"] for e in cfg["devices"]}) == ranks
-    assert all(e["hip_index"] == 0 and chosen_by in e["device_chosen_by"] for e in cfg["devices"]), cfg["devices"]
+    # (under a per-rank mask rank 0's LOCAL_RANK 0 IS the one visible device: it says "LOCAL_RANK", the others say why they took index 0)
+    assert all(e["hip_index"] == 0 and (chosen_by in e["device_chosen_by"] or (e["local_rank"] == 0 and e["device_chosen_by"] == "LOCAL_RANK"))
+               for e in cfg["devices"]), [(e["local_rank"], e["device_chosen_by"]) for e in cfg["devices"]]
     x = cfg["exchange_detail"]
     if x["mode"] == "hip-ipc":
         assert [p["rank"] for p in x["peers"]] == list(range(1, ranks))

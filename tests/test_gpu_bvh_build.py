@@ -166,6 +166,59 @@ def test_a_mesh_dense_in_one_morton_cell_builds_with_the_sah_builder(built, orac
         assert "stack" in str(e) or "deep" in str(e), str(e)
 
 
+def _outlier_chain_mesh():
+    """Geometrically spaced outliers: a cluster of 5 000 triangles at the origin and 48 tiny triangles at
+    +-0.05 x 32^k along the three axes, k = 1 .. 8 (up to 5.5e10: inside the upload's coordinate bound).  A 16-bin split of a node
+    that still holds the outermost outlier finds everything else in its first bin: the cheapest plane peels that ONE triangle off,
+    level after level -- ~48 levels before the cluster's own log2(2 500) = 12 begin, twice the 32-entry traversal stack."""
+    from polaris_amd import scenes
+
+    rng = np.random.default_rng(11)
+    n = 5000
+    c = rng.uniform(-0.01, 0.01, (n, 1, 3))
+    tri = c + rng.uniform(-0.05, 0.05, (n, 3, 3))
+    far = []
+    for k in range(1, 9):
+        for axis in range(3):
+            for sign in (1.0, -1.0):
+                p = np.zeros(3)
+                p[axis] = sign * 0.05 * 32.0 ** k
+                far.append(p + np.array([[0, 0, 0], [1e-3, 0, 0], [0, 1e-3, 0]]))
+    verts = np.concatenate([tri, np.array(far)]).astype(np.float32)
+    mt = scenes.MaterialTable()
+    d, e = mt.diffuse((0.7, 0.7, 0.7)), mt.emissive((8, 8, 8))
+    mat = np.full(len(verts), d, np.uint32)
+    mat[:40] = e
+    mesh = scenes.Mesh(verts, scenes._flat_normals(verts), np.zeros((len(verts), 3, 2), np.float32), mat)
+    sc = scenes.compile_scene([mesh], [(0, np.eye(4))], mt, max_leaf=4, name="outlier-chain")
+    sc.set_camera(eye=(0.0, 0.0, 1.2), look=(0.0, 0.0, 0.0), fov=0.5, aspect=80 / 60)
+    return sc
+
+
+def test_geometrically_spaced_outliers_stay_inside_the_depth_budget(built, oracle):
+    """The SAH builder's depth budget (bvh_build.hip, sah_levels_needed): a split that would leave a child more items than the
+    remaining levels can finish is replaced by a halving by position, so the chain the outliers start is cut where the cluster
+    still fits below it -- a valid tree within the traversal stack, traced bit for bit like the oracle.  (Without the budget the
+    chain runs ~48 levels and upload_scene refuses the tree.)"""
+    from oracle import pybind as ob
+    from polaris_amd import bvh_build, scenes
+
+    old = _outlier_chain_mesh()
+    sc, info = bvh_build.rebuild_on_device(old, max_leaf_tris=2, algorithm="sah")
+    need = check_tree(sc, old)
+    assert 20 < need < 32, need          # the chain really formed (a balanced tree over 5 048 triangles needs 12) and was cut in time
+    W, H, spp, B = 80, 60, 2, 3
+    seeds = scenes.make_seeds(spp, B, base=3)
+    want, wst, _ = oracle.trace(sc, ob.make_request(W, H, spp=spp, bounces=B), seeds)
+    tr = make_hip_tracer(sc, W, H, exact_accumulate=1)
+    try:
+        tr.Trace(ob.make_request(W, H, spp=spp, bounces=B), seeds)
+        got = tr.read_accumulator(0)
+    finally:
+        tr.Close()
+    assert want[..., :3].sum() > 0 and np.array_equal(bits(got[..., :3]), bits(want[..., :3]))
+
+
 @pytest.mark.parametrize("name", ["material-ball", "terrain"])
 def test_sah_build_of_the_big_scenes_is_valid_and_traces_like_the_oracle(built, oracle, name):
     """The C4 scene (58 682 triangles: seven levels of big-node passes above the wave-per-node levels) and the 1 M-triangle terrain
@@ -230,6 +283,10 @@ def test_build_refuses_malformed_input(built):
     n = C.c_uint32()
     assert lib.polaris_hip_build_bvh(0, C.byref(inp), None, 0, C.byref(n), None, None, None) == 2
     assert b"null" in lib.polaris_hip_build_bvh_error()
+    inp.struct_size = 72                                                     # a caller built against ABI 4's layout
+    assert lib.polaris_hip_build_bvh(0, C.byref(inp), C.c_void_p(1), 8, C.byref(n), C.c_void_p(1), C.c_void_p(1), None) == 2
+    assert b"struct_size" in lib.polaris_hip_build_bvh_error()
+    inp.struct_size = C.sizeof(inp)
     verts = np.zeros((6, 4), np.float32)
     first, count = np.array([0], np.uint32), np.array([3], np.uint32)       # 3 triangles claimed, 2 present
     boxes, im = np.zeros((1, 6), np.float32), np.zeros(1, np.uint32)
