@@ -209,6 +209,17 @@ def issue_roofline(valu_per_launch, launches, ms_per_frame, lane_util, cus: int)
             "instructions_from": "SQ_INSTS_VALU of the same kernel symbol on the same workload (see counters_source); time: this run's HIP events"}
 
 
+def ray_counts(st, B: int):
+    """PolarisTraceStats of one Trace as a dict: rays per bounce by class, the shading events, and the occluded fraction of the shadow rays."""
+    if st is None:
+        return None
+    occl, un = int(st.occlusion_rays), int(st.unoccluded)
+    return {"closest_hit_rays_per_bounce": [int(v) for v in st.rays_per_bounce[:B]], "shadow_rays_per_bounce": [int(v) for v in st.occl_per_bounce[:B]],
+            "primary_rays": int(st.primary_rays), "indirect_rays": int(st.indirect_rays), "shadow_rays": occl, "unoccluded_shadow_rays": un,
+            "occluded_fraction": (1.0 - un / occl) if occl else None, "shaded_hits": int(st.shaded_hits), "shaded_misses": int(st.shaded_misses),
+            "emitter_hits": int(st.emitter_hits)}
+
+
 def host_cpu() -> str:
     """'<n> x <model name>' of the host the CPU baseline runs on (state the cores)."""
     try:
@@ -544,6 +555,7 @@ def main() -> None:
             detail["mode"] = "strips-rccl" if backend == "nccl" else "strips-gloo"
             detail["peers"] = [{"rank": r, "branch": detail["mode"]} for r in range(1, world)]
     totals = {k: 0 for k in ("primary_rays", "indirect_rays", "occlusion_rays", "shaded_hits", "shaded_misses", "emitter_hits", "unoccluded")}
+    last_counts = [None]                           # PolarisTraceStats of this rank's last timed Trace (config.ray_counts)
     pending = []
     rows_log = []
 
@@ -594,6 +606,7 @@ def main() -> None:
             for k in totals:
                 totals[k] += int(getattr(st, k))
             rows_log.append(list(rows))
+            last_counts[0] = st
         if world == 1:
             tr.MergeOutput(tr, req)                # primary merges its own block (default.go:191)
             tr.SyncFramebuffer(make_req(0, H) if not args.emulate_rank else req)
@@ -692,7 +705,10 @@ def main() -> None:
                        "rows_first_timed_frame": rows_log[0] if rows_log else None, "rows_last_frame": rows_log[-1] if rows_log else None,
                        "bvh": "as compiled with the scene" if bvh_info is None else {"built_on_device": bvh_info}, "exchange": exchange, "perfect_scheduler" if (second or {}).get("scheduler") == "perfect" else "second_scheduler": second,
                        "frame": [W, H], "spp": spp, "bounces": B, "rays_per_frame": rays // args.steps,
-                       "paths_per_s": W * H * spp * args.steps / elapsed},
+                       "paths_per_s": W * H * spp * args.steps / elapsed,
+                       # the ray population of rank 0's block in the last timed frame, per bounce (PolarisTraceStats): what anyone reasoning about
+                       # the any-hit kernel needs first -- how many shadow rays there are and how many of them are blocked
+                       "ray_counts": ray_counts(last_counts[0], B)},
         }
         # ---- roofline, per kernel symbol -----------------------------------------------------------
         # Kernel durations are HIP events on the tracer's own streams (the library brackets every launch

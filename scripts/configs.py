@@ -82,6 +82,7 @@ def main():
         d = json.loads(line[-1])
         out["configs"][key] = {"what": what, "args": args, "Mrays_per_s": round(d["value"], 1), "ms_per_frame": round(d["ms_per_frame"], 2),
                                "rays_per_frame": d["config"]["rays_per_frame"], "workload": d["config"]["workload"],
+                               "ray_counts": d["config"].get("ray_counts"),   # per bounce and per class, with the occluded fraction of the shadow rays
                                "kernels_isolated_ms_per_frame": d.get("kernels_isolated_ms_per_frame"), "roofline": d.get("roofline"),
                                "roofline_per_kernel": {k: {f: v.get(f) for f in ("timer", "ms_per_frame", "launches", "achieved", "frac")} for k, v in (d.get("roofline_per_kernel") or {}).items()}}
         print(key, out["configs"][key]["Mrays_per_s"], "Mrays/s", out["configs"][key]["ms_per_frame"], "ms/frame", flush=True)

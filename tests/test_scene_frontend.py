@@ -418,3 +418,26 @@ def test_oracle_traces_the_obj_scene(tmp_path, oracle):
     acc, st, _ = oracle.trace(sc, req, scenes.make_seeds(4, 4, base=3))
     assert np.isfinite(acc).all() and acc[..., :3].mean() > 0.05
     assert st.primary_rays == 24 * 24 * 4 and st.shaded_hits > 0 and st.occlusion_rays > 0
+
+
+def test_the_references_own_scene_fixture_compiles_to_the_golden_arrays():
+    """tracer/opencl/fixtures/cube.obj + cube.mtl -- the one scene file the reference ships (a 12-triangle cube `instance`d twice with scale
+    arguments of 0, which types.Scale4 reads as 1: types/matrix.go:42-53) -- read WHERE IT LIES through wavefront_reader.cpp ->
+    scene_compiler.cpp must give exactly the arrays tests/golden/reference_cube_32.npz was traced from by the compiled reference
+    (tests/tools/make_golden.py; the golden stores arrays, never the file's text).  Build container only: the GPU box has no
+    /root/reference, there the golden itself carries the fixture (tests/test_oracle_golden.py, test_hip_reproduces_reference_golden)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import make_golden
+
+    if not os.path.exists(make_golden.REFERENCE_CUBE):
+        pytest.skip("the reference tree is not on this machine")
+    from conftest import load_golden
+
+    d, want, _ = load_golden(os.path.join(ROOT, "tests", "golden", "reference_cube_32.npz"))
+    sc = make_golden.build_scene("reference-cube", 1.0)
+    assert sc.num_triangles == 12 and len(sc.mesh_instances) == 2 and len(sc.emissives) == 1      # 12 triangles x 2 instances + the harness's environment light
+    for name in ("bvh_nodes", "mesh_instances", "material_nodes", "emissives", "vertices", "normals", "uvs", "material_index"):
+        assert np.asarray(getattr(sc, name)).tobytes() == np.asarray(getattr(want, name)).tobytes(), name
+    # the two instances: the cube where it is, and one unit to the left (the inverse transform carries +1 in x)
+    inv = sc.mesh_instances["inv_transform"].reshape(2, 4, 4)
+    assert np.array_equal(inv[0], np.eye(4, dtype=np.float32)) and inv[1][3, 0] == 1.0 and np.array_equal(inv[1][:3, :3], np.eye(3, dtype=np.float32))

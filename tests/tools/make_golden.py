@@ -34,7 +34,14 @@ CASES = [
     # the C4 stand-in at low tessellation: bump-mapped mix of rough conductor over diffuse, rough glass, textured floor,
     # two area lights + environment, 16:9, an inner row block
     ("material_ball_48", "material-ball-small", 48, 27, 3, 5, 3, 5, 17),
+    # the ONE scene file the reference ships: tracer/opencl/fixtures/cube.obj + cube.mtl (a 12-triangle cube, `instance`d twice -- with
+    # scale arguments of 0, which types.Scale4 reads as 1 -- one diffuse material, no light, no camera), read where it lies through the
+    # C++ reader + compiler.  The harness adds what a render needs and the file lacks -- a camera and an environment light -- in a wrapper
+    # scene that `call`s the fixture; only the compiled ARRAYS are stored, never the file's text.
+    ("reference_cube_32", "reference-cube", 32, 32, 4, 5, 3, 0, 32),
 ]
+
+REFERENCE_CUBE = "/root/reference/tracer/opencl/fixtures/cube.obj"
 
 
 def build_scene(key, aspect):
@@ -46,6 +53,20 @@ def build_scene(key, aspect):
         from polaris_amd import host_api
 
         return host_api.read_scene(obj_fixtures.write_cornell(tempfile.mkdtemp()), aspect=aspect)
+    if key == "reference-cube":
+        import tempfile
+
+        from polaris_amd import host_api
+
+        d = tempfile.mkdtemp()
+        with open(os.path.join(d, "sky.mtl"), "w") as f:     # the harness's own: an environment light and a background
+            f.write("newmtl scene_emissive_material\nKe 1.6 1.5 1.3\nnewmtl scene_diffuse_material\nKd 0.25 0.3 0.4\n")
+        with open(os.path.join(d, "wrapper.obj"), "w") as f:
+            f.write(f"call {os.path.relpath(REFERENCE_CUBE, d)}\nmtllib sky.mtl\ncamera_fov 0.7\ncamera_eye 1.1 1.3 2.4\ncamera_look -0.5 0 0\ncamera_up 0 1 0\n")
+        sc = host_api.read_scene(os.path.join(d, "wrapper.obj"), aspect=aspect)
+        sc.name = "reference-cube"
+        assert sc.num_triangles == 12 and len(sc.mesh_instances) == 2, "the reference's fixture is a 12-triangle cube instanced twice"
+        return sc
     return scenes.SCENES[key](aspect)
 
 
@@ -57,6 +78,9 @@ def main():
     only = set(sys.argv[1:])  # optional: fixture names to (re)generate
     for name, key, W, H, spp, B, rr, by, bh in CASES:
         if only and name not in only:
+            continue
+        if key == "reference-cube" and not os.path.exists(REFERENCE_CUBE):
+            print(f"{name}: skipped, {REFERENCE_CUBE} is not here (the build container has it)")
             continue
         sc = build_scene(key, W / H)
         seeds = scenes.make_seeds(spp, B, base=0xC0FFEE + len(name))
