@@ -260,7 +260,7 @@ func (tr *Tracer) ReadFrameBuffer(pix []uint8) error {
 // ---- one tracer per PROCESS (INTEGRATION.md section 3b): the merge as a peer read through HIP IPC --------------------------
 
 // IpcExport turns the trace accumulator into a ring of `depth` buffers (every Trace writes the next; TraceSlot says which) and
-// returns the 544-byte blob another process opens with IpcOpen.  Plain bytes: send them over any channel.
+// returns the 576-byte blob (ABI 5: it carries the exporting GPU's PCI bus id) another process opens with IpcOpen.  Plain bytes: send them over any channel.
 func (tr *Tracer) IpcExport(depth uint32) ([]byte, error) {
 	var x C.PolarisIpcExport
 	if err := tr.check(C.polaris_hip_ipc_export(tr.handle, C.uint32_t(depth), &x)); err != nil {
@@ -290,6 +290,44 @@ func (tr *Tracer) MergeIpc(peer *Peer, slot uint32, blockReq *tracer.BlockReques
 	start := time.Now()
 	creq := toC(blockReq)
 	return time.Since(start), tr.check(C.polaris_hip_merge_ipc(tr.handle, peer.p, C.uint32_t(slot), &creq))
+}
+
+// PeerInfo says what a mapped ring really is (ABI 5): the exporter's GPU by PCI bus id, whether that is this tracer's own GPU (a
+// second mapping of local memory) or another one (reads cross xGMI / PCIe), and hipDeviceCanAccessPeer towards it (-1 unknown).
+type PeerInfo struct {
+	Pid           uint32
+	PCIBusID      string
+	SameDevice    int
+	LocalDevice   int
+	CanAccessPeer int
+	HasEvents     bool
+}
+
+func (p *Peer) Info() (PeerInfo, error) {
+	var i C.PolarisPeerInfo
+	i.struct_size = C.uint32_t(unsafe.Sizeof(i))
+	if rc := C.polaris_hip_peer_info(p.p, &i); rc != C.POLARIS_OK {
+		return PeerInfo{}, fmt.Errorf("hip: peer_info failed (%d)", int(rc))
+	}
+	return PeerInfo{Pid: uint32(i.pid), PCIBusID: C.GoString(&i.pci_bus_id[0]), SameDevice: int(i.same_device), LocalDevice: int(i.local_device),
+		CanAccessPeer: int(i.can_access_peer), HasEvents: i.has_events != 0}, nil
+}
+
+// MergeBranches names the entries of MergeCounts (POLARIS_MERGE_* in polaris_hip.h).
+var MergeBranches = [...]string{"local", "peer-access", "staged", "ipc-local", "ipc-peer", "ipc-unknown", "device-strip"}
+
+// MergeCounts reports which branch the merges onto this tracer took since it was created: a staged copy where a peer read was
+// expected, or a mapping of local memory where another GPU was, shows here instead of in a timing nobody can explain.
+func (tr *Tracer) MergeCounts() (map[string]uint64, error) {
+	var c [C.POLARIS_MERGE_BRANCHES]C.uint64_t
+	if err := tr.check(C.polaris_hip_merge_counts(tr.handle, &c[0])); err != nil {
+		return nil, err
+	}
+	out := make(map[string]uint64, len(c))
+	for i, name := range MergeBranches {
+		out[name] = uint64(c[i])
+	}
+	return out, nil
 }
 
 // TraceSlot is the ring slot the last Trace wrote (0 without a ring).

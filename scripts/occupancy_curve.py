@@ -41,6 +41,9 @@ def main():
     seeds = scenes.make_seeds(spp, B)
     tr = HipTracer("occ", 0)
     tr.Init()
+    for kv in filter(None, os.environ.get("EXTRA_OPTS", "").split(",")):      # e.g. EXTRA_OPTS=trace_spill=1 PER_CU=5,6,7,8 (options that shape the upload)
+        k, v = kv.split("=")
+        tr.set_option(k, int(v))
     tr.UpdateState(UpdateMode.Synchronous, ChangeType.FrameDimensions, (W, H))
     tr.UpdateState(UpdateMode.Synchronous, ChangeType.SceneData, sc)
     tr.UpdateState(UpdateMode.Synchronous, ChangeType.CameraData, sc)
@@ -67,7 +70,7 @@ def main():
         wall = (time.perf_counter() - t) / frames * 1e3
         st = tr.last_trace_stats
         ms = {n: tr.kernel_ms(n) for n in names}
-        out = {"config": cfg, "scene": sc.name, "frame": [W, H], "spp": spp, "trace_wgs_per_cu": per_cu, "grid_threads": tr.device_cus * per_cu * 256,
+        out = {"config": cfg, "options": os.environ.get("EXTRA_OPTS", ""), "any_symbol": tr.kernel_symbol("occlusion") if not pmc else None, "scene": sc.name, "frame": [W, H], "spp": spp, "trace_wgs_per_cu": per_cu, "grid_threads": tr.device_cus * per_cu * 256,
                "frame_ms_overlap1": round(wall, 3), "rays": st.total_rays(),
                "closest_hit_ms_per_frame": round(ms["intersect"][0] / frames, 3), "closest_hit_launches": ms["intersect"][1] // frames,
                "any_hit_ms_per_frame": round(ms["occlusion"][0] / frames, 3), "any_hit_launches": ms["occlusion"][1] // frames,

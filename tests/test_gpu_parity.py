@@ -685,6 +685,78 @@ def test_big_scene_kernel_variants_agree_with_the_oracle(built, oracle, name):
         assert np.array_equal(bits(got[..., :3]), bits(want[..., :3])), opts
 
 
+def _nested_shells_scene(n=22):
+    """A tree whose rays NEED a deep stack: n camera-facing triangles at z = -0.05 x 1.6^k, each 1.6^k big (every camera ray's line
+    crosses every one of their boxes), under a HAND-MADE BVH in the reference's encoding (optimized_scene.go:14-64): a chain that splits
+    the outermost triangle off per level -- node j = { leaf of triangle n-1-j, node j+1 }.  Both children of every node lie on a camera
+    ray; the traversal takes the nearer one (the rest of the chain) first and pushes the far leaf: one stack entry per level, n - 1 = 21
+    of them, well beyond the 16 the spill variant keeps in LDS.  (Any tree whose boxes bound their contents is a valid input.)  A light
+    behind the camera faces the shells: the innermost one is lit, its shadow rays walk the same chain."""
+    from polaris_amd import ctypes_api as T
+    from polaris_amd import scenes
+
+    tris = []
+    for k in range(n):
+        sz, z = 0.15 * 1.6 ** k, -0.05 * 1.6 ** k
+        tris.append([[-sz, -sz, z], [sz, -sz, z], [0.0, 1.5 * sz, z]])
+    tris.append([[-2.0, -2.0, 3.0], [0.0, 3.0, 3.0], [2.0, -2.0, 3.0]])      # the light: behind the camera, facing the shells (-z)
+    n += 1
+    verts = np.asarray(tris, np.float32)
+    mt = scenes.MaterialTable()
+    d, e = mt.diffuse((0.6, 0.7, 0.8)), mt.emissive((3, 3, 3))
+    mat = np.full(n, d, np.uint32)
+    mat[-1] = e
+    mesh = scenes.Mesh(verts, scenes._flat_normals(verts), np.zeros((n, 3, 2), np.float32), mat)
+    sc = scenes.compile_scene([mesh], [(0, np.eye(4))], mt, max_leaf=1, name="nested-shells")
+    sc.set_camera(eye=(0.0, 0.0, 1.0), look=(0.0, 0.0, -1.0), fov=0.4, aspect=4 / 3)
+    v = sc.vertices[:, :3].reshape(n, 3, 3)
+    order = np.argsort(-v[:, 0, 2], kind="stable")   # compiled triangle indices, nearest (largest z) first
+    nodes = np.zeros(2 * n, T.BVH_NODE)
+    lo, hi = v.min(axis=1), v.max(axis=1)
+    nodes[0] = (lo.min(axis=0), 0, hi.max(axis=0), 0)                         # the top-level tree: one leaf = instance 0
+    for k in range(n):                                                        # leaf of the k-th nearest triangle: node n + k
+        t = int(order[k])
+        nodes[n + k] = (lo[t], -t, hi[t], 1)
+    for j in range(n - 1):                                                    # inner node j: node 1 + j over the j-th .. nearest triangles
+        members = order[: n - j]
+        far_leaf = n + (n - 1 - j)
+        rest = 1 + j + 1 if j + 1 < n - 1 else n + 0                          # the last inner node holds the two nearest leaves
+        nodes[1 + j] = (lo[members].min(axis=0), far_leaf, hi[members].max(axis=0), rest)
+    sc.bvh_nodes = nodes
+    sc.mesh_instances["bvh_root"] = 1
+    return sc
+
+
+def test_rays_that_hold_twenty_stack_entries(built, oracle):
+    """The deep end of the per-lane node stack: on the nested-shells chain every camera ray holds one entry per level, 20 and more --
+    the 24-entry LDS variant of k_trace (max_stack is computed exactly at upload and picks it), closest hit and any hit, exact and
+    batched: the oracle's frame bit for bit / within 1e-6.  (Also the regression scene of the round-6 experiment that kept only 16
+    entries in LDS: polaris_amd/csrc/experiments/trace_spill.patch.)"""
+    from oracle import pybind as ob
+    from polaris_amd import scenes
+
+    sc = _nested_shells_scene()
+    W, H, spp, B = 64, 48, 3, 4
+    seeds = scenes.make_seeds(spp, B, base=5)
+    want, wst, _ = oracle.trace(sc, ob.make_request(W, H, spp=spp, bounces=B, rr=2), seeds)
+    assert wst.shaded_hits > 0 and want[..., :3].sum() > 0 and wst.occlusion_rays > 0
+    for opts in ({"exact_accumulate": 1}, {"exact_accumulate": 0}, {"exact_accumulate": 1, "traversal": 0}):
+        tr = make_hip_tracer(sc, W, H, time_kernels=1, node_mode=0, max_leaf_tris=0, **opts)
+        try:
+            tr.Trace(ob.make_request(W, H, spp=spp, bounces=B, rr=2), seeds)
+            got, st = tr.read_accumulator(0), tr.last_trace_stats
+            syms = (tr.kernel_symbol("intersect"), tr.kernel_symbol("occlusion"))
+        finally:
+            tr.Close()
+        if opts.get("traversal", 1):
+            assert syms == ("pol::k_trace<false, 24, 0, false>", "pol::k_trace<true, 24, 0, false>"), syms   # 17 .. 24 entries needed
+        assert counters(st, B) == counters(wst, B), opts
+        if opts["exact_accumulate"]:
+            assert np.array_equal(bits(got[..., :3]), bits(want[..., :3])), opts
+        else:
+            assert rmse(got, want, spp) <= 1e-6
+
+
 @pytest.mark.parametrize("name,one", [("cornell", True), ("sphere", True), ("cubes", False), ("transformed", False)])
 def test_tiny_scene_kernel_variants_are_selected_as_documented(built, oracle, name, one):
     """Tiny-scene mode (whole tree + triangle records in LDS): scenes that ARE one instance with bounding boxes run the variant
