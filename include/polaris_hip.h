@@ -126,7 +126,7 @@ int polaris_hip_set_camera(polaris_hip_tracer *h, const float eye[3], const floa
  *                        2 up to 32 K triangles, 4 above; 0 = keep the caller's leaves).  Never
  *                        changes a result: DESIGN.md 2 (HBM data layout)
  *   further A/B switches of the kernels ("traversal", "node_mode", "packet_shadow", "shade_wave",
- *   "shade_wave_from", "shade_sort", "shade_wgs_per_cu", "stage_lds", "trace_wgs_per_cu", "trace_grid", "hit12", "o12"): see
+ *   "shade_wave_from", "shade_sort", "shade_wgs_per_cu", "stage_lds", "trace_wgs_per_cu", "trace_grid", "hit12", "o12", "ipc_staged"): see
  *   DESIGN.md 3.  Apart from "exact_accumulate" (the order of the float sums) no option changes a
  *   result; an unknown key is POLARIS_E_BAD_ARGUMENT.  The batch size chosen automatically
  *   ("samples_per_batch" = 0) is clamped by the FREE device memory, and with it the order of the
@@ -215,7 +215,10 @@ int polaris_hip_ipc_close(polaris_hip_tracer *dst, polaris_hip_peer *peer); /* w
 /* What a mapped ring really is (ABI 5): the exporter's GPU by PCI bus id, whether that is dst's OWN GPU (the mapping is then a second
  * mapping of local memory: ranks sharing a device, the one-GPU tests) or ANOTHER one (reads cross xGMI / PCIe), the exporter's GPU as a
  * device index of this process (-1: not visible here, e.g. under a per-rank visibility mask) and hipDeviceCanAccessPeer towards it
- * (-1: unknown).  The caller sets struct_size. */
+ * (-1: unknown).  ipc_open REFUSES (POLARIS_E_UNSUPPORTED) a ring on another GPU that this process cannot see at all -- there is no way to
+ * tell whether the mapping would be reachable, and a kernel that reads an unreachable mapping faults the GPU; the caller falls back to
+ * its strip transfers -- and marks a ring on a visible GPU without peer access for the staged path (POLARIS_MERGE_IPC_STAGED; option
+ * "ipc_staged" = 1 forces that path for the peers opened afterwards: a testing aid).  The caller sets struct_size. */
 typedef struct PolarisPeerInfo {
 	uint32_t struct_size;
 	uint32_t pid;             /* exporting process */
@@ -225,6 +228,8 @@ typedef struct PolarisPeerInfo {
 	int32_t can_access_peer;  /* hipDeviceCanAccessPeer(dst's device, local_device); -1 = unknown */
 	uint32_t depth, has_events;
 	char pci_bus_id[32];
+	int32_t staged;           /* 1: merges from this ring go through the staging strip (no peer access, or forced); 0: read where it lies */
+	int32_t reserved;
 } PolarisPeerInfo;
 int polaris_hip_peer_info(polaris_hip_peer *peer, PolarisPeerInfo *out);
 /* dst.frameAccumulator[rows of req] += peer.traceAccumulator ring[slot][rows of req]; asynchronous on dst's merge stream
@@ -242,7 +247,10 @@ int polaris_hip_merge_slot(polaris_hip_tracer *dst, polaris_hip_tracer *src, uin
  *   PEER_ACCESS   ... source on another GPU of this process, read directly (hipDeviceEnablePeerAccess: xGMI peer read)
  *   STAGED        ... source on another GPU, no peer access: hipMemcpyPeerAsync into a staging strip, then added
  *   IPC_LOCAL     polaris_hip_merge_ipc, the peer's ring lives on dst's own GPU
- *   IPC_PEER      polaris_hip_merge_ipc, the peer's ring lives on another GPU (IPC_UNKNOWN: the exporter gave no bus id)
+ *   IPC_PEER      polaris_hip_merge_ipc, the peer's ring lives on another GPU and is read directly (IPC_UNKNOWN: the exporter gave no bus id)
+ *   IPC_STAGED    polaris_hip_merge_ipc, the ring lives on a GPU this one has NO peer access to (hipDeviceCanAccessPeer = 0): the rows are
+ *                 copied into a staging strip by the runtime (hipMemcpyAsync, which may go through the host) and added from there --
+ *                 a kernel is never pointed at memory the device cannot reach
  *   DEVICE_STRIP  polaris_hip_merge_device (a strip some transport delivered: bench.py's fallback)
  * bench.py reports them in config.exchange_detail: a fallback that ran silently shows in the numbers' own line. */
 #define POLARIS_MERGE_LOCAL 0
@@ -252,7 +260,8 @@ int polaris_hip_merge_slot(polaris_hip_tracer *dst, polaris_hip_tracer *src, uin
 #define POLARIS_MERGE_IPC_PEER 4
 #define POLARIS_MERGE_IPC_UNKNOWN 5
 #define POLARIS_MERGE_DEVICE_STRIP 6
-#define POLARIS_MERGE_BRANCHES 7
+#define POLARIS_MERGE_IPC_STAGED 7
+#define POLARIS_MERGE_BRANCHES 8
 int polaris_hip_merge_counts(polaris_hip_tracer *dst, uint64_t counts[POLARIS_MERGE_BRANCHES]);
 
 /* The pipeline's Reset stage on its own (tracer/opencl/tracer.go:208-213: clearAccumulator(frameAccumulator)).

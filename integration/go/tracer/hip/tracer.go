@@ -301,6 +301,7 @@ type PeerInfo struct {
 	LocalDevice   int
 	CanAccessPeer int
 	HasEvents     bool
+	Staged        bool // merges from this ring go through a staging strip (no peer access to its GPU): a runtime copy, then the add
 }
 
 func (p *Peer) Info() (PeerInfo, error) {
@@ -310,11 +311,11 @@ func (p *Peer) Info() (PeerInfo, error) {
 		return PeerInfo{}, fmt.Errorf("hip: peer_info failed (%d)", int(rc))
 	}
 	return PeerInfo{Pid: uint32(i.pid), PCIBusID: C.GoString(&i.pci_bus_id[0]), SameDevice: int(i.same_device), LocalDevice: int(i.local_device),
-		CanAccessPeer: int(i.can_access_peer), HasEvents: i.has_events != 0}, nil
+		CanAccessPeer: int(i.can_access_peer), HasEvents: i.has_events != 0, Staged: i.staged != 0}, nil
 }
 
 // MergeBranches names the entries of MergeCounts (POLARIS_MERGE_* in polaris_hip.h).
-var MergeBranches = [...]string{"local", "peer-access", "staged", "ipc-local", "ipc-peer", "ipc-unknown", "device-strip"}
+var MergeBranches = [...]string{"local", "peer-access", "staged", "ipc-local", "ipc-peer", "ipc-unknown", "device-strip", "ipc-staged"}
 
 // MergeCounts reports which branch the merges onto this tracer took since it was created: a staged copy where a peer read was
 // expected, or a mapping of local memory where another GPU was, shows here instead of in a timing nobody can explain.

@@ -136,6 +136,7 @@ struct polaris_hip_tracer {
 	int num_cus = 256;
 	void *staging = nullptr; // peer-merge staging strip
 	size_t staging_bytes = 0;
+	int opt_ipc_staged = 0;  // testing aid: peers opened from now on are merged through the staging strip (the path of a GPU without peer access)
 
 	// options
 	int64_t opt_samples_per_batch = 0; // 0 = auto
@@ -943,6 +944,7 @@ int polaris_hip_set_option(polaris_hip_tracer *h, const char *key, int64_t value
 	else if (k == "shade_wgs_per_cu") h->opt_shade_wgs_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(value, 64));
 	else if (k == "stage_lds") h->opt_stage_lds = value != 0;
 	else if (k == "shade_sort") h->opt_shade_sort = (int)std::max<int64_t>(-1, std::min<int64_t>(value, POLARIS_MAX_BOUNCES));
+	else if (k == "ipc_staged") h->opt_ipc_staged = value != 0;
 	else if (k == "overlap") h->opt_overlap = (int)std::max<int64_t>(1, std::min<int64_t>(value, polaris_hip_tracer::kMaxPipes));
 	else if (k == "trace_grid") h->opt_trace_grid = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20));
 	else if (k == "trace_wgs_per_cu") h->opt_trace_wgs_per_cu = (int)std::max<int64_t>(0, std::min<int64_t>(value, 64));
@@ -1164,6 +1166,22 @@ static int merge_rows(polaris_hip_tracer *dst, polaris_hip_tracer *src, polaris_
 		if (getenv("POLARIS_DEBUG")) fprintf(stderr, "[polaris] merge_ipc: hipStreamWaitEvent on the peer's inter-process event failed; continuing with the host-side ordering\n");
 	}
 	int branch = peer ? (peer->info.same_device == 1 ? POLARIS_MERGE_IPC_LOCAL : (peer->info.same_device == 0 ? POLARIS_MERGE_IPC_PEER : POLARIS_MERGE_IPC_UNKNOWN)) : POLARIS_MERGE_LOCAL;
+	auto need_staging = [&]() -> bool { // the merge stream's staging strip, big enough for this block (merges are serialised on the stream)
+		if (dst->staging_bytes >= n * sizeof(float4)) return true;
+		(void)hipStreamSynchronize(q);
+		if (dst->staging) (void)hipFree(dst->staging);
+		dst->staging = nullptr;
+		dst->staging_bytes = 0;
+		if (hipMalloc(&dst->staging, n * sizeof(float4)) != hipSuccess) return false;
+		dst->staging_bytes = n * sizeof(float4);
+		return true;
+	};
+	if (peer && peer->info.staged) { // no peer access to the ring's GPU (or forced): the RUNTIME moves the rows, the kernel adds a local strip
+		if (!need_staging()) return fail_merge(POLARIS_E_DEVICE, "merge: out of device memory for the staging strip");
+		if (hipMemcpyAsync(dst->staging, rows, n * sizeof(float4), hipMemcpyDefault, q) != hipSuccess) return fail_merge(POLARIS_E_DEVICE, "merge_ipc: hipMemcpyAsync from the peer's ring failed");
+		rows = (const float4 *)dst->staging;
+		branch = POLARIS_MERGE_IPC_STAGED;
+	}
 	if (!peer && src_device != dst->device) {
 		branch = POLARIS_MERGE_PEER_ACCESS;
 		int can = 0;
@@ -1176,14 +1194,7 @@ static int merge_rows(polaris_hip_tracer *dst, polaris_hip_tracer *src, polaris_
 		}
 		if (!direct) { // staged copy over xGMI / PCIe, then add (the staging strip is the merge stream's: merges are serialised on it)
 			branch = POLARIS_MERGE_STAGED;
-			if (dst->staging_bytes < n * sizeof(float4)) {
-				(void)hipStreamSynchronize(q);
-				if (dst->staging) (void)hipFree(dst->staging);
-				dst->staging = nullptr;
-				dst->staging_bytes = 0;
-				if (hipMalloc(&dst->staging, n * sizeof(float4)) != hipSuccess) return fail_merge(POLARIS_E_DEVICE, "merge: out of device memory for the staging strip");
-				dst->staging_bytes = n * sizeof(float4);
-			}
+			if (!need_staging()) return fail_merge(POLARIS_E_DEVICE, "merge: out of device memory for the staging strip");
 			if (hipMemcpyPeerAsync(dst->staging, dst->device, rows, src_device, n * sizeof(float4), q) != hipSuccess) return fail_merge(POLARIS_E_DEVICE, "merge: hipMemcpyPeerAsync failed");
 			rows = (const float4 *)dst->staging;
 		}
@@ -1328,6 +1339,15 @@ int polaris_hip_ipc_open(polaris_hip_tracer *dst, const PolarisIpcExport *x, pol
 				else (void)hipGetLastError();
 			}
 		}
+		// A kernel must never be pointed at memory its device cannot reach (a fault there can take the whole node down):
+		//   the ring is on another GPU this process cannot even SEE (a per-rank visibility mask): refuse, the caller has its strip fallback;
+		//   the ring is on a visible GPU without peer access: merges go through the staging strip (a runtime copy, then the add).
+		if (I.same_device == 0 && I.local_device < 0) {
+			delete p;
+			return fail(dst, POLARIS_E_UNSUPPORTED, "ipc_open: the peer's ring lives on GPU %s, which is not visible to this process (device visibility mask?): "
+			            "a peer mapping cannot be verified; use a transport that does not need one", I.pci_bus_id);
+		}
+		I.staged = (dst->opt_ipc_staged || (I.same_device == 0 && I.can_access_peer == 0)) ? 1 : 0;
 	}
 	auto undo = [&]() {
 		for (uint32_t i = 0; i < POLARIS_IPC_MAX_DEPTH; i++)

@@ -129,7 +129,7 @@ class PeerInfo(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("pid", C.c_uint32), ("exporter_device", C.c_int32), ("local_device", C.c_int32),
         ("same_device", C.c_int32), ("can_access_peer", C.c_int32), ("depth", C.c_uint32), ("has_events", C.c_uint32),
-        ("pci_bus_id", C.c_char * 32),
+        ("pci_bus_id", C.c_char * 32), ("staged", C.c_int32), ("reserved", C.c_int32),
     ]
 
     def __init__(self, *args, **kw):
@@ -137,8 +137,8 @@ class PeerInfo(C.Structure):
         self.struct_size = C.sizeof(self)
 
 
-assert C.sizeof(DeviceIdentity) == 168 and C.sizeof(PeerInfo) == 64
-MERGE_BRANCHES = ("local", "peer-access", "staged", "ipc-local", "ipc-peer", "ipc-unknown", "device-strip")   # POLARIS_MERGE_* (include/polaris_hip.h)
+assert C.sizeof(DeviceIdentity) == 168 and C.sizeof(PeerInfo) == 72
+MERGE_BRANCHES = ("local", "peer-access", "staged", "ipc-local", "ipc-peer", "ipc-unknown", "device-strip", "ipc-staged")   # POLARIS_MERGE_* (include/polaris_hip.h)
 
 
 def device_identity(index: int) -> dict:

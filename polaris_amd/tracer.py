@@ -247,13 +247,15 @@ class HipTracer:
 
     def peer_info(self, peer: int) -> dict:
         """What a mapped peer ring really is (polaris_hip_peer_info): the exporter's GPU by PCI bus id, whether it is this tracer's own
-        GPU, and the merge branch that follows from it ("ipc-local" / "ipc-peer" / "ipc-unknown")."""
+        GPU, and the merge branch that follows from it ("ipc-local" / "ipc-peer" / "ipc-unknown"; "ipc-staged" where the merges go
+        through the staging strip: no peer access to the ring's GPU, or option ipc_staged)."""
         i = T.PeerInfo()
         self._check(self._lib.polaris_hip_peer_info(C.c_void_p(peer), C.byref(i)), None)
         same = int(i.same_device)
         return {"pid": int(i.pid), "exporter_device": int(i.exporter_device), "pci_bus_id": i.pci_bus_id.decode(errors="replace"),
                 "local_device": int(i.local_device), "same_device": same, "can_access_peer": int(i.can_access_peer), "depth": int(i.depth),
-                "has_events": int(i.has_events), "branch": "ipc-local" if same == 1 else ("ipc-peer" if same == 0 else "ipc-unknown")}
+                "has_events": int(i.has_events), "staged": int(i.staged),
+                "branch": "ipc-staged" if i.staged else ("ipc-local" if same == 1 else ("ipc-peer" if same == 0 else "ipc-unknown"))}
 
     def merge_counts(self) -> dict:
         """How many merges onto this tracer took which branch since it was created (polaris_hip_merge_counts)."""

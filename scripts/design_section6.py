@@ -9,7 +9,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 P = lambda name: os.path.join(ROOT, "profiles", f"{tag}_{name}")
 spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
 bench = importlib.util.module_from_spec(spec)
@@ -41,18 +41,36 @@ for key in ['C2', 'headline', 'headline-refbvh', 'C3', 'C4', 'C5', 'C5-16spp', '
     what = c['what'].split(' (configs')[0].split(' (58,682')[0].split(' (1,060')[0].split(' (1.0 M')[0]
     crow.append(f"| {key} | {what} | {c['Mrays_per_s']:.0f} | {c['ms_per_frame']:.2f} | `{r.get('kernel', '').replace('pol::', '')}` {r.get('frac', 0):.3f} |")
 c1 = cfg['C1']
+import re
+big = {"lane": [], "valu": [], "wait": [], "l2": []}
+for c in ("C4", "C5", "terrain"):
+    try:
+        sqt = open(P(f"big_{c}_pmc_sq.txt")).read()
+        cat = open(P(f"big_{c}_pmc_cache.txt")).read()
+        l = [x for x in sqt.splitlines() if "k_trace<false" in x][0]
+        big["lane"].append(re.search(r"lane_util=([\d.]+)", l).group(1)[:4])
+        big["valu"].append(re.search(r"valu_busy=([\d.]+)", l).group(1)[:4])
+        big["wait"].append(re.search(r"wait_any=([\d.]+)", l).group(1)[:4])
+        big["l2"].append(re.search(r"l2_hit=([\d.]+)", [x for x in cat.splitlines() if "k_trace<false" in x][0]).group(1)[:4])
+    except (OSError, IndexError, AttributeError):
+        for k in big:
+            big[k].append("n/a")
+big = {k: " / ".join(v) for k, v in big.items()}
+pops = "; ".join(f"{k} {cfg[k]['ray_counts']['shadow_rays'] / 1e6:.1f} M, {100 * cfg[k]['ray_counts']['occluded_fraction']:.0f} %" for k in ("headline", "C4", "C5-16spp", "terrain") if cfg[k].get("ray_counts"))
 ks = list(csv.DictReader(open(P("kernel_stats_overlap1.csv"))))
 top = [r for r in ks if 'k_trace<false' in r['Name']][0]
 iso = sum(v for k, v in d['kernels_isolated_ms_per_frame'].items() if k != 'shade')
 R = d['roofline']
 Rt = traffic[R['kernel']]
 Rtr = (Rt["hbm_read_bytes"] + Rt["hbm_write_bytes"]) / Rt["launches"]
-new6 = f'''## 6. Measured (MI355X, round 5) — evidence under `profiles/{tag}_*`
+new6 = f'''## 6. Measured (MI355X, round {int(tag[1:])}) — evidence under `profiles/{tag}_*`
 
-(Earlier rounds: `EXPERIMENTS.md`.  Headline frame 20.2 → 11.3 ms over rounds 1-2, 11.5 → 10.3 in round 4; round 5 moved bytes, not time.)
+(Earlier rounds: `EXPERIMENTS.md`.  Headline frame 20.2 → 11.3 ms over rounds 1-2, 11.5 → 10.3 in round 4; round 5 moved bytes, round 6 measured what is left
+(§3.1, §8) and changed no kernel on the path: the numbers below are round 5's kernels re-measured on this round's build.)
 
 `bench.py`, headline (layered Cornell box, 808 triangles, 512² × 128 spp, 5 bounces, RR from bounce 3; 163.5 M rays per frame):
-**{d['value']:.0f} Mrays/s, {d['ms_per_frame']:.2f} ms per frame** (`{tag}_bench.json`; 10.3-10.5 ms across the round's leases).  Per kernel SYMBOL, one batch at a
+**{d['value']:.0f} Mrays/s, {d['ms_per_frame']:.2f} ms per frame** (`{tag}_bench.json`; 10.3-10.5 ms across the round's leases; `config.devices` names the GPU it ran on, `config.ray_counts` the ray
+population: {d['config']['ray_counts']['shadow_rays'] / 1e6:.1f} M shadow rays per frame, {100 * d['config']['ray_counts']['occluded_fraction']:.1f} % of them occluded).  Per kernel SYMBOL, one batch at a
 time (HIP events of the extra frame `bench.py` traces after its timed region; `{tag}_kernel_stats_overlap1.csv` — rocprofv3
 `--kernel-trace --stats` of the same command — agrees: `k_trace<false, 16, 2, true>` {float(top['AverageNs'])/1e3:.1f} µs average over {top['Calls']} calls against
 {R['avg_launch_ms']*1e3:.1f} µs).  `frac` = HBM roofline on the smaller of the two prices (§3); traffic = FETCH_SIZE × 2 + WRITE_SIZE (`{tag}_traffic.json`);
@@ -79,9 +97,10 @@ each, which reads 1-3 % above `bench.py`'s twenty):
 | C1 | sphere 256² × 16 spp on the CPU restatement (stand-in for the reference's OpenCL CPU device; {c1['cores']} threads) | {c1['reference_order']['Mrays_per_s']} in the reference's schedule, {c1['sample_parallel']['Mrays_per_s']} sample-parallel | {c1['reference_order']['ms_per_frame']} / {c1['sample_parallel']['ms_per_frame']} | — |
 ''' + "\n".join(crow) + f'''
 
-Big scenes, counters re-collected on this round's kernel (`{tag}_big_{{C4,C5,terrain}}_pmc_{{sq,cache,fetch,write}}.txt`): `k_trace<false, 24, 0, false>`
-live lanes 0.56 / 0.43 / 0.53, VALU busy 0.20 / 0.22 / 0.20 of wave cycles, waves waiting 0.64 / 0.60 / 0.66, L2 hit rate
-0.89 / 0.91 / 0.78 (C4 / C5 / terrain): the gather-bound picture of round 3, unchanged (§3.1).
+Big scenes, counters re-collected on this round's build (`{tag}_big_{{C4,C5,terrain}}_pmc_{{sq,cache,fetch,write}}.txt`): `k_trace<false, 24, 0, false>`
+live lanes {big['lane']}, VALU busy {big['valu']} of wave cycles, waves waiting {big['wait']}, L2 hit rate
+{big['l2']} (C4 / C5 / terrain): the gather-bound picture of round 3, unchanged (§3.1; the residency curve: `{tag}_occupancy_curve.txt`).
+Ray populations (`config.ray_counts` in `{tag}_configs.json`): shadow rays per frame and their occluded share — {pops}.
 
 CPU baseline (oracle, sample-parallel OpenMP on the 16 CPUs the box grants): {d['cpu_baseline']['sample'].split(',')[1].strip()} of the same frame: {d['cpu_baseline']['value']:.1f} Mrays/s,
 {d['cpu_baseline']['ms_per_frame_extrapolated']/1e3:.2f} s per 128-spp frame — baseline only.  The boundary hands over no per-frame host buffers (scene and camera are

@@ -108,7 +108,7 @@ def test_bench_two_ranks_bare_launch_and_frame(built, tmp_path):
     _two_rank_frame_matches_the_oracle(d, acc)
 
 
-def _one_gpu_shared_by(d, ranks, chosen_by):
+def _one_gpu_shared_by(d, ranks, chosen_by, branch="ipc-local"):
     """config.devices / distinct_gpus / exchange_detail of a run whose `ranks` ranks all sit on the box's one GPU."""
     cfg = d["config"]
     assert d["n_gpus"] == ranks and cfg["distinct_gpus"] == 1 and len(cfg["devices"]) == ranks
@@ -120,10 +120,10 @@ def _one_gpu_shared_by(d, ranks, chosen_by):
     x = cfg["exchange_detail"]
     if x["mode"] == "hip-ipc":
         assert [p["rank"] for p in x["peers"]] == list(range(1, ranks))
-        assert all(p["branch"] == "ipc-local" and p["same_device"] == 1 and p["pci_bus_id"] == cfg["devices"][0]["pci_bus_id"] for p in x["peers"]), x["peers"]
+        assert all(p["branch"] == branch and p["same_device"] == 1 and p["pci_bus_id"] == cfg["devices"][0]["pci_bus_id"] for p in x["peers"]), x["peers"]
         mc = x["merge_counts"]
-        assert mc["ipc-local"] > 0 and mc["ipc-peer"] == 0 and mc["ipc-unknown"] == 0 and mc["staged"] == 0 and mc["device-strip"] == 0, mc
-        assert mc["ipc-local"] == (ranks - 1) * mc["local"] or mc["local"] >= mc["ipc-local"] // (ranks - 1), mc   # one merge_slot of its own block per frame
+        assert mc[branch] > 0 and mc["local"] > 0 and sum(mc.values()) == mc[branch] + mc["local"], mc     # every peer block by that branch, its own block by merge_slot
+        assert mc[branch] == (ranks - 1) * mc["local"], mc
     else:
         assert x["mode"] == "strips-gloo" and all(p["branch"] == "strips-gloo" for p in x["peers"]) and x["merge_counts"]["device-strip"] > 0, x
 
@@ -567,6 +567,25 @@ def test_bench_four_ranks_masked_to_one_visible_device_each(built, tmp_path):
     assert all(e["visible_devices"] == 1 and e["HIP_VISIBLE_DEVICES"] == "0" for e in d["config"]["devices"])
     assert d["config"]["exchange_detail"]["can_access_peer_from_primary"] == {"0": None}     # rank 0 sees its own device only
     _frame_matches_the_oracle_block_by_block(acc, W, H, spp, B, [32] * 4, scenes.make_seeds(spp, B, base=0xC0FFEE + steps + warmup - 1))
+
+
+def test_merge_ipc_through_the_staging_strip(built, tmp_path):
+    """A ring on a GPU the primary has no peer access to must never be read by a kernel (a fault there can take a node down): the
+    runtime copies the rows into a staging strip (hipMemcpyAsync) and k_aggregate adds from there.  Every pair of GPUs of an MI355X
+    node has peer access, so the path is exercised by forcing it (option ipc_staged = 1) on the one GPU: the line says `ipc-staged`
+    for every peer, the library counted every peer merge under that branch, and the frame is the per-block oracle's, bit for bit."""
+    acc = str(tmp_path / "frame.npy")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", *SMALL, "--same-device", "--no-cpu-baseline", "--no-kernel-timers", "--no-second-scheduler",
+           "--opt", "exact_accumulate=1", "--opt", "ipc_staged=1", "--save-accumulator", acc]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["exchange"].startswith("hip-ipc"), d["config"]["exchange"]
+    _one_gpu_shared_by(d, 3, "--same-device", branch="ipc-staged")
+    from polaris_amd import scenes
+
+    _frame_matches_the_oracle_block_by_block(acc, 128, 97, 8, 5, [33, 32, 32], scenes.make_seeds(8, 5))
 
 
 def test_a_rank_that_fails_during_setup_reaches_every_rank(built):
