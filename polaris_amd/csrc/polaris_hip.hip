@@ -1379,6 +1379,20 @@ int polaris_hip_ipc_open(polaris_hip_tracer *dst, const PolarisIpcExport *x, pol
 			}
 		}
 	}
+	// Every slot's event was recorded (and waited for) once by the export, so each must read COMPLETE here.  One that does not -- its state
+	// is not visible in this process (another device, another container) -- would make a merge's device-side wait hang instead of fail:
+	// drop them all, the host message that follows the peer's synchronous Trace is ordering enough.
+	if (p->ev[0]) {
+		bool visible = true;
+		for (uint32_t i = 0; i < x->depth && visible; i++) visible = hipEventQuery(p->ev[i]) == hipSuccess;
+		if (!visible) {
+			(void)hipGetLastError();
+			for (auto &e : p->ev)
+				if (e) { (void)hipEventDestroy(e); e = nullptr; }
+			(void)hipGetLastError();
+			if (getenv("POLARIS_DEBUG")) fprintf(stderr, "[polaris] ipc_open: the peer's inter-process events do not read complete here; merging on the host-side ordering alone\n");
+		}
+	}
 	p->info.has_events = p->ev[0] ? 1u : 0u;
 	*out = p;
 	return POLARIS_OK;

@@ -357,7 +357,7 @@ def test_trace_accumulator_ring_and_merge_from_a_slot(built, oracle):
     try:
         blob = tr.ipc_export(3)
         x = T.IpcExport.from_buffer_copy(blob)
-        assert (x.depth, x.frame_w, x.frame_h, x.abi_version) == (3, W, H, 4) and x.pid == __import__("os").getpid()
+        assert (x.depth, x.frame_w, x.frame_h, x.abi_version) == (3, W, H, 5) and x.pci_bus_id == tr.device_identity()["pci_bus_id"].encode() and x.pid == __import__("os").getpid()
         with pytest.raises(TracerError, match="this process"):
             tr.ipc_open(blob)
         want, slots = [], []
