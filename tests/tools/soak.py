@@ -55,7 +55,7 @@ def run(iters=200):
         if ring:
             depth = int(rng.integers(1, 5))
             blob = tr.ipc_export(depth)
-            assert len(blob) == 544
+            assert len(blob) == 576
         tr.Trace(req, scenes.make_seeds(spp, B, base=it))
         if ring and int(rng.integers(0, 2)):         # a second Trace moves on to the next slot; the first frame's slot stays readable
             first = tr.trace_slot()
