@@ -328,6 +328,9 @@ def main() -> None:
                     "hipIpcGetMemHandle had -- either way the run must fall back to the strip transfers inside the same processes, on every rank")
     ap.add_argument("--test-delay-rank", default="", help="testing aid, R:MS -- rank R sleeps MS milliseconds after every Trace, so that the others run as far "
                     "ahead as the exchange protocol lets them (a ring slot reused too early then shows in the assembled frame)")
+    ap.add_argument("--test-random-delays", type=int, default=0, help="testing aid, SEED: every rank sleeps a seeded random time (0 - 3 ms, most of them short) after every "
+                    "Trace of every frame, so that who runs ahead and who lags changes from frame to frame (the randomised schedule of "
+                    "tests/test_distributed_cpu.py, here through the real IPC mappings)")
     ap.add_argument("--no-second-scheduler", action="store_true", help="N > 1: skip the second timed region (the perfect scheduler when --scheduler naive)")
     ap.add_argument("--same-device", action="store_true", help="testing aid: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--control-timeout", type=float, default=120.0, help="N > 1: timeout in seconds of the gloo control group (set-up exchange, 32 bytes per rank "
@@ -587,6 +590,12 @@ def main() -> None:
         dr, dms = args.test_delay_rank.split(":")
         delay_rank, delay_s = int(dr), float(dms) * 1e-3
 
+    jitter = None
+    if args.test_random_delays:
+        import random
+
+        jitter = random.Random(args.test_random_delays * 7919 + rank)
+
     def frame(count: bool):
         nonlocal rows, block_y, block_h
         if world > 1 and not args.emulate_rank:
@@ -601,6 +610,8 @@ def main() -> None:
         tr.Trace(req, fseeds)                      # Trace (tracer.go:194-247)
         if delay_rank == rank:
             time.sleep(delay_s)
+        if jitter is not None:
+            time.sleep(jitter.choice((0.0, 0.0, 0.0, 0.0002, 0.0005, 0.001, 0.003)))
         if count:
             st = tr.last_trace_stats
             for k in totals:

@@ -569,6 +569,31 @@ def test_bench_four_ranks_masked_to_one_visible_device_each(built, tmp_path):
     _frame_matches_the_oracle_block_by_block(acc, W, H, spp, B, [32] * 4, scenes.make_seeds(spp, B, base=0xC0FFEE + steps + warmup - 1))
 
 
+def test_bench_four_ranks_sixty_frames_under_random_delays(built, tmp_path):
+    """The randomised schedule of the CPU protocol test, through the REAL exchange: four processes, HIP-IPC mappings of three rings of
+    depth 3, per-slot inter-process events, 60 frames with a different seed list each, every rank sleeping a seeded random time after
+    every Trace -- who runs ahead and who lags changes from frame to frame -- under the perfect scheduler, whose rows follow the
+    measured times.  The frame rank 0 assembled LAST must be the per-block oracle of the last frame's seeds for the rows it ended on
+    (a slot reused too early, a merge from the wrong slot or ranks disagreeing about rows would break it)."""
+    from polaris_amd import scenes
+
+    acc = str(tmp_path / "frame.npy")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    W, H, spp, B, steps, warmup = 96, 122, 2, 4, 60, 2
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--width", str(W), "--height", str(H), "--spp", str(spp), "--bounces", str(B),
+           "--steps", str(steps), "--warmup", str(warmup), "--same-device", "--no-cpu-baseline", "--no-kernel-timers", "--no-second-scheduler",
+           "--scheduler", "perfect", "--opt", "exact_accumulate=1", "--save-accumulator", acc, "--test-seeds", "--test-random-delays", "11"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["exchange"].startswith("hip-ipc") and d["config"]["exchange_detail"]["mode"] == "hip-ipc"
+    mc = d["config"]["exchange_detail"]["merge_counts"]
+    assert mc["ipc-local"] == 3 * (steps + warmup) and mc["local"] == steps + warmup, mc        # every frame: three peer blocks + its own, nothing else
+    rows = d["config"]["rows_last_frame"]
+    assert sum(rows) == H and min(rows) >= 1
+    _frame_matches_the_oracle_block_by_block(acc, W, H, spp, B, rows, scenes.make_seeds(spp, B, base=0xC0FFEE + steps + warmup - 1))
+
+
 def test_merge_ipc_through_the_staging_strip(built, tmp_path):
     """A ring on a GPU the primary has no peer access to must never be read by a kernel (a fault there can take a node down): the
     runtime copies the rows into a staging strip (hipMemcpyAsync) and k_aggregate adds from there.  Every pair of GPUs of an MI355X
