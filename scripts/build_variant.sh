@@ -9,6 +9,7 @@
 #     --patch profile_prologue  + -DPOLARIS_PROFILE_PROLOGUE   s_memrealtime stamps around k_trace's LDS staging
 #     --patch reorder           + -DPOLARIS_EXP_REORDER        the coherence-reorder experiment (scripts/wave_lines.py; closed: EXPERIMENTS.md)
 #     --patch timing_inexact    + -DPOLARIS_TIMING_FMA_SLAB / -DPOLARIS_TIMING_CONTRACT_MT   TIMING-ONLY inexact arithmetic (profiles/r06_price_of_exactness.txt)
+#     --patch tiny_lds_transposed  [-DPOLARIS_AB_B128]        the tiny mode's pair records transposed in LDS (closed: profiles/r06_tiny_lds_layout_ab.txt)
 #     --patch trace_spill       (option trace_spill=1)         16 stack entries in LDS + a global overflow column: 8 workgroups per CU (closed: profiles/r06_occupancy_curve.txt)
 # (the three combine: apply them in the order reorder, profile_loops, profile_prologue -- scripts/wave_lines.py needs the first two.)
 # Only the tracer's translation unit is rebuilt, from a patched COPY of polaris_amd/csrc in a temporary directory; the device BVH

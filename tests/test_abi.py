@@ -62,7 +62,7 @@ def test_experiment_patches_still_apply_to_the_product_sources():
 
     csrc = os.path.join(ROOT, "polaris_amd", "csrc")
     patches = sorted(glob.glob(os.path.join(csrc, "experiments", "*.patch")))
-    assert [os.path.basename(p) for p in patches] == ["profile_loops.patch", "profile_prologue.patch", "reorder.patch", "timing_inexact.patch", "trace_spill.patch"]
+    assert [os.path.basename(p) for p in patches] == ["profile_loops.patch", "profile_prologue.patch", "reorder.patch", "timing_inexact.patch", "tiny_lds_transposed.patch", "trace_spill.patch"]
     for f in ("kernels.h", "polaris_hip.hip"):
         text = open(os.path.join(csrc, f)).read()
         assert "POLARIS_EXP_REORDER" not in text and "POLARIS_PROFILE_" not in text and "hipcub" not in text, f
@@ -74,7 +74,7 @@ def test_experiment_patches_still_apply_to_the_product_sources():
             assert r.returncode == 0, (name, r.stdout, r.stderr)
         text = open(os.path.join(tmp, "kernels.h")).read()
         assert "POLARIS_EXP_REORDER" in text and "POLARIS_PROFILE_LOOPS" in text and "POLARIS_PROFILE_PROLOGUE" in text
-    for name in ("timing_inexact.patch", "trace_spill.patch"):       # each of these applies to the product sources on its own
+    for name in ("timing_inexact.patch", "trace_spill.patch", "tiny_lds_transposed.patch"):       # each of these applies to the product sources on its own
         with tempfile.TemporaryDirectory() as tmp:
             for f in glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.hip")):
                 shutil.copy(f, tmp)
