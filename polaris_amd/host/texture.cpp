@@ -2,6 +2,7 @@
 // channel count 1/3/4, rows top to bottom; finish() applies the reference's layout rules
 // (asset/texure/texture.go:60-147).
 #include "texture.hpp"
+#include "jpeg.hpp"
 
 #include <zlib.h>
 
@@ -353,8 +354,11 @@ Error Decode(const std::string &name, const std::vector<uint8_t> &f, Texture *ou
 	else if (f.size() >= 3 && f[0] == 'P' && (f[1] == '2' || f[1] == '3' || f[1] == '5' || f[1] == '6')) e = decodePNM(name, f, &r);
 	else if (f.size() >= 2 && f[0] == 'B' && f[1] == 'M') e = decodeBMP(name, f, &r);
 	else if (f.size() >= 10 && (!memcmp(f.data(), "#?RADIANCE", 10) || !memcmp(f.data(), "#?RGBE", 6))) e = decodeHDR(name, f, &r);
-	else if (name.size() >= 4 && !strcasecmp(name.c_str() + name.size() - 4, ".tga")) e = decodeTGA(name, f, &r);
-	else return bad("texture: no decoder in this build for " + name + " (supported: png, pnm, bmp, tga, hdr)");
+	else if (f.size() >= 3 && f[0] == 0xFF && f[1] == 0xD8 && f[2] == 0xFF) { // JPEG: 8-bit grey or RGB, as libjpeg (OpenImageIO's reader) delivers it
+		r.isFloat = false;
+		e = DecodeJPEG(name, f, &r.w, &r.h, &r.channels, &r.u8);
+	} else if (name.size() >= 4 && !strcasecmp(name.c_str() + name.size() - 4, ".tga")) e = decodeTGA(name, f, &r);
+	else return bad("texture: no decoder in this build for " + name + " (supported: png, jpeg, pnm, bmp, tga, hdr)");
 	if (e) return e;
 	return finish(name, r, out);
 }

@@ -7,7 +7,7 @@
 // rows top to bottom, and rejects any other channel count.  This build decodes the formats it
 // can without a library -- PNG (zlib), PNM (P2/P3/P5/P6), BMP, TGA, Radiance HDR -- into exactly
 // that representation (wider-than-8-bit integer samples are normalised to [0,1] floats, which
-// is OpenImageIO's integer->float conversion); jpg/gif/tiff/exr/webp are reported as unsupported.
+// is OpenImageIO's integer->float conversion); JPEG (jpeg.hpp: libjpeg's default pipeline restated, 8-bit grey or RGB); gif/tiff/exr/webp are reported as unsupported.
 #pragma once
 
 #include <cstdint>

@@ -17,7 +17,7 @@ HOST = os.path.join(ROOT, "polaris_amd", "host")
 BUILD = os.path.join(ROOT, "tests", "_build")
 BIN = os.path.join(BUILD, "frontend_fuzz")
 SRCS = [os.path.join(ROOT, "tests", "tools", "frontend_fuzz.cpp")] + [os.path.join(HOST, f) for f in
-                                                                    ("texture.cpp", "material_expr.cpp", "wavefront_reader.cpp", "scene_compiler.cpp")]
+                                                                    ("texture.cpp", "jpeg.cpp", "material_expr.cpp", "wavefront_reader.cpp", "scene_compiler.cpp")]
 
 
 @pytest.fixture(scope="module")
@@ -73,10 +73,18 @@ def test_texture_decoders_survive_malformed_files(fuzz_bin, tmp_path):
     F.write_tga(str(tmp_path / "s.tga"), rgba, rle=True); seeds["tga"] = (tmp_path / "s.tga").read_bytes()
     F.write_tga(str(tmp_path / "s2.tga"), rgb); seeds["tga2"] = (tmp_path / "s2.tga").read_bytes()
     F.write_hdr(str(tmp_path / "s.hdr"), rng.integers(0, 256, (3, 9, 4), dtype=np.uint8)); seeds["hdr"] = (tmp_path / "s.hdr").read_bytes()
-    ext = {"pnm": "pnm", "pnm16": "pnm", "png": "png", "png16": "png", "bmp": "bmp", "tga": "tga", "tga2": "tga", "hdr": "hdr"}
-    files = [str(tmp_path / n) for n in ("s.pnm", "s16.pnm", "s.png", "s16.png", "s.bmp", "s.tga", "s2.tga", "s.hdr")]
+    # JPEG seeds (written by Pillow): baseline 4:2:0 with restart markers, progressive 4:2:2, greyscale -- every entropy decoder, both
+    # fancy upsamplers, the restart logic and the progressive refinement scans see truncated and corrupted streams
+    from PIL import Image  # (part of this image; the JPEG seeds need an encoder)
+
+    pic = Image.fromarray(rng.integers(0, 256, (37, 45, 3), dtype=np.uint8), "RGB")
+    pic.save(str(tmp_path / "s.jpg"), "JPEG", quality=70, subsampling=2, restart_marker_blocks=2); seeds["jpg"] = (tmp_path / "s.jpg").read_bytes()
+    pic.save(str(tmp_path / "sp.jpg"), "JPEG", quality=60, subsampling=1, progressive=True); seeds["jpgp"] = (tmp_path / "sp.jpg").read_bytes()
+    pic.convert("L").save(str(tmp_path / "sg.jpg"), "JPEG", quality=85); seeds["jpgg"] = (tmp_path / "sg.jpg").read_bytes()
+    ext = {"pnm": "pnm", "pnm16": "pnm", "png": "png", "png16": "png", "bmp": "bmp", "tga": "tga", "tga2": "tga", "hdr": "hdr", "jpg": "jpg", "jpgp": "jpg", "jpgg": "jpg"}
+    files = [str(tmp_path / n) for n in ("s.pnm", "s16.pnm", "s.png", "s16.png", "s.bmp", "s.tga", "s2.tga", "s.hdr", "s.jpg", "sp.jpg", "sg.jpg")]
     for kind, data in seeds.items():
-        for k, m in enumerate(mutations(data, rng)):
+        for k, m in enumerate(mutations(data, rng, n_flip=120 if kind.startswith("jpg") else 40)):
             p = tmp_path / f"m_{kind}_{k}.{ext[kind]}"
             p.write_bytes(m)
             files.append(str(p))
@@ -84,7 +92,8 @@ def test_texture_decoders_survive_malformed_files(fuzz_bin, tmp_path):
     (tmp_path / "huge.pnm").write_bytes(b"P6\n100000 100000\n255\n" + b"\0" * 64); files.append(str(tmp_path / "huge.pnm"))
     (tmp_path / "zero.pnm").write_bytes(b"P5\n0 0\n255\n"); files.append(str(tmp_path / "zero.pnm"))
     ok, rejected = run(fuzz_bin, files)
-    assert ok >= 8 and rejected > 100  # the eight valid files decode; most mutations are rejected (some still decode: flipped texels)
+    assert ok >= 11 and rejected > 100  # the eleven valid files decode; most mutations are rejected (some still decode: flipped texels; a JPEG with a
+    # damaged entropy-coded segment decodes to garbage samples, as it does in libjpeg)
 
 
 def test_obj_reader_and_expression_parser_survive_malformed_text(fuzz_bin, tmp_path):

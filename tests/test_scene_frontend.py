@@ -326,8 +326,11 @@ def test_texture_decoders(tmp_path):
     with pytest.raises(RuntimeError, match="unsupported channel count 2"):
         H.texture_load(str(tmp_path / "ga.png"))
     (tmp_path / "x.jpg").write_bytes(b"\xff\xd8\xff\xe0 not really a jpeg")
-    with pytest.raises(RuntimeError, match="no decoder in this build"):
+    with pytest.raises(RuntimeError, match="texture: jpeg: "):
         H.texture_load(str(tmp_path / "x.jpg"))
+    (tmp_path / "x.tif").write_bytes(b"II*\x00\x08\x00\x00\x00 a TIFF header and nothing else")
+    with pytest.raises(RuntimeError, match="no decoder in this build"):
+        H.texture_load(str(tmp_path / "x.tif"))
 
 
 # ---- compiler: material trees, textures, emissives, camera ---------------------------------------------
@@ -441,3 +444,54 @@ def test_the_references_own_scene_fixture_compiles_to_the_golden_arrays():
     # the two instances: the cube where it is, and one unit to the left (the inverse transform carries +1 in x)
     inv = sc.mesh_instances["inv_transform"].reshape(2, 4, 4)
     assert np.array_equal(inv[0], np.eye(4, dtype=np.float32)) and inv[1][3, 0] == 1.0 and np.array_equal(inv[1][:3, :3], np.eye(3, dtype=np.float32))
+
+
+def test_jpeg_textures_decode_like_libjpeg(tmp_path):
+    """asset/texure/texture.go:25-150 hands every image to OpenImageIO, whose JPEG reader is libjpeg.  polaris_amd/host/jpeg.cpp restates
+    libjpeg's default pipeline (islow IDCT, fancy upsampling, fixed-point YCbCr -> RGB); the texels must equal what Pillow -- libjpeg-turbo,
+    bit-compatible with libjpeg -- decodes from the same file, byte for byte: greyscale and colour, 4:4:4 / 4:2:2 / 4:2:0 / 4:1:1, sizes that are
+    not multiples of the MCU, qualities 1 .. 100, Huffman-optimised, restart intervals, progressive (spectral selection + successive
+    approximation), RGB-coded files; CMYK and truncated files are errors, not crashes."""
+    Image = pytest.importorskip("PIL.Image")  # (the comparison needs libjpeg itself: Pillow carries it)
+
+    rng = np.random.default_rng(3)
+
+    def picture(w, h, mode):
+        y, x = np.mgrid[0:h, 0:w]
+        a = np.stack([(x * 255 // max(w - 1, 1)), (y * 255 // max(h - 1, 1)), ((x + y) * 3) % 256], -1).astype(np.int32) + rng.integers(-40, 40, (h, w, 3))
+        a[h // 3: h // 2, w // 4: w // 2] = (255, 0, 255)
+        a = np.clip(a, 0, 255).astype(np.uint8)
+        return Image.fromarray(a if mode == "RGB" else np.ascontiguousarray(a[..., 0]), mode)
+
+    path = str(tmp_path / "t.jpg")
+    cases = []
+    for (w, h) in [(1, 1), (2, 3), (7, 5), (8, 8), (17, 33), (64, 48), (129, 67)]:
+        for mode in ("L", "RGB"):
+            for sub in ((0, 1, 2) if mode == "RGB" else (None,)):
+                for q, prog in ((35, False), (75, True), (95, False), (90, True)):
+                    cases.append((w, h, mode, dict(quality=q, progressive=prog, **({} if sub is None else {"subsampling": sub}))))
+    big = (131, 97)
+    for kw in (dict(quality=1), dict(quality=100, subsampling=0), dict(quality=60, subsampling="4:1:1"), dict(quality=85, restart_marker_blocks=3),
+               dict(quality=85, restart_marker_rows=1, subsampling=2), dict(quality=70, progressive=True, restart_marker_blocks=5), dict(quality=90, keep_rgb=True, subsampling=0),
+               dict(quality=50, progressive=True, subsampling="4:1:1"), dict(quality=80, optimize=True, subsampling=2), dict(quality=30, qtables="web_low")):
+        cases.append((*big, "RGB", kw))
+    cases.append((77, 50, "L", dict(quality=80, restart_marker_blocks=2)))
+    for w, h, mode, kw in cases:
+        picture(w, h, mode).save(path, "JPEG", **kw)
+        want = np.asarray(Image.open(path))
+        fmt, tw, th, data = H.texture_load(path)
+        assert (tw, th) == (w, h) and fmt == (T.TEX_RGBA8 if mode == "RGB" else T.TEX_L8), (w, h, mode, kw)
+        got = data.reshape(th, tw, 4) if mode == "RGB" else data.reshape(th, tw)
+        if mode == "RGB":
+            assert (got[..., 3] == 255).all()
+            got = got[..., :3]
+        assert np.array_equal(got, want), (w, h, mode, kw, int(np.abs(got.astype(int) - want.astype(int)).max()))
+    Image.fromarray(rng.integers(0, 256, (8, 8, 4), dtype=np.uint8), "CMYK").save(path, "JPEG")
+    with pytest.raises(RuntimeError, match="CMYK"):
+        H.texture_load(path)
+    picture(64, 48, "RGB").save(path, "JPEG", quality=80)
+    whole = open(path, "rb").read()
+    for cut in (3, 20, 100):
+        open(path, "wb").write(whole[:cut])
+        with pytest.raises(RuntimeError, match="jpeg"):
+            H.texture_load(path)
