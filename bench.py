@@ -677,6 +677,28 @@ def main() -> None:
         totals.update(keep_totals)
         rows_log[:] = keep_rows_log
 
+    # N > 1: the exchange proves itself on the frame it has just delivered.  Every rank reads the rows of ITS block back from its own trace
+    # accumulator (the ring slot its last Trace wrote), rank 0 gathers them over gloo -- a path that shares nothing with the exchange -- and
+    # compares them with the same rows of its frame accumulator (Reset + one merge per block: 0 + x, so the floats must be EQUAL, whatever
+    # branch carried them: a peer read over xGMI, a staged copy, a strip over RCCL or gloo).  After the timed regions, never inside one.
+    if world > 1 and not args.emulate_rank:
+        proof = {"frame": "the last frame of the last timed region", "rows": list(rows)}
+        try:
+            mine = np.ascontiguousarray(tr.read_accumulator(0)[block_y:block_y + block_h])
+            got = [None] * world if rank == 0 else None
+            dist.gather_object((block_y, block_h, mine), got, dst=0)
+            if rank == 0:
+                merged = tr.read_accumulator(1)
+                equal = [bool(np.array_equal(merged[y:y + h, :, :3], blk[..., :3])) for (y, h, blk) in got]   # (k_aggregate adds .xyz)
+                lit = [bool(np.any(blk[..., :3] != 0)) for (_, _, blk) in got]     # (an all-black frame would prove nothing; a single block may well be black)
+                proof.update(blocks_equal=equal, blocks_not_black=lit, all_equal=all(equal) and any(lit),
+                             covered_rows=sum(h for _, h, _ in got), bytes_compared=int(sum(blk.nbytes for _, _, blk in got)))
+                if not proof["all_equal"]:
+                    print(f"bench.py: EXCHANGE PROOF FAILED -- the primary's frame does not hold every rank's rows: equal={equal} not_black={lit}", file=sys.stderr)
+        except Exception as e:  # noqa: BLE001 -- the proof is evidence, not part of the measurement: report, do not lose the line
+            proof["error"] = f"{type(e).__name__}: {e}"[:300]
+        detail["proof"] = proof
+
     el = torch.tensor([elapsed, second[1] if second else 0.0], dtype=torch.float64)       # (CPU tensors: gloo)
     cnt = torch.tensor([totals[k] for k in sorted(totals)] + [second[2] if second else 0], dtype=torch.int64)
     if dist is not None:

@@ -118,6 +118,9 @@ def _one_gpu_shared_by(d, ranks, chosen_by, branch="ipc-local"):
     assert all(e["hip_index"] == 0 and (chosen_by in e["device_chosen_by"] or (e["local_rank"] == 0 and e["device_chosen_by"] == "LOCAL_RANK"))
                for e in cfg["devices"]), [(e["local_rank"], e["device_chosen_by"]) for e in cfg["devices"]]
     x = cfg["exchange_detail"]
+    # the exchange proves itself: every rank's own rows, gathered over gloo after the timed regions, equal the primary's frame accumulator
+    pr = x["proof"]
+    assert pr.get("all_equal") is True and pr["blocks_equal"] == [True] * ranks and pr["covered_rows"] == sum(pr["rows"]) == cfg["frame"][1], pr
     if x["mode"] == "hip-ipc":
         assert [p["rank"] for p in x["peers"]] == list(range(1, ranks))
         assert all(p["branch"] == branch and p["same_device"] == 1 and p["pci_bus_id"] == cfg["devices"][0]["pci_bus_id"] for p in x["peers"]), x["peers"]
