@@ -50,6 +50,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the host driver of this pool only supports dmabuf IPC: without this, hipIpcGetMemHandle fails across processes.  The images export it already;
+# a launcher with a scrubbed environment must not cost the peer-read exchange (read by the runtime when it initialises, i.e. after this line)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 
