@@ -36,6 +36,43 @@ def test_trace_bit_exact(oracle, ref_pm, name):
         assert np.array_equal(bits(ta["throughput0"][:, :3]), bits(tb["throughput0"][:, :3]))
 
 
+@pytest.mark.parametrize("first", range(0, 96, 24))
+def test_random_scenes_bit_exact(oracle, ref_pm, first):
+    """Seeded random scenes (tests/tools/random_scenes.py: every BxDF family, material trees of all five operators, the four texture
+    formats, instances under non-uniform scales, area / environment lights, odd frames, partial blocks, 1-6 bounces, any RR threshold):
+    the restatement equals the compiled reference bit for bit on each.  The same seeds run HIP against the oracle on the GPU
+    (tests/test_gpu_fuzz_parity.py)."""
+    import os
+    import sys
+
+    from oracle import pybind as ob
+    from polaris_amd import scenes
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    from random_scenes import random_case
+
+    compared = 0
+    for seed in range(first, first + 24):
+        sc, c = random_case(seed)
+        # an RGBA32F texture at an offset that is not a multiple of 16 (the reference's compiler aligns to 4, compiler.go bakeTexture): the
+        # HOST-compiled kernels load float4 with aligned moves and fault -- a property of this build of the reference, not of the path
+        if any(int(m["format"]) == 3 and int(m["data_offset"]) % 16 for m in sc.texture_meta):
+            continue
+        B = c["bounces"]
+        seeds = scenes.make_seeds(c["spp"], B, base=1000 + seed)
+
+        def request():
+            return ob.make_request(c["W"], c["H"], spp=c["spp"], bounces=B, rr=c["rr"], block_y=c["block_y"], block_h=c["block_h"])
+
+        a, sa, _ = ref_pm.trace(sc, request(), seeds)
+        b, sb, _ = oracle.trace(sc, request(), seeds)
+        assert np.array_equal(bits(a[..., :3]), bits(b[..., :3])), (seed, c)
+        assert list(sa.rays_per_bounce[:B]) == list(sb.rays_per_bounce[:B]) and list(sa.occl_per_bounce[:B]) == list(sb.occl_per_bounce[:B]), (seed, c)
+        assert (sa.unoccluded, sa.shaded_hits, sa.shaded_misses) == (sb.unoccluded, sb.shaded_hits, sb.shaded_misses), (seed, c)
+        compared += 1
+    assert compared >= 16
+
+
 def test_reference_emitter_index_quirk(oracle, ref_pm):
     """Without the fix the reference stores direct emitter hits at the block-local index
     (pt_integrator.cl:106); both checkers reproduce that too when asked."""

@@ -1,0 +1,100 @@
+"""A long run of the parity fuzz (GPU): seeds [first, last) of tests/tools/random_scenes.py, HIP (exact mode + a batched run, random
+tracer options) against the CPU oracle -- the loop of tests/test_gpu_fuzz_parity.py without pytest, reporting every seed that differs.
+    python tests/tools/fuzz_sweep.py 96 3000
+    python tests/tools/fuzz_sweep.py 0 4096 ref      (CPU, build container: the oracle against the compiled reference instead)"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+
+from conftest import bits, make_hip_tracer  # noqa: E402
+from oracle import pybind as ob  # noqa: E402
+from polaris_amd import scenes  # noqa: E402
+from random_scenes import random_case  # noqa: E402
+from test_gpu_fuzz_parity import counters, draw_options  # noqa: E402
+
+
+def against_the_reference(first, last):
+    oracle, ref = ob.Oracle("oracle"), ob.Oracle("ref_pm")
+    bad, skipped, rays, t0 = [], 0, 0, time.time()
+    for seed in range(first, last):
+        sc, c = random_case(seed)
+        if any(int(m["format"]) == 3 and int(m["data_offset"]) % 16 for m in sc.texture_meta):   # (see tests/test_oracle_vs_reference.py)
+            skipped += 1
+            continue
+        B = c["bounces"]
+        seeds = scenes.make_seeds(c["spp"], B, base=1000 + seed)
+
+        def request():
+            return ob.make_request(c["W"], c["H"], spp=c["spp"], bounces=B, rr=c["rr"], block_y=c["block_y"], block_h=c["block_h"])
+
+        a, sa, _ = ref.trace(sc, request(), seeds)
+        b, sb, _ = oracle.trace(sc, request(), seeds)
+        rays += sb.total_rays()
+        same = (np.array_equal(bits(a[..., :3]), bits(b[..., :3])) and list(sa.rays_per_bounce[:B]) == list(sb.rays_per_bounce[:B])
+                and list(sa.occl_per_bounce[:B]) == list(sb.occl_per_bounce[:B]) and (sa.unoccluded, sa.shaded_hits, sa.shaded_misses) == (sb.unoccluded, sb.shaded_hits, sb.shaded_misses))
+        if not same:
+            bad.append(seed)
+            print(f"seed {seed} MISMATCH oracle vs compiled reference; case {c}", flush=True)
+    print(f"fuzz sweep, oracle vs compiled reference: seeds [{first}, {last}): {last - first - skipped - len(bad)} equal, {len(bad)} differing {bad[:20]}, "
+          f"{skipped} skipped (float4 texture at an offset the host-compiled kernels cannot load), {rays} rays traced, {time.time() - t0:.0f} s")
+    return 1 if bad else 0
+
+
+def main():
+    first, last = int(sys.argv[1]), int(sys.argv[2])
+    if len(sys.argv) > 3 and sys.argv[3] == "ref":
+        return against_the_reference(first, last)
+    oracle = ob.Oracle("oracle")
+    bad, rays, t0 = [], 0, time.time()
+    for seed in range(first, last):
+        sc, c = random_case(seed)
+        B, spp = c["bounces"], c["spp"]
+        seeds = scenes.make_seeds(spp, B, base=1000 + seed)
+
+        def request():
+            return ob.make_request(c["W"], c["H"], spp=spp, bounces=B, rr=c["rr"], block_y=c["block_y"], block_h=c["block_h"])
+
+        want, ws, _ = oracle.trace(sc, request(), seeds)
+        rays += ws.total_rays()
+        if np.isnan(want[..., :3]).any():
+            print(f"seed {seed}: NaN in the oracle's frame (not compared)", flush=True)
+            continue
+        rng = np.random.default_rng(0xF00D + seed)
+        opts = draw_options(rng)
+        batched = dict(opts, samples_per_batch=int(rng.integers(1, spp + 1)), overlap=int(rng.integers(1, 4)))
+        for options, exact in ((dict(opts, exact_accumulate=1), True), (batched, False)):
+            tr = make_hip_tracer(sc, c["W"], c["H"], **options)
+            try:
+                tr.Trace(request(), seeds)
+                got, gs = tr.read_accumulator(0), tr.last_trace_stats
+            finally:
+                tr.Close()
+            by, bh = c["block_y"], c["block_h"]
+            why = ""
+            if counters(gs, B) != counters(ws, B):
+                why = f"counters {counters(gs, B)} != {counters(ws, B)}"
+            elif exact and not np.array_equal(bits(got[by:by + bh, :, :3]), bits(want[by:by + bh, :, :3])):
+                why = f"{int((bits(got[by:by + bh, :, :3]) != bits(want[by:by + bh, :, :3])).sum())} accumulator words differ"
+            elif not exact:
+                scale = max(1.0, float(np.abs(want[by:by + bh, :, :3]).max()) / spp)
+                err = float(np.sqrt(np.mean((got[by:by + bh, :, :3] / spp - want[by:by + bh, :, :3] / spp) ** 2)))
+                if err > 1e-6 * scale:
+                    why = f"rmse {err:.3e} > 1e-6 x {scale:.3g}"
+            if why:
+                bad.append(seed)
+                print(f"seed {seed} MISMATCH ({'exact' if exact else 'batched'}): {why}; case {c}; options {options}", flush=True)
+        if (seed - first) % 250 == 249:
+            print(f"... {seed + 1 - first} seeds, {len(bad)} differing, {rays} rays, {time.time() - t0:.0f} s", flush=True)
+    print(f"fuzz sweep: seeds [{first}, {last}): {last - first - len(set(bad))} equal, {len(set(bad))} differing {sorted(set(bad))[:20]}, {rays} rays traced, {time.time() - t0:.0f} s")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())
