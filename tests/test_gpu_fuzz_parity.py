@@ -37,14 +37,23 @@ def draw_options(rng):
     return o
 
 
-@pytest.mark.parametrize("first", range(0, 8 * PER_TEST, PER_TEST))
-def test_random_scenes_against_the_oracle(built, oracle, first):
+FAMILIES = ([(f, "plain") for f in range(0, 8 * PER_TEST, PER_TEST)] + [(f, "big") for f in range(0, 4 * PER_TEST, PER_TEST)]
+            + [(f, "single") for f in range(0, 4 * PER_TEST, PER_TEST)] + [(0, "big-single")])
+
+
+@pytest.mark.parametrize("first,family", FAMILIES)
+def test_random_scenes_against_the_oracle(built, oracle, first, family):
+    """`big`: the same generator plus a height field of up to 4 600 triangles and / or a swarm of up to 150 instances -- trees that do not fit
+    LDS and deep top-level trees, i.e. the general traversal kernels (`k_trace<*, 24, 0 / 1, false>`) instead of the tiny-scene ones.
+    `single`: everything baked into ONE mesh under the identity transform -- the single-instance kernels (`k_trace<*, *, *, true>`, the
+    headline's) and, for camera rays, the wave-packet kernel."""
+    big, single = "big" in family, "single" in family
     from oracle import pybind as ob
     from polaris_amd import scenes
     from random_scenes import random_case
 
     for seed in range(first, first + PER_TEST):
-        sc, c = random_case(seed)
+        sc, c = random_case(seed, big=big, single=single)
         B, spp = c["bounces"], c["spp"]
         seeds = scenes.make_seeds(spp, B, base=1000 + seed)
 
@@ -63,7 +72,7 @@ def test_random_scenes_against_the_oracle(built, oracle, first):
                 got, gs = tr.read_accumulator(0), tr.last_trace_stats
             finally:
                 tr.Close()
-            what = (seed, c, options)
+            what = (seed, family, c, options)
             assert counters(gs, B) == counters(ws, B), what
             by, bh = c["block_y"], c["block_h"]
             if exact:

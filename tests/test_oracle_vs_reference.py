@@ -36,8 +36,8 @@ def test_trace_bit_exact(oracle, ref_pm, name):
         assert np.array_equal(bits(ta["throughput0"][:, :3]), bits(tb["throughput0"][:, :3]))
 
 
-@pytest.mark.parametrize("first", range(0, 96, 24))
-def test_random_scenes_bit_exact(oracle, ref_pm, first):
+@pytest.mark.parametrize("first,family", [(0, "plain"), (24, "plain"), (48, "plain"), (72, "plain"), (0, "big"), (24, "big"), (0, "single"), (24, "single")])
+def test_random_scenes_bit_exact(oracle, ref_pm, first, family):
     """Seeded random scenes (tests/tools/random_scenes.py: every BxDF family, material trees of all five operators, the four texture
     formats, instances under non-uniform scales, area / environment lights, odd frames, partial blocks, 1-6 bounces, any RR threshold):
     the restatement equals the compiled reference bit for bit on each.  The same seeds run HIP against the oracle on the GPU
@@ -53,7 +53,8 @@ def test_random_scenes_bit_exact(oracle, ref_pm, first):
 
     compared = 0
     for seed in range(first, first + 24):
-        sc, c = random_case(seed)
+        # (big: plus a height field and / or a swarm of instances -- trees beyond the tiny-scene kernels; single: all of it as ONE mesh)
+        sc, c = random_case(seed, big="big" in family, single="single" in family)
         # an RGBA32F texture at an offset that is not a multiple of 16 (the reference's compiler aligns to 4, compiler.go bakeTexture): the
         # HOST-compiled kernels load float4 with aligned moves and fault -- a property of this build of the reference, not of the path
         if any(int(m["format"]) == 3 and int(m["data_offset"]) % 16 for m in sc.texture_meta):
@@ -66,7 +67,7 @@ def test_random_scenes_bit_exact(oracle, ref_pm, first):
 
         a, sa, _ = ref_pm.trace(sc, request(), seeds)
         b, sb, _ = oracle.trace(sc, request(), seeds)
-        assert np.array_equal(bits(a[..., :3]), bits(b[..., :3])), (seed, c)
+        assert np.array_equal(bits(a[..., :3]), bits(b[..., :3])), (seed, family, c)
         assert list(sa.rays_per_bounce[:B]) == list(sb.rays_per_bounce[:B]) and list(sa.occl_per_bounce[:B]) == list(sb.occl_per_bounce[:B]), (seed, c)
         assert (sa.unoccluded, sa.shaded_hits, sa.shaded_misses) == (sb.unoccluded, sb.shaded_hits, sb.shaded_misses), (seed, c)
         compared += 1

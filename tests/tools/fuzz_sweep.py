@@ -1,7 +1,8 @@
 """A long run of the parity fuzz (GPU): seeds [first, last) of tests/tools/random_scenes.py, HIP (exact mode + a batched run, random
 tracer options) against the CPU oracle -- the loop of tests/test_gpu_fuzz_parity.py without pytest, reporting every seed that differs.
     python tests/tools/fuzz_sweep.py 96 3000
-    python tests/tools/fuzz_sweep.py 0 4096 ref      (CPU, build container: the oracle against the compiled reference instead)"""
+    python tests/tools/fuzz_sweep.py 0 4096 ref      (CPU, build container: the oracle against the compiled reference instead)
+    ... big / single                                  (random_case(seed, big=True / single=True))"""
 import os
 import sys
 import time
@@ -20,11 +21,15 @@ from random_scenes import random_case  # noqa: E402
 from test_gpu_fuzz_parity import counters, draw_options  # noqa: E402
 
 
+BIG = "big" in sys.argv[3:]     # the generator's second family: plus a height field and / or a swarm of instances
+SINGLE = "single" in sys.argv[3:]   # ... and its third: everything baked into one mesh under the identity
+
+
 def against_the_reference(first, last):
     oracle, ref = ob.Oracle("oracle"), ob.Oracle("ref_pm")
     bad, skipped, rays, t0 = [], 0, 0, time.time()
     for seed in range(first, last):
-        sc, c = random_case(seed)
+        sc, c = random_case(seed, big=BIG, single=SINGLE)
         if any(int(m["format"]) == 3 and int(m["data_offset"]) % 16 for m in sc.texture_meta):   # (see tests/test_oracle_vs_reference.py)
             skipped += 1
             continue
@@ -42,19 +47,20 @@ def against_the_reference(first, last):
         if not same:
             bad.append(seed)
             print(f"seed {seed} MISMATCH oracle vs compiled reference; case {c}", flush=True)
-    print(f"fuzz sweep, oracle vs compiled reference: seeds [{first}, {last}): {last - first - skipped - len(bad)} equal, {len(bad)} differing {bad[:20]}, "
+    print(f"fuzz sweep{' (big)' if BIG else ''}{' (single)' if SINGLE else ''}, oracle vs compiled reference: seeds [{first}, {last}): {last - first - skipped - len(bad)} equal, {len(bad)} differing {bad[:20]}, "
           f"{skipped} skipped (float4 texture at an offset the host-compiled kernels cannot load), {rays} rays traced, {time.time() - t0:.0f} s")
     return 1 if bad else 0
 
 
 def main():
     first, last = int(sys.argv[1]), int(sys.argv[2])
-    if len(sys.argv) > 3 and sys.argv[3] == "ref":
+    if "ref" in sys.argv[3:]:
         return against_the_reference(first, last)
     oracle = ob.Oracle("oracle")
     bad, rays, t0 = [], 0, time.time()
+    symbols = {}
     for seed in range(first, last):
-        sc, c = random_case(seed)
+        sc, c = random_case(seed, big=BIG, single=SINGLE)
         B, spp = c["bounces"], c["spp"]
         seeds = scenes.make_seeds(spp, B, base=1000 + seed)
 
@@ -72,8 +78,13 @@ def main():
         for options, exact in ((dict(opts, exact_accumulate=1), True), (batched, False)):
             tr = make_hip_tracer(sc, c["W"], c["H"], **options)
             try:
+                tr.set_option("time_kernels", 1)    # (so that the library remembers which kernel symbol every step ran)
                 tr.Trace(request(), seeds)
                 got, gs = tr.read_accumulator(0), tr.last_trace_stats
+                for timer in ("intersect_packet", "intersect", "occlusion", *tr.SHADE_TIMERS):
+                    sym = tr.kernel_symbol(timer)
+                    if sym:
+                        symbols[sym] = symbols.get(sym, 0) + 1
             finally:
                 tr.Close()
             by, bh = c["block_y"], c["block_h"]
@@ -92,7 +103,10 @@ def main():
                 print(f"seed {seed} MISMATCH ({'exact' if exact else 'batched'}): {why}; case {c}; options {options}", flush=True)
         if (seed - first) % 250 == 249:
             print(f"... {seed + 1 - first} seeds, {len(bad)} differing, {rays} rays, {time.time() - t0:.0f} s", flush=True)
-    print(f"fuzz sweep: seeds [{first}, {last}): {last - first - len(set(bad))} equal, {len(set(bad))} differing {sorted(set(bad))[:20]}, {rays} rays traced, {time.time() - t0:.0f} s")
+    print(f"fuzz sweep{' (big)' if BIG else ''}{' (single)' if SINGLE else ''}: seeds [{first}, {last}): {last - first - len(set(bad))} equal, {len(set(bad))} differing {sorted(set(bad))[:20]}, {rays} rays traced, {time.time() - t0:.0f} s")
+    print("kernel symbols the traces ran (traces that used each):")
+    for sym, n in sorted(symbols.items(), key=lambda kv: -kv[1]):
+        print(f"  {n:6d}  {sym}")
     return 1 if bad else 0
 
 

@@ -121,9 +121,22 @@ def _object(rng, mat):
     return S.Mesh(verts, S._flat_normals(verts), uvs, np.full(n, mat))
 
 
-def random_case(seed: int):
-    """-> (scene, dict(W, H, spp, bounces, rr, block_y, block_h))"""
+def _baked(mesh, xf):
+    """The mesh with the instance transform applied to its vertices (normals by the inverse transpose)."""
+    m3 = np.asarray(xf)[:3, :3]
+    verts = mesh.verts @ m3.T + np.asarray(xf)[:3, 3]
+    nrm = mesh.normals @ np.linalg.inv(m3)
+    nrm /= np.maximum(np.linalg.norm(nrm, axis=-1, keepdims=True), 1e-30)
+    return S.Mesh(verts, nrm, mesh.uvs, mesh.mat)
+
+
+def random_case(seed: int, big: bool = False, single: bool = False):
+    """-> (scene, dict(W, H, spp, bounces, rr, block_y, block_h)).  `big`: the same scene plus a height field of 300-4 600 triangles and / or
+    a swarm of 20-150 instances (drawn from a second stream, so the plain cases keep their scenes): trees that do not fit LDS, deep
+    top-level trees -- the general traversal kernels instead of the tiny-scene ones.  `single`: all of it baked into ONE mesh under the
+    identity transform (the kernels specialised for single-instance scenes)."""
     rng = np.random.default_rng(0x5EED0000 + seed)
+    rng2 = np.random.default_rng(0xB160000 + seed)
     mt = S.MaterialTable()
     textures = [_texture(mt, rng) for _ in range(int(rng.integers(0, 5)))]
     mats = [_tree(mt, rng, textures, int(rng.integers(0, 4))) for _ in range(int(rng.integers(2, 9)))]
@@ -163,12 +176,26 @@ def random_case(seed: int):
         c = rng.uniform(-2.0, 2.0, 3) * (1, 0, 1) + (0, rng.uniform(2.8, 4.6), 0)
         hx, hz = rng.uniform(0.3, 1.2, 2)
         room.append(S.quad(c + (-hx, 0, -hz), c + (hx, 0, -hz), c + (hx, 0, hz), c + (-hx, 0, hz), e))
+    if big:
+        kind = int(rng2.integers(0, 3))
+        if kind in (0, 2):   # a height field, as its own mesh under a transform of its own
+            n = int(rng2.integers(12, 49))
+            meshes.append(S.displaced_grid(n, float(rng2.uniform(3.0, 7.0)), float(rng2.uniform(0.2, 0.9)), int(rng2.choice(mats)), seed=int(rng2.integers(0, 1 << 30))))
+            insts.append((len(meshes) - 1, S.translation((0, float(rng2.uniform(0.05, 0.6)), 0)) @ _rot(1, rng2.uniform(-3, 3)) @ S.scaling(*rng2.uniform(0.7, 1.3, 3))))
+        if kind in (1, 2):   # a swarm: many instances of one small mesh
+            meshes.append(S.uv_sphere((0, 0, 0), 0.5, int(rng2.choice(mats)), n_lat=int(rng2.integers(4, 11)), n_lon=int(rng2.integers(4, 13))))
+            mi = len(meshes) - 1
+            for _ in range(int(rng2.integers(20, 151))):
+                xf = S.translation(rng2.uniform(-3.5, 3.5, 3) * (1, 0.5, 1) + (0, 2.0, 0)) @ _rot(1, rng2.uniform(-3, 3)) @ _rot(0, rng2.uniform(-1, 1)) @ S.scaling(*rng2.uniform(0.15, 0.6, 3))
+                insts.append((mi, xf))
     meshes.append(S.merge(room))
     insts.append((len(meshes) - 1, np.eye(4)))
     order = rng.permutation(len(insts))
     insts = [insts[i] for i in order]
+    if single:   # the same geometry as ONE mesh under the identity: the single-instance kernels (the headline's `k_trace<*, 16, 2, true>`)
+        meshes, insts = [S.merge([_baked(meshes[mi], xf) for mi, xf in insts])], [(0, np.eye(4))]
     bg = mt.diffuse(_tint(rng, 0.05, 0.5)) if rng.random() < 0.6 else -1
-    scn = S.compile_scene(meshes, insts, mt, max_leaf=int(rng.choice([1, 2, 4])), scene_diffuse=bg, scene_emissive=env, name=f"random-{seed}")
+    scn = S.compile_scene(meshes, insts, mt, max_leaf=int(rng.choice([1, 2, 4])), scene_diffuse=bg, scene_emissive=env, name=f"random-{seed}{'-big' if big else ''}{'-single' if single else ''}")
     W, H = int(rng.choice([17, 33, 64, 97, 130])), int(rng.choice([9, 24, 40, 71]))
     th, el, dist = rng.uniform(0, 2 * math.pi), rng.uniform(0.15, 0.9), rng.uniform(3.0, 3.9 if closed else 7.0)
     eye = (dist * math.cos(el) * math.cos(th), 0.3 + dist * math.sin(el), dist * math.cos(el) * math.sin(th))
