@@ -2,7 +2,8 @@
 tracer options) against the CPU oracle -- the loop of tests/test_gpu_fuzz_parity.py without pytest, reporting every seed that differs.
     python tests/tools/fuzz_sweep.py 96 3000
     python tests/tools/fuzz_sweep.py 0 4096 ref      (CPU, build container: the oracle against the compiled reference instead)
-    ... big / single                                  (random_case(seed, big=True / single=True))"""
+    ... big / single                                  (random_case(seed, big=True / single=True))
+    ... devbvh                                        (GPU: the tree rebuilt by polaris_hip_build_bvh first)"""
 import os
 import sys
 import time
@@ -23,6 +24,7 @@ from test_gpu_fuzz_parity import counters, draw_options  # noqa: E402
 
 BIG = "big" in sys.argv[3:]     # the generator's second family: plus a height field and / or a swarm of instances
 SINGLE = "single" in sys.argv[3:]   # ... and its third: everything baked into one mesh under the identity
+DEVBVH = "devbvh" in sys.argv[3:]   # the scene's tree rebuilt by polaris_hip_build_bvh first (SAH or linear, leaves of 1-4 triangles), validated, then traced
 
 
 def against_the_reference(first, last):
@@ -63,6 +65,21 @@ def main():
         sc, c = random_case(seed, big=BIG, single=SINGLE)
         B, spp = c["bounces"], c["spp"]
         seeds = scenes.make_seeds(spp, B, base=1000 + seed)
+        if DEVBVH:
+            from polaris_amd import bvh_build
+            from test_gpu_bvh_build import check_tree
+
+            r2 = np.random.default_rng(0xB0B + seed)
+            algorithm, max_leaf = ("sah", "lbvh")[int(r2.integers(0, 2))], int(r2.integers(1, 5))
+            old = sc
+            sc, _ = bvh_build.rebuild_on_device(old, max_leaf_tris=max_leaf, algorithm=algorithm)
+            try:
+                need = check_tree(sc, old)
+                assert need < 32, f"stack need {need}"
+            except AssertionError as e:
+                bad.append(seed)
+                print(f"seed {seed} INVALID TREE ({algorithm}, leaves of {max_leaf}): {e}", flush=True)
+                continue
 
         def request():
             return ob.make_request(c["W"], c["H"], spp=spp, bounces=B, rr=c["rr"], block_y=c["block_y"], block_h=c["block_h"])
@@ -103,7 +120,7 @@ def main():
                 print(f"seed {seed} MISMATCH ({'exact' if exact else 'batched'}): {why}; case {c}; options {options}", flush=True)
         if (seed - first) % 250 == 249:
             print(f"... {seed + 1 - first} seeds, {len(bad)} differing, {rays} rays, {time.time() - t0:.0f} s", flush=True)
-    print(f"fuzz sweep{' (big)' if BIG else ''}{' (single)' if SINGLE else ''}: seeds [{first}, {last}): {last - first - len(set(bad))} equal, {len(set(bad))} differing {sorted(set(bad))[:20]}, {rays} rays traced, {time.time() - t0:.0f} s")
+    print(f"fuzz sweep{' (big)' if BIG else ''}{' (single)' if SINGLE else ''}{' (tree built on the device)' if DEVBVH else ''}: seeds [{first}, {last}): {last - first - len(set(bad))} equal, {len(set(bad))} differing {sorted(set(bad))[:20]}, {rays} rays traced, {time.time() - t0:.0f} s")
     print("kernel symbols the traces ran (traces that used each):")
     for sym, n in sorted(symbols.items(), key=lambda kv: -kv[1]):
         print(f"  {n:6d}  {sym}")
