@@ -38,7 +38,7 @@ def draw_options(rng):
 
 
 FAMILIES = ([(f, "plain") for f in range(0, 8 * PER_TEST, PER_TEST)] + [(f, "big") for f in range(0, 4 * PER_TEST, PER_TEST)]
-            + [(f, "single") for f in range(0, 4 * PER_TEST, PER_TEST)] + [(0, "big-single")])
+            + [(f, "single") for f in range(0, 4 * PER_TEST, PER_TEST)] + [(0, "big-single"), (0, "wide"), (PER_TEST, "wide-single")])
 
 
 @pytest.mark.parametrize("first,family", FAMILIES)
@@ -46,14 +46,15 @@ def test_random_scenes_against_the_oracle(built, oracle, first, family):
     """`big`: the same generator plus a height field of up to 4 600 triangles and / or a swarm of up to 150 instances -- trees that do not fit
     LDS and deep top-level trees, i.e. the general traversal kernels (`k_trace<*, 24, 0 / 1, false>`) instead of the tiny-scene ones.
     `single`: everything baked into ONE mesh under the identity transform -- the single-instance kernels (`k_trace<*, *, *, true>`, the
-    headline's) and, for camera rays, the wave-packet kernel."""
-    big, single = "big" in family, "single" in family
+    headline's) and, for camera rays, the wave-packet kernel.
+    `wide`: the request's edges -- rows of 255-1025 pixels, 1-40 rows, up to 9 samples, 0 to 32 bounces."""
+    big, single, wide = "big" in family, "single" in family, "wide" in family
     from oracle import pybind as ob
     from polaris_amd import scenes
     from random_scenes import random_case
 
     for seed in range(first, first + PER_TEST):
-        sc, c = random_case(seed, big=big, single=single)
+        sc, c = random_case(seed, big=big, single=single, wide=wide)
         B, spp = c["bounces"], c["spp"]
         seeds = scenes.make_seeds(spp, B, base=1000 + seed)
 

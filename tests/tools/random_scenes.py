@@ -130,11 +130,12 @@ def _baked(mesh, xf):
     return S.Mesh(verts, nrm, mesh.uvs, mesh.mat)
 
 
-def random_case(seed: int, big: bool = False, single: bool = False):
+def random_case(seed: int, big: bool = False, single: bool = False, wide: bool = False):
     """-> (scene, dict(W, H, spp, bounces, rr, block_y, block_h)).  `big`: the same scene plus a height field of 300-4 600 triangles and / or
     a swarm of 20-150 instances (drawn from a second stream, so the plain cases keep their scenes): trees that do not fit LDS, deep
     top-level trees -- the general traversal kernels instead of the tiny-scene ones.  `single`: all of it baked into ONE mesh under the
-    identity transform (the kernels specialised for single-instance scenes)."""
+    identity transform (the kernels specialised for single-instance scenes).  `wide`: the request's edges instead of the small frame --
+    rows of 255-1025 pixels, 1-40 rows, up to 9 samples, 0 to 32 bounces."""
     rng = np.random.default_rng(0x5EED0000 + seed)
     rng2 = np.random.default_rng(0xB160000 + seed)
     mt = S.MaterialTable()
@@ -205,4 +206,13 @@ def random_case(seed: int, big: bool = False, single: bool = False):
     if rng.random() < 0.3:
         by = int(rng.integers(0, H - 1))
         bh = int(rng.integers(1, H - by + 1))
-    return scn, dict(W=W, H=H, spp=int(rng.integers(1, 5)), bounces=B, rr=int(rng.integers(0, B + 2)), block_y=by, block_h=bh)
+    case = dict(W=W, H=H, spp=int(rng.integers(1, 5)), bounces=B, rr=int(rng.integers(0, B + 2)), block_y=by, block_h=bh)
+    if wide:   # the edges of the request: rows wider than a workgroup / a chunk / several, single rows, many samples, 0 and up to 32 bounces
+        r3 = np.random.default_rng(0x51DE0000 + seed)
+        W, H = int(r3.choice([255, 256, 257, 300, 511, 513, 1025])), int(r3.choice([1, 2, 3, 7, 16, 40]))
+        scn.set_camera(eye=eye, look=(0.0, 1.0, 0.0), fov=float(r3.uniform(0.5, 1.1)), aspect=W / H)
+        B = int(r3.choice([0, 1, 2, 7, 12, 20, 32]))
+        by = int(r3.integers(0, H))
+        bh = int(r3.integers(1, H - by + 1)) if r3.random() < 0.5 else H - by
+        case = dict(W=W, H=H, spp=int(r3.choice([1, 2, 5, 9])), bounces=B, rr=int(r3.integers(0, B + 2)), block_y=by if bh < H else 0, block_h=bh)
+    return scn, case
