@@ -192,7 +192,7 @@ struct Decoder {
 		const Huffman &hd = dc[c.dcTable], &ha = ac[c.acTable];
 		int s = br.decode(hd);
 		if (s) { if (s > 15) fail("corrupt DC coefficient"); s = extend((int)br.get(s), s); }
-		c.pred += s;
+		c.pred = (int)((uint32_t)c.pred + (uint32_t)s); // (wraps like the library's on a corrupt stream instead of overflowing)
 		b[0] = (int16_t)c.pred;
 		for (int k = 1; k < 64; k++) {
 			const int rs = br.decode(ha), r = rs >> 4;
@@ -209,8 +209,8 @@ struct Decoder {
 	void blockDcFirst(BitReader &br, Component &c, int16_t *b, int al) { // T.81 G.1.2.1
 		int s = br.decode(dc[c.dcTable]);
 		if (s) { if (s > 15) fail("corrupt DC coefficient"); s = extend((int)br.get(s), s); }
-		c.pred += s;
-		b[0] = (int16_t)(c.pred * (1 << al));
+		c.pred = (int)((uint32_t)c.pred + (uint32_t)s);
+		b[0] = (int16_t)((uint32_t)c.pred << al);
 	}
 	void blockDcRefine(BitReader &br, int16_t *b, int al) { if (br.bit()) b[0] |= (int16_t)(1 << al); }
 	void blockAcFirst(BitReader &br, Component &c, int16_t *b, const Scan &sc) { // T.81 G.1.2.2
