@@ -38,7 +38,7 @@ def draw_options(rng):
 
 
 FAMILIES = ([(f, "plain") for f in range(0, 8 * PER_TEST, PER_TEST)] + [(f, "big") for f in range(0, 4 * PER_TEST, PER_TEST)]
-            + [(f, "single") for f in range(0, 4 * PER_TEST, PER_TEST)] + [(0, "big-single"), (0, "wide"), (PER_TEST, "wide-single")])
+            + [(f, "single") for f in range(0, 4 * PER_TEST, PER_TEST)] + [(0, "big-single"), (0, "wide"), (PER_TEST, "wide-single"), (0, "refbvh"), (PER_TEST, "refbvh-big")])
 
 
 @pytest.mark.parametrize("first,family", FAMILIES)
@@ -47,14 +47,16 @@ def test_random_scenes_against_the_oracle(built, oracle, first, family):
     LDS and deep top-level trees, i.e. the general traversal kernels (`k_trace<*, 24, 0 / 1, false>`) instead of the tiny-scene ones.
     `single`: everything baked into ONE mesh under the identity transform -- the single-instance kernels (`k_trace<*, *, *, true>`, the
     headline's) and, for camera rays, the wave-packet kernel.
-    `wide`: the request's edges -- rows of 255-1025 pixels, 1-40 rows, up to 9 samples, 0 to 32 bounces."""
-    big, single, wide = "big" in family, "single" in family, "wide" in family
+    `wide`: the request's edges -- rows of 255-1025 pixels, 1-40 rows, up to 9 samples, 0 to 32 bounces.
+    `refbvh`: the arrays come out of the C++ scene compiler (the reference's builder restated: leaves of up to 10 triangles, which the upload
+    subdivides) -- the trees `polaris render` would hand the tracer."""
+    big, single, wide, refbvh = "big" in family, "single" in family, "wide" in family, "refbvh" in family
     from oracle import pybind as ob
     from polaris_amd import scenes
     from random_scenes import random_case
 
     for seed in range(first, first + PER_TEST):
-        sc, c = random_case(seed, big=big, single=single, wide=wide)
+        sc, c = random_case(seed, big=big, single=single, wide=wide, refbvh=refbvh)
         B, spp = c["bounces"], c["spp"]
         seeds = scenes.make_seeds(spp, B, base=1000 + seed)
 

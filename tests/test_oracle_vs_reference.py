@@ -36,7 +36,7 @@ def test_trace_bit_exact(oracle, ref_pm, name):
         assert np.array_equal(bits(ta["throughput0"][:, :3]), bits(tb["throughput0"][:, :3]))
 
 
-@pytest.mark.parametrize("first,family", [(0, "plain"), (24, "plain"), (48, "plain"), (72, "plain"), (0, "big"), (24, "big"), (0, "single"), (24, "single"), (0, "wide")])
+@pytest.mark.parametrize("first,family", [(0, "plain"), (24, "plain"), (48, "plain"), (72, "plain"), (0, "big"), (24, "big"), (0, "single"), (24, "single"), (0, "wide"), (0, "refbvh")])
 def test_random_scenes_bit_exact(oracle, ref_pm, first, family):
     """Seeded random scenes (tests/tools/random_scenes.py: every BxDF family, material trees of all five operators, the four texture
     formats, instances under non-uniform scales, area / environment lights, odd frames, partial blocks, 1-6 bounces, any RR threshold):
@@ -54,7 +54,7 @@ def test_random_scenes_bit_exact(oracle, ref_pm, first, family):
     compared = 0
     for seed in range(first, first + 24):
         # (big: plus a height field and / or a swarm of instances -- trees beyond the tiny-scene kernels; single: all of it as ONE mesh)
-        sc, c = random_case(seed, big="big" in family, single="single" in family, wide="wide" in family)   # (wide: rows of up to 1025 pixels, 0-32 bounces)
+        sc, c = random_case(seed, big="big" in family, single="single" in family, wide="wide" in family, refbvh="refbvh" in family)   # (refbvh: trees from the C++ scene compiler; wide: rows of up to 1025 pixels, 0-32 bounces)
         # an RGBA32F texture at an offset that is not a multiple of 16 (the reference's compiler aligns to 4, compiler.go bakeTexture): the
         # HOST-compiled kernels load float4 with aligned moves and fault -- a property of this build of the reference, not of the path
         if any(int(m["format"]) == 3 and int(m["data_offset"]) % 16 for m in sc.texture_meta):

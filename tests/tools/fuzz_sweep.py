@@ -25,6 +25,7 @@ from test_gpu_fuzz_parity import counters, draw_options  # noqa: E402
 BIG = "big" in sys.argv[3:]     # the generator's second family: plus a height field and / or a swarm of instances
 SINGLE = "single" in sys.argv[3:]   # ... and its third: everything baked into one mesh under the identity
 WIDE = "wide" in sys.argv[3:]   # ... the request's edges: rows of 255-1025 pixels, 1-40 rows, up to 9 samples, 0-32 bounces
+REFBVH = "refbvh" in sys.argv[3:]   # ... the trees built by the C++ scene compiler (the reference's builder restated)
 DEVBVH = "devbvh" in sys.argv[3:]   # the scene's tree rebuilt by polaris_hip_build_bvh first (SAH or linear, leaves of 1-4 triangles), validated, then traced
 
 
@@ -32,7 +33,7 @@ def against_the_reference(first, last):
     oracle, ref = ob.Oracle("oracle"), ob.Oracle("ref_pm")
     bad, skipped, rays, t0 = [], 0, 0, time.time()
     for seed in range(first, last):
-        sc, c = random_case(seed, big=BIG, single=SINGLE, wide=WIDE)
+        sc, c = random_case(seed, big=BIG, single=SINGLE, wide=WIDE, refbvh=REFBVH)
         if any(int(m["format"]) == 3 and int(m["data_offset"]) % 16 for m in sc.texture_meta):   # (see tests/test_oracle_vs_reference.py)
             skipped += 1
             continue
@@ -50,7 +51,7 @@ def against_the_reference(first, last):
         if not same:
             bad.append(seed)
             print(f"seed {seed} MISMATCH oracle vs compiled reference; case {c}", flush=True)
-    print(f"fuzz sweep{' (big)' if BIG else ''}{' (single)' if SINGLE else ''}{' (wide)' if WIDE else ''}, oracle vs compiled reference: seeds [{first}, {last}): {last - first - skipped - len(bad)} equal, {len(bad)} differing {bad[:20]}, "
+    print(f"fuzz sweep{' (big)' if BIG else ''}{' (single)' if SINGLE else ''}{' (wide)' if WIDE else ''}{' (refbvh)' if REFBVH else ''}, oracle vs compiled reference: seeds [{first}, {last}): {last - first - skipped - len(bad)} equal, {len(bad)} differing {bad[:20]}, "
           f"{skipped} skipped (float4 texture at an offset the host-compiled kernels cannot load), {rays} rays traced, {time.time() - t0:.0f} s")
     return 1 if bad else 0
 
@@ -63,7 +64,7 @@ def main():
     bad, rays, t0 = [], 0, time.time()
     symbols = {}
     for seed in range(first, last):
-        sc, c = random_case(seed, big=BIG, single=SINGLE, wide=WIDE)
+        sc, c = random_case(seed, big=BIG, single=SINGLE, wide=WIDE, refbvh=REFBVH)
         B, spp = c["bounces"], c["spp"]
         seeds = scenes.make_seeds(spp, B, base=1000 + seed)
         if DEVBVH:
@@ -121,7 +122,7 @@ def main():
                 print(f"seed {seed} MISMATCH ({'exact' if exact else 'batched'}): {why}; case {c}; options {options}", flush=True)
         if (seed - first) % 250 == 249:
             print(f"... {seed + 1 - first} seeds, {len(bad)} differing, {rays} rays, {time.time() - t0:.0f} s", flush=True)
-    print(f"fuzz sweep{' (big)' if BIG else ''}{' (single)' if SINGLE else ''}{' (wide)' if WIDE else ''}{' (tree built on the device)' if DEVBVH else ''}: seeds [{first}, {last}): {last - first - len(set(bad))} equal, {len(set(bad))} differing {sorted(set(bad))[:20]}, {rays} rays traced, {time.time() - t0:.0f} s")
+    print(f"fuzz sweep{' (big)' if BIG else ''}{' (single)' if SINGLE else ''}{' (wide)' if WIDE else ''}{' (refbvh)' if REFBVH else ''}{' (tree built on the device)' if DEVBVH else ''}: seeds [{first}, {last}): {last - first - len(set(bad))} equal, {len(set(bad))} differing {sorted(set(bad))[:20]}, {rays} rays traced, {time.time() - t0:.0f} s")
     print("kernel symbols the traces ran (traces that used each):")
     for sym, n in sorted(symbols.items(), key=lambda kv: -kv[1]):
         print(f"  {n:6d}  {sym}")

@@ -130,12 +130,13 @@ def _baked(mesh, xf):
     return S.Mesh(verts, nrm, mesh.uvs, mesh.mat)
 
 
-def random_case(seed: int, big: bool = False, single: bool = False, wide: bool = False):
+def random_case(seed: int, big: bool = False, single: bool = False, wide: bool = False, refbvh: bool = False):
     """-> (scene, dict(W, H, spp, bounces, rr, block_y, block_h)).  `big`: the same scene plus a height field of 300-4 600 triangles and / or
     a swarm of 20-150 instances (drawn from a second stream, so the plain cases keep their scenes): trees that do not fit LDS, deep
     top-level trees -- the general traversal kernels instead of the tiny-scene ones.  `single`: all of it baked into ONE mesh under the
     identity transform (the kernels specialised for single-instance scenes).  `wide`: the request's edges instead of the small frame --
-    rows of 255-1025 pixels, 1-40 rows, up to 9 samples, 0 to 32 bounces."""
+    rows of 255-1025 pixels, 1-40 rows, up to 9 samples, 0 to 32 bounces.  `refbvh`: the arrays come out of the C++ scene compiler
+    (polaris_amd/host/scene_compiler.cpp, the reference's builder restated: what `polaris render` would upload) instead of scenes.py's."""
     rng = np.random.default_rng(0x5EED0000 + seed)
     rng2 = np.random.default_rng(0xB160000 + seed)
     mt = S.MaterialTable()
@@ -196,7 +197,14 @@ def random_case(seed: int, big: bool = False, single: bool = False, wide: bool =
     if single:   # the same geometry as ONE mesh under the identity: the single-instance kernels (the headline's `k_trace<*, 16, 2, true>`)
         meshes, insts = [S.merge([_baked(meshes[mi], xf) for mi, xf in insts])], [(0, np.eye(4))]
     bg = mt.diffuse(_tint(rng, 0.05, 0.5)) if rng.random() < 0.6 else -1
-    scn = S.compile_scene(meshes, insts, mt, max_leaf=int(rng.choice([1, 2, 4])), scene_diffuse=bg, scene_emissive=env, name=f"random-{seed}{'-big' if big else ''}{'-single' if single else ''}")
+    name = f"random-{seed}{'-big' if big else ''}{'-single' if single else ''}{'-refbvh' if refbvh else ''}"
+    max_leaf = int(rng.choice([1, 2, 4]))
+    if refbvh:   # the C++ restatement of the reference's own compiler (asset/compiler: SAH sweep, leaves of up to `min_leaf` triangles) builds the trees
+        from polaris_amd import host_api
+
+        scn = host_api.compile_scene(meshes, insts, mt, scene_diffuse=bg, scene_emissive=env, min_leaf=int(np.random.default_rng(0x1EAF + seed).choice([1, 3, 10])), name=name)
+    else:
+        scn = S.compile_scene(meshes, insts, mt, max_leaf=max_leaf, scene_diffuse=bg, scene_emissive=env, name=name)
     W, H = int(rng.choice([17, 33, 64, 97, 130])), int(rng.choice([9, 24, 40, 71]))
     th, el, dist = rng.uniform(0, 2 * math.pi), rng.uniform(0.15, 0.9), rng.uniform(3.0, 3.9 if closed else 7.0)
     eye = (dist * math.cos(el) * math.cos(th), 0.3 + dist * math.sin(el), dist * math.cos(el) * math.sin(th))
