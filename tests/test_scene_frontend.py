@@ -495,3 +495,32 @@ def test_jpeg_textures_decode_like_libjpeg(tmp_path):
         open(path, "wb").write(whole[:cut])
         with pytest.raises(RuntimeError, match="jpeg"):
             H.texture_load(path)
+
+
+def test_a_jpeg_texture_reaches_the_scene_arrays(tmp_path):
+    """`map_Kd wood.jpg` goes reader -> texture.cpp (JPEG by its signature) -> bakeTexture like any other image: the compiled scene equals the
+    one that names a PNG of the pixels libjpeg decodes from the same file (asset/texure/texture.go:25-150: 8-bit RGB -> Rgba8, grey -> Luminance8)."""
+    Image = pytest.importorskip("PIL.Image")
+
+    rng = np.random.default_rng(5)
+    y, x = np.mgrid[0:24, 0:40]
+    rgb = np.clip(np.stack([x * 6, y * 10, (x + y) * 4], -1) + rng.integers(-20, 20, (24, 40, 3)), 0, 255).astype(np.uint8)
+    for mode, fmt in (("RGB", T.TEX_RGBA8), ("L", T.TEX_L8)):
+        d = tmp_path / mode
+        d.mkdir()
+        pic = Image.fromarray(rgb if mode == "RGB" else np.ascontiguousarray(rgb[..., 1]), mode)
+        pic.save(str(d / "wood.jpg"), "JPEG", quality=80, subsampling=2 if mode == "RGB" else -1)
+        F.write_png(str(d / "wood.png"), np.asarray(Image.open(str(d / "wood.jpg"))))
+        scenes_read = []
+        for ext in ("jpg", "png"):
+            (d / f"s_{ext}.mtl").write_text(f"newmtl wood\nmap_Kd wood.{ext}\nnewmtl lamp\nKe 5 5 5\n")
+            (d / f"s_{ext}.obj").write_text(f"mtllib s_{ext}.mtl\ncamera_fov 0.7\ncamera_eye 0 1 3\ncamera_look 0 0 0\ncamera_up 0 1 0\n"
+                                            "v -1 0 1\nv 1 0 1\nv 1 0 -1\nv -1 0 -1\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nusemtl wood\nf 1/1 2/2 3/3 4/4\n"
+                                            "v -1 2 -1\nv 1 2 -1\nv 1 2 1\nv -1 2 1\nusemtl lamp\nf 5 6 7 8\n")
+            sc = H.read_scene(str(d / f"s_{ext}.obj"), aspect=1.0)
+            assert sc.warnings == [], sc.warnings
+            scenes_read.append(sc)
+        a, b = scenes_read
+        assert list(a.texture_meta["format"]) == [fmt] and (int(a.texture_meta["width"][0]), int(a.texture_meta["height"][0])) == (40, 24)
+        for name in ("texture_meta", "texture_data", "material_nodes", "vertices", "uvs", "material_index", "bvh_nodes", "emissives"):
+            assert np.array_equal(getattr(a, name), getattr(b, name)), (mode, name)
