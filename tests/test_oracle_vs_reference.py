@@ -55,10 +55,6 @@ def test_random_scenes_bit_exact(oracle, ref_pm, first, family):
     for seed in range(first, first + 24):
         # (big: plus a height field and / or a swarm of instances -- trees beyond the tiny-scene kernels; single: all of it as ONE mesh)
         sc, c = random_case(seed, big="big" in family, single="single" in family, wide="wide" in family, refbvh="refbvh" in family)   # (refbvh: trees from the C++ scene compiler; wide: rows of up to 1025 pixels, 0-32 bounces)
-        # an RGBA32F texture at an offset that is not a multiple of 16 (the reference's compiler aligns to 4, compiler.go bakeTexture): the
-        # HOST-compiled kernels load float4 with aligned moves and fault -- a property of this build of the reference, not of the path
-        if any(int(m["format"]) == 3 and int(m["data_offset"]) % 16 for m in sc.texture_meta):
-            continue
         B = c["bounces"]
         seeds = scenes.make_seeds(c["spp"], B, base=1000 + seed)
 
@@ -71,7 +67,7 @@ def test_random_scenes_bit_exact(oracle, ref_pm, first, family):
         assert list(sa.rays_per_bounce[:B]) == list(sb.rays_per_bounce[:B]) and list(sa.occl_per_bounce[:B]) == list(sb.occl_per_bounce[:B]), (seed, c)
         assert (sa.unoccluded, sa.shaded_hits, sa.shaded_misses) == (sb.unoccluded, sb.shaded_hits, sb.shaded_misses), (seed, c)
         compared += 1
-    assert compared >= 16
+    assert compared == 24
 
 
 def test_reference_emitter_index_quirk(oracle, ref_pm):
