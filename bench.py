@@ -380,6 +380,12 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # ONE line on the job's stdout, the JSON line of rank 0: whatever a library prints there (gloo announces every rank's connections on
+    # stdout, from every rank) goes to stderr instead -- file descriptor 1 is pointed at 2 before anything is loaded, and the line is
+    # written to a duplicate of the original descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} launched with WORLD_SIZE={world}: they must agree")
 
@@ -850,7 +856,7 @@ def main() -> None:
             from PIL import Image
 
             Image.fromarray(tr.read_framebuffer()[..., :3]).save(args.save_png)
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()                             # every rank's ring stays mapped until the primary has closed its mappings
     if px is not None:

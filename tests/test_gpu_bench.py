@@ -97,6 +97,7 @@ def test_bench_two_ranks_bare_launch_and_frame(built, tmp_path):
            "--opt", "exact_accumulate=1", "--save-accumulator", acc]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
+    assert len(out.stdout.splitlines()) == 1, out.stdout[:600]     # ONE line on stdout, whatever gloo / the runtime print (they go to stderr)
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["exchange"].startswith("hip-ipc"), d["config"]["exchange"]      # the default: peer reads, no fallback
