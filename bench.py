@@ -15,8 +15,8 @@ tracer/opencl/resources.go:108-124) -- is a PEER READ, as in the reference (whos
 OpenCL context, renderer/default.go:225-229): every rank publishes HIP-IPC handles of its trace
 accumulator ring once, rank 0 maps them and its merge stream runs the aggregate kernel straight over the
 peer-mapped rows (polaris_hip_merge_ipc; xGMI).  No RCCL on the data path ("independent tiles, so no
-RCCL"): torch.distributed (gloo) carries control only -- the handles at set-up and 32 bytes per rank and
-frame.  If a mapping cannot be opened the run falls back, in the same processes, to point-to-point strip
+RCCL"): control only travels otherwise -- the handles at set-up over torch.distributed (gloo), 32 bytes per rank and
+frame through a shared-memory mailbox (ranks of one host; a gloo all_gather where they cannot map one).  If a mapping cannot be opened the run falls back, in the same processes, to point-to-point strip
 transfers (`--exchange strips`: backend nccl = RCCL); `config.exchange` names which ran.  The block
 scheduler for N > 1 is `naive` (what `polaris render` passes, cmd/render.go:65); the same run then times
 the perfect scheduler (tracer/scheduler.go:50-80) as a second region -> `config.perfect_scheduler`.
@@ -336,6 +336,8 @@ def main() -> None:
                     "tests/test_distributed_cpu.py, here through the real IPC mappings)")
     ap.add_argument("--no-second-scheduler", action="store_true", help="N > 1: skip the second timed region (the perfect scheduler when --scheduler naive)")
     ap.add_argument("--same-device", action="store_true", help="testing aid: every rank uses GPU 0 (needs --backend gloo)")
+    ap.add_argument("--control", default="shm", choices=("shm", "gloo"), help="N > 1, --exchange ipc: the per-frame control message (32 bytes per rank) through a "
+                    "shared-memory mailbox (ranks of one host; falls back to gloo where it cannot be mapped) or always as a gloo all_gather")
     ap.add_argument("--control-timeout", type=float, default=120.0, help="N > 1: timeout in seconds of the gloo control group (set-up exchange, 32 bytes per rank "
                     "and frame): a rank that dies surfaces as an error on the others within this time")
     ap.add_argument("--test-setup-failure", type=int, default=-1, help="testing aid: rank R fails during set-up (as a tracer that cannot be created would); every "
@@ -507,11 +509,13 @@ def main() -> None:
                 def refuse_export(depth):
                     raise RuntimeError("hipIpcGetMemHandle: refused (--test-ipc-failure export)")
                 port.export = refuse_export
-            px = PeerExchange(dist, rank, world, W, H, port, scheduler=args.scheduler)
+            px = PeerExchange(dist, rank, world, W, H, port, scheduler=args.scheduler, control=args.control, control_timeout_s=args.control_timeout)
             if px.setup():
                 exchange = (f"hip-ipc: rank 0's merge stream reads every rank's rows through an IPC mapping of its trace accumulator ring "
-                            f"(depth {px.depth}), one frame behind the tracing; control = 32 B per rank and frame over gloo; no RCCL")
+                            f"(depth {px.depth}), one frame behind the tracing; control = 32 B per rank and frame "
+                            f"{'through a shared-memory mailbox' if px.control == 'shm' else 'over gloo'}; no RCCL")
                 detail["mode"] = "hip-ipc"
+                detail["control"] = px.control      # the 32 bytes per rank and frame: "shm" (a mailbox in /dev/shm: ranks of one host) or "gloo"
                 if rank == 0:   # what every mapping really is: the peer's GPU by bus id, local or across xGMI (polaris_hip_peer_info)
                     detail["peers"] = [{"rank": r, **tr.peer_info(p)} for r, p in sorted(px.peers().items())]
             else:

@@ -206,7 +206,7 @@ def _synthetic_frame(f, Hh):
     return (np.float32(f) * 4096.0 + y * 32.0 + x * 0.25 + c * 0.0625).astype(np.float32)
 
 
-def _fuzz_worker(rank, world, port, out_path, scheduler, Hh, frames):
+def _fuzz_worker(rank, world, port, out_path, scheduler, Hh, frames, control="shm"):
     """PeerExchange under a RANDOMISED schedule: every rank sleeps a seeded random time before and after
     every "Trace" of every frame (0 - 20 ms, most of them short, so that any rank may be the one running ahead or lagging in any
     frame), the ring is poisoned at the start of every Trace, and with the perfect scheduler the made-up times are random too, so the
@@ -223,8 +223,9 @@ def _fuzz_worker(rank, world, port, out_path, scheduler, Hh, frames):
 
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     shm = ShmPort(rank, W, Hh)
-    px = PeerExchange(dist, rank, world, W, Hh, shm, scheduler=scheduler)
+    px = PeerExchange(dist, rank, world, W, Hh, shm, scheduler=scheduler, control=control)
     assert px.setup()
+    assert px.control == control, (px.control, control)     # (the ranks of this test share a host: the mailbox must have been mapped)
     rng = random.Random(20261004 + 7919 * rank)
     delays = (0.0, 0.0, 0.0, 0.0005, 0.001, 0.002, 0.004, 0.008, 0.02)
     pending, all_rows = [], []
@@ -389,18 +390,22 @@ def test_peer_exchange_refuses_a_ring_that_is_too_short():
         PeerExchange(None, 0, 2, 8, 8, None, depth=2)
 
 
-@pytest.mark.parametrize("scheduler", ["naive", "perfect"])
-def test_eight_rank_exchange_under_random_per_frame_delays(built, tmp_path, scheduler):
+@pytest.mark.parametrize("scheduler,control", [("naive", "shm"), ("perfect", "shm"), ("perfect", "gloo")])
+def test_eight_rank_exchange_under_random_per_frame_delays(built, tmp_path, scheduler, control):
     """100 frames x 8 ranks, a seeded random delay per rank PER FRAME on both sides of every Trace (not one rank held back by a
     constant): whoever runs ahead or lags changes from frame to frame, so a ring slot reused one frame too early, a merge from the
     wrong slot, or ranks disagreeing about the rows would show as NaNs (the poisoned slot) or as another frame's pattern.  Every
     assembled frame must be exactly the frame's pattern (renderer/default.go:127-136,188-191: a worker per tracer, merges as they
-    finish)."""
+    finish).  The per-frame message travels through the shared-memory mailbox (ranks of one host: the default) or the gloo all_gather."""
+    import glob
+
     import torch.multiprocessing as mp
 
     world, Hh, frames = 8, 61, 100
     out = str(tmp_path / "fuzz.npy")
-    mp.spawn(_fuzz_worker, args=(world, _free_port(), out, scheduler, Hh, frames), nprocs=world, join=True)
+    before = set(glob.glob("/dev/shm/polaris_ctl_*"))
+    mp.spawn(_fuzz_worker, args=(world, _free_port(), out, scheduler, Hh, frames, control), nprocs=world, join=True)
+    assert set(glob.glob("/dev/shm/polaris_ctl_*")) <= before          # the primary removed its mailbox
     got = np.load(out)
     all_rows = np.load(out + ".rows.npy").tolist()
     assert got.shape == (frames, Hh, W, 4) and np.isfinite(got).all()
@@ -409,6 +414,33 @@ def test_eight_rank_exchange_under_random_per_frame_delays(built, tmp_path, sche
         assert len({tuple(r) for r in all_rows}) > 10          # the rows really moved
     for f in range(frames):
         assert np.array_equal(got[f], _synthetic_frame(f, Hh)), f
+
+
+def test_mailbox_records_timeouts_and_torn_reads(tmp_path):
+    """ShmMailbox on its own (two views of one file in this process): a record is there once its sequence word is, a record whose check
+    word does not fit (a torn read on a weakly ordered machine) counts as not there, slots are reused four posts later, and a wait for a
+    rank that never posts raises after the timeout instead of hanging."""
+    from polaris_amd.distributed import ShmMailbox
+
+    path = str(tmp_path / "box")
+    a = ShmMailbox(0, 2, path, True, timeout_s=0.3)
+    b = ShmMailbox(1, 2, path, False, timeout_s=0.3)
+    for seq in range(11):                                   # wraps the four slots twice
+        a.post(seq, (seq, 1, 30 + seq, 10 ** 12 + seq))
+        b.post(seq, (seq, 2, 31 - seq, 7))
+        assert a.wait(seq) == b.wait(seq) == [[seq, 1, 30 + seq, 10 ** 12 + seq], [seq, 2, 31 - seq, 7]]
+    a.post(11, (11, 0, 1, 2))
+    with pytest.raises(RuntimeError, match=r"nothing from rank\(s\) \[1\]"):
+        a.wait(11)
+    b.post(11, (11, 0, 3, 4))
+    b.a[11 % 4, 1, 2] = 99                                  # payload and check word no longer agree
+    with pytest.raises(RuntimeError, match="nothing from rank"):
+        a.wait(11)
+    b.post(11, (11, 0, 3, 4))
+    assert a.wait(11) == [[11, 0, 1, 2], [11, 0, 3, 4]]
+    b.close()
+    a.close()
+    assert not os.path.exists(path)
 
 
 def test_device_for_rank_covers_the_launch_shapes():

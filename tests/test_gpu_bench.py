@@ -123,6 +123,7 @@ def _one_gpu_shared_by(d, ranks, chosen_by, branch="ipc-local"):
     pr = x["proof"]
     assert pr.get("all_equal") is True and pr["blocks_equal"] == [True] * ranks and pr["covered_rows"] == sum(pr["rows"]) == cfg["frame"][1], pr
     if x["mode"] == "hip-ipc":
+        assert x["control"] == "shm"     # the ranks of one box: the per-frame message goes through the shared-memory mailbox
         assert [p["rank"] for p in x["peers"]] == list(range(1, ranks))
         assert all(p["branch"] == branch and p["same_device"] == 1 and p["pci_bus_id"] == cfg["devices"][0]["pci_bus_id"] for p in x["peers"]), x["peers"]
         mc = x["merge_counts"]
@@ -211,9 +212,11 @@ def test_bench_two_ranks_perfect_scheduler(built, tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     small = ["--width", "128", "--height", "97", "--spp", "8", "--steps", "4", "--warmup", "3"]
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *small, "--same-device", "--no-cpu-baseline", "--no-kernel-timers",
-           "--scheduler", "perfect", "--no-second-scheduler", "--opt", "exact_accumulate=1", "--save-accumulator", acc]
+           "--scheduler", "perfect", "--no-second-scheduler", "--opt", "exact_accumulate=1", "--save-accumulator", acc,
+           "--control", "gloo"]    # (the per-frame message as a gloo all_gather: what ranks that cannot map a common /dev/shm file fall back to)
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
+    assert json.loads(out.stdout.splitlines()[-1])["config"]["exchange_detail"]["control"] == "gloo"
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     rows = d["config"]["rows_last_frame"]
     assert d["config"]["scheduler"] == "perfect" and "perfect scheduler" in d["config"]["workload"] and sum(rows) == 97 and min(rows) >= 1
