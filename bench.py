@@ -576,6 +576,7 @@ def main() -> None:
     rows_log = []
 
     own_work = [0.0]                               # seconds of this rank's OWN work in the current frame (what the scheduler balances)
+    trace_s = [0.0]                                # seconds this rank spent inside Trace over the timed frames (config.frame_loop)
 
     def finish_frame(ticket):
         if px is not None:
@@ -621,6 +622,8 @@ def main() -> None:
             frame_no[0] += 1
         t_own = time.perf_counter()
         tr.Trace(req, fseeds)                      # Trace (tracer.go:194-247)
+        if count:
+            trace_s[0] += time.perf_counter() - t_own
         if delay_rank == rank:
             time.sleep(delay_s)
         if jitter is not None:
@@ -666,6 +669,8 @@ def main() -> None:
         return time.perf_counter() - t0
 
     elapsed = timed_region(args.steps, args.warmup, True)
+    # rank 0's frame loop: how much of a frame is the synchronous Trace, how much everything around it (merge / exchange / tone-map / Python)
+    frame_loop = {"trace_ms_per_frame": trace_s[0] / args.steps * 1e3, "other_ms_per_frame": (elapsed - trace_s[0]) / args.steps * 1e3, "of": "rank 0, first timed region"}
     if fb is not None:
         fb.drain()
     main_rows = list(rows)                         # (the second region below schedules its own)
@@ -747,7 +752,7 @@ def main() -> None:
                        # which physical GPU every rank traced on (PCI bus id + UUID: device indices are per process) and how many DISTINCT ones
                        # took part: n_gpus is the launch's WORLD_SIZE, distinct_gpus is what the hardware says
                        "devices": identities, "distinct_gpus": distinct_gpus,
-                       "exchange_detail": {**detail, "merge_counts": tr.merge_counts()},
+                       "exchange_detail": {**detail, "merge_counts": tr.merge_counts()}, "frame_loop": frame_loop,
                        "rows_first_timed_frame": rows_log[0] if rows_log else None, "rows_last_frame": rows_log[-1] if rows_log else None,
                        "bvh": "as compiled with the scene" if bvh_info is None else {"built_on_device": bvh_info}, "exchange": exchange, "perfect_scheduler" if (second or {}).get("scheduler") == "perfect" else "second_scheduler": second,
                        "frame": [W, H], "spp": spp, "bounces": B, "rays_per_frame": rays // args.steps,
