@@ -216,9 +216,11 @@ class SchedulerFeedback:
 
 class ShmMailbox:
     """The per-frame control message of `PeerExchange` -- four integers per rank -- through SHARED MEMORY instead of a gloo all_gather, for
-    ranks that live on one host (the launch contract: N GPUs of ONE node).  A torch.distributed collective costs the calling thread
-    ~0.2 ms to start and ~0.05 ms to complete however small it is; next to an 8-GPU headline frame of ~1.8 ms per rank that is a tenth
-    of the frame, paid on every rank, in sequence with the Trace.  Here a post is three numpy stores and a completed wait three loads.
+    ranks that live on one host (the launch contract: N GPUs of ONE node).  What an asynchronous torch.distributed collective costs the
+    calling thread depends on the host: ~18 us to start and ~10 us to complete on the GPU box's EPYC, ~0.2 ms + ~0.05 ms in an 8-CPU
+    container -- next to an 8-GPU headline frame of ~1.8 ms per rank, in sequence with the Trace on every rank
+    (profiles/r06_exchange_overhead.txt).  Here a post is three numpy stores (1.4 us) and a completed wait three loads (8 us), with no
+    worker thread of a communication library in between.
 
     One file in /dev/shm, created by the primary and mapped by every rank: SLOTS x world records of six int64 --
     [v0, v1, v2, v3, check, sequence + 1].  post(seq, values) writes the payload and the check word, THEN the sequence word (x86 keeps
