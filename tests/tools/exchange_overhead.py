@@ -2,7 +2,8 @@
     python -m torch.distributed.run --standalone --local-addr 127.0.0.1 --nnodes=1 --nproc-per-node 8 tests/tools/exchange_overhead.py shm|gloo
 Every rank runs the frame loop of bench.py around a stand-in for the Trace that takes exactly 1.8 ms (an 8-GPU headline block) without
 holding the GIL-free time hostage (sleep + a short spin), with a do-nothing tracer port; prints the wall time per frame and what post()
-and finish() took."""
+and finish() took.  (On a gpurun box keep it to 4 ranks: every process that imports torch counts as a user of the GPU there, and the box
+admits six.)"""
 import datetime
 import os
 import sys
